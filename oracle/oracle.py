@@ -1,0 +1,124 @@
+"""ctypes binding of the C oracle (oracle/libxfeat_oracle.so).
+
+TEST INFRASTRUCTURE ONLY -- see oracle/xfeat_oracle.h.  Imported by tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg; never by xfeatslam_amd/.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_DIR, "libxfeat_oracle.so")
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+
+T = dict(X=0, XSTAT=1, SKIP_POOL=2, XUNFOLD=3, B2IN=4, FUSE_IN=5, FEATS=6, M1N=7, H1=8, K1H=9,
+         LOGITS=10, RAW0=16, STAT0=48, SEL=80, CAND=81)
+NUM_LAYERS = 23
+LAYER_COUT = [4, 8, 8, 24, 24, 24, 64, 64, 64, 64, 64, 64, 128, 128, 128, 64, 64, 64, 64, 64, 64, 64, 64]
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_DIR, "xfeat_oracle.c")
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _DIR, "-s", "-B"])
+    return _LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB):
+            build()
+        L = C.CDLL(_LIB)
+        L.xfo_create.restype = C.c_void_p
+        L.xfo_create.argtypes = [C.c_void_p, C.c_size_t]
+        L.xfo_destroy.argtypes = [C.c_void_p]
+        L.xfo_set_threads.argtypes = [C.c_int]
+        L.xfo_get_threads.restype = C.c_int
+        L.xfo_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                  C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.xfo_get_tensor.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_int64)]
+        L.xfo_match_mnn.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+        L.xfo_distance_i32.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        L.xfo_descriptor_distance.argtypes = [C.c_void_p, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def set_threads(n: int) -> None:
+    lib().xfo_set_threads(int(n))
+
+
+def get_threads() -> int:
+    return int(lib().xfo_get_threads())
+
+
+class Oracle:
+    """CPU restatement of XFextractor::operator() (reference src/XFextractor.cc:250-356)."""
+
+    def __init__(self, blob: bytes):
+        self._blob = blob
+        self._h = lib().xfo_create(blob, len(blob))
+        if not self._h:
+            raise RuntimeError("oracle: bad weight blob")
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().xfo_destroy(self._h)
+            self._h = None
+
+    def extract(self, gray: np.ndarray, nfeatures: int = 4096, lapping=(0, 0)):
+        gray = np.ascontiguousarray(gray, dtype=np.uint8)
+        H, W = gray.shape
+        kps = np.zeros(nfeatures, KP_DTYPE)
+        desc = np.zeros((nfeatures, 64), np.float32)
+        nv, mono = C.c_int(0), C.c_int(0)
+        rc = lib().xfo_extract(self._h, gray.ctypes.data, H, W, nfeatures, int(lapping[0]), int(lapping[1]),
+                               kps.ctypes.data, desc.ctypes.data, C.byref(nv), C.byref(mono))
+        if rc != 0:
+            raise RuntimeError(f"xfo_extract rc={rc}")
+        return kps, desc, nv.value, mono.value
+
+    def tensor(self, tid: int) -> np.ndarray:
+        p = C.POINTER(C.c_float)()
+        n = C.c_int64(0)
+        if lib().xfo_get_tensor(self._h, tid, C.byref(p), C.byref(n)) != 0:
+            raise KeyError(tid)
+        if n.value == 0:
+            return np.zeros(0, np.float32)
+        return np.ctypeslib.as_array(p, shape=(n.value,)).copy()
+
+
+def match_mnn(d1: np.ndarray, d2: np.ndarray, min_cossim: float = -1.0):
+    d1 = np.ascontiguousarray(d1, np.float32)
+    d2 = np.ascontiguousarray(d2, np.float32)
+    n = max(1, min(len(d1), len(d2)))
+    i1 = np.zeros(n, np.int32); i2 = np.zeros(n, np.int32); dist = np.zeros(n, np.float32)
+    nm = C.c_int(0)
+    lib().xfo_match_mnn(d1.ctypes.data, len(d1), d2.ctypes.data, len(d2), float(min_cossim),
+                        i1.ctypes.data, i2.ctypes.data, dist.ctypes.data, C.byref(nm))
+    k = nm.value
+    return i1[:k].copy(), i2[:k].copy(), dist[:k].copy()
+
+
+def distance_i32(d1: np.ndarray, d2: np.ndarray) -> np.ndarray:
+    d1 = np.ascontiguousarray(d1, np.float32)
+    d2 = np.ascontiguousarray(d2, np.float32)
+    out = np.zeros((len(d1), len(d2)), np.int32)
+    lib().xfo_distance_i32(d1.ctypes.data, len(d1), d2.ctypes.data, len(d2), out.ctypes.data)
+    return out
+
+
+def descriptor_distance(a: np.ndarray, b: np.ndarray) -> int:
+    a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32)
+    return int(lib().xfo_descriptor_distance(a.ctypes.data, b.ctypes.data))

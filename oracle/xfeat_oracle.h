@@ -1,0 +1,89 @@
+/*
+ * xfeat_oracle.h -- CPU oracle for the XFeat extraction + descriptor matching hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library, and
+ * only as the checker.  The shipped path is the HIP library behind include/xfeat_hip.h.
+ *
+ * PARITY STATUS: "parity unpinned" by execution of the reference.  The reference
+ * (udaysankar01/xfeatSLAM) has no tests or golden vectors for this path,
+ * is C++ (not importable), and its two source files include <opencv2/...> headers that
+ * this image does not have, so it cannot be compiled here without writing stand-in
+ * headers (not allowed).  What pins this restatement instead:
+ *   (1) oracle/torch_restatement.py calls, line by line, the same libtorch/ATen CPU
+ *       operators the reference calls (conv2d, batch_norm(training), instance_norm,
+ *       avg_pool2d, interpolate, softmax, max_pool2d, nonzero, grid_sample, argsort,
+ *       normalize) and tests/test_oracle_vs_torch.py checks this C code against it;
+ *   (2) golden vectors produced by (1) are committed under tests/golden/.
+ * ORBmatcher::match has no compiled definition in the reference at all (dead code,
+ * src/ORBmatcher.cc:340-405); DescriptorDistance calls cv::norm from OpenCV 4.5.4
+ * (un-vendored).  Both are restated from the call sites.
+ *
+ * Tensor ids below are shared with the HIP library's debug accessor (XFH_T_* in
+ * include/xfeat_hip.h) so that tests can diff every intermediate.  All image-like
+ * tensors are NHWC float32.
+ */
+#ifndef XFEAT_ORACLE_H
+#define XFEAT_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct xfo_ctx xfo_ctx;
+
+/* mirrors cv::KeyPoint (28 bytes): pt.x, pt.y, size, angle, response, octave, class_id */
+typedef struct {
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+} xfo_keypoint;
+
+enum {
+    XFO_T_X = 0,        /* [H][W]        image/255 after the resize to multiples of 32 */
+    XFO_T_XSTAT = 1,    /* [2]           InstanceNorm mean, rstd                       */
+    XFO_T_SKIP_POOL = 2,/* [H/4][W/4]    AvgPool4x4 of the normalised image            */
+    XFO_T_XUNFOLD = 3,  /* [H/8][W/8][64] unfold2d(xhat, 8)                             */
+    XFO_T_B2IN = 4,     /* [H/4][W/4][24] x1 + skip1(x)                                 */
+    XFO_T_FUSE_IN = 5,  /* [H/8][W/8][64] x3 + up(x4) + up(x5)                          */
+    XFO_T_FEATS = 6,    /* [H/8][W/8][64] block_fusion output                           */
+    XFO_T_M1N = 7,      /* [H/8][W/8][64] F::normalize(feats, dim=1)                    */
+    XFO_T_H1 = 8,       /* [H/8][W/8]    heatmap (sigmoid)                             */
+    XFO_T_K1H = 9,      /* [H][W]        keypoint heatmap after softmax+depth-to-space  */
+    XFO_T_LOGITS = 10,  /* [H/8][W/8][65] keypoint logits (oracle only)                 */
+    XFO_T_RAW0 = 16,    /* +i: raw conv output of BasicLayer i (before BN), i = 0..22   */
+    XFO_T_STAT0 = 48,   /* +i: [2][C]  batch mean[C] then rstd[C] of BasicLayer i       */
+    XFO_T_SEL = 80,     /* [N][3]      x, y, score of the top-N list, descending score  */
+    XFO_T_CAND = 81     /* [C][3]      x, y, score of every NMS candidate, row-major    */
+};
+
+#define XFO_NUM_LAYERS 23
+
+xfo_ctx* xfo_create(const void* weight_blob, size_t nbytes);
+void xfo_destroy(xfo_ctx* c);
+void xfo_set_threads(int n); /* OpenMP threads for the heavy loops (<=0: library default) */
+int xfo_get_threads(void);
+
+/* XFextractor::operator() (reference src/XFextractor.cc:250-356).
+ * gray: dense H x W u8.  kps: nfeatures records, desc: nfeatures x 64 floats.
+ * returns 0, or -1 for an empty image (H*W == 0), -2 for an unsupported size. */
+int xfo_extract(xfo_ctx* c, const uint8_t* gray, int H, int W, int nfeatures, int lap0, int lap1,
+                xfo_keypoint* kps, float* desc, int* n_valid, int* mono_index);
+
+/* intermediate of the last xfo_extract call; pointer stays valid until the next call */
+int xfo_get_tensor(xfo_ctx* c, int id, const float** ptr, int64_t* count);
+
+/* ORBmatcher::match, intended semantics of the dead code (src/ORBmatcher.cc:340-405). */
+int xfo_match_mnn(const float* d1, int n1, const float* d2, int n2, float min_cossim,
+                  int* idx1, int* idx2, float* dist, int* n_matches);
+
+/* dense form of ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:2242-2250) */
+int xfo_distance_i32(const float* d1, int n1, const float* d2, int n2, int32_t* out);
+int xfo_descriptor_distance(const float* a, const float* b);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,157 @@
+"""Canonical XFeat weight set for the hot path: tensor table, deterministic synthetic
+generator, flat blob (de)serialiser and a state_dict converter.
+
+The 31 tensors are the ones `XFeatModel::forward` touches (reference
+`src/XFeat.cc:30-122`, names as libtorch registers them).  The
+886 848-float `fine_matcher` MLP (`XFeat.cc:94-108`) and every BatchNorm buffer are
+not part of the path (BatchNorm runs on batch statistics) and are not
+stored.
+
+Blob layout (little endian), consumed by both `oracle/xfeat_oracle.c` and
+`xfeatslam_amd/csrc/weights.cpp`:
+
+    char     magic[8]   = "XFHWGT01"
+    uint32   n_tensors
+    uint32   reserved
+    entry[n_tensors]:  char name[48]; uint32 ndim; uint32 dims[4]; uint64 offset_floats
+    float32  data[...]            (tensors in PyTorch OIHW order, C-contiguous)
+"""
+from __future__ import annotations
+
+import struct
+from collections import OrderedDict
+
+import numpy as np
+
+MAGIC = b"XFHWGT01"
+
+# (name, shape) in canonical order -- OIHW for conv weights.
+TENSORS = [
+    ("skip1.1.weight", (24, 1, 1, 1)),
+    ("skip1.1.bias", (24,)),
+    ("block1.0.layer.0.weight", (4, 1, 3, 3)),
+    ("block1.1.layer.0.weight", (8, 4, 3, 3)),
+    ("block1.2.layer.0.weight", (8, 8, 3, 3)),
+    ("block1.3.layer.0.weight", (24, 8, 3, 3)),
+    ("block2.0.layer.0.weight", (24, 24, 3, 3)),
+    ("block2.1.layer.0.weight", (24, 24, 3, 3)),
+    ("block3.0.layer.0.weight", (64, 24, 3, 3)),
+    ("block3.1.layer.0.weight", (64, 64, 3, 3)),
+    ("block3.2.layer.0.weight", (64, 64, 1, 1)),
+    ("block4.0.layer.0.weight", (64, 64, 3, 3)),
+    ("block4.1.layer.0.weight", (64, 64, 3, 3)),
+    ("block4.2.layer.0.weight", (64, 64, 3, 3)),
+    ("block5.0.layer.0.weight", (128, 64, 3, 3)),
+    ("block5.1.layer.0.weight", (128, 128, 3, 3)),
+    ("block5.2.layer.0.weight", (128, 128, 3, 3)),
+    ("block5.3.layer.0.weight", (64, 128, 1, 1)),
+    ("block_fusion.0.layer.0.weight", (64, 64, 3, 3)),
+    ("block_fusion.1.layer.0.weight", (64, 64, 3, 3)),
+    ("block_fusion.2.weight", (64, 64, 1, 1)),
+    ("block_fusion.2.bias", (64,)),
+    ("heatmap_head.0.layer.0.weight", (64, 64, 1, 1)),
+    ("heatmap_head.1.layer.0.weight", (64, 64, 1, 1)),
+    ("heatmap_head.2.weight", (1, 64, 1, 1)),
+    ("heatmap_head.2.bias", (1,)),
+    ("keypoint_head.0.layer.0.weight", (64, 64, 1, 1)),
+    ("keypoint_head.1.layer.0.weight", (64, 64, 1, 1)),
+    ("keypoint_head.2.layer.0.weight", (64, 64, 1, 1)),
+    ("keypoint_head.3.weight", (65, 64, 1, 1)),
+    ("keypoint_head.3.bias", (65,)),
+]
+N_PARAMS = sum(int(np.prod(s)) for _, s in TENSORS)  # 657 910
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def splitmix64(x: np.ndarray) -> np.ndarray:
+    """Counter-based 64-bit mixer (Steele/Lea/Flood splitmix64 finaliser), vectorised."""
+    with np.errstate(over="ignore"):
+        z = (x + np.uint64(0x9E3779B97F4A7C15)) & _M64
+        z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & _M64
+        z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & _M64
+        return z ^ (z >> np.uint64(31))
+
+
+def uniform01(seed: int, stream: int, n: int) -> np.ndarray:
+    """n float64 values in [0,1), reproducible from (seed, stream) alone."""
+    base = splitmix64(np.array([seed], dtype=np.uint64))[0] ^ splitmix64(
+        np.array([stream + 0x51ED], dtype=np.uint64))[0]
+    with np.errstate(over="ignore"):
+        ctr = (np.arange(n, dtype=np.uint64) + base) & _M64
+    bits = splitmix64(ctr) >> np.uint64(11)
+    return bits.astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+def make_synthetic(seed: int = 1234, kp_logit_gain: float = 1.0) -> "OrderedDict[str, np.ndarray]":
+    """Deterministic stand-in for the absent `weights/xfeat.pt`.
+
+    conv weights/biases ~ U(-1/sqrt(fan_in), +1/sqrt(fan_in)) (the libtorch Conv2d default
+    bound).  `kp_logit_gain` scales `keypoint_head.3.weight`; random-weight nets give a
+    nearly flat 65-way softmax (few NMS candidates), gain≈6 produces a "dense" frame
+    with more than 4096 candidates at VGA so the top-k cut is exercised.
+    """
+    out: "OrderedDict[str, np.ndarray]" = OrderedDict()
+    for i, (name, shape) in enumerate(TENSORS):
+        if name.endswith("bias"):
+            wshape = dict(TENSORS)[name[:-4] + "weight"]
+            fan_in = int(np.prod(wshape[1:]))
+        else:
+            fan_in = int(np.prod(shape[1:]))
+        bound = 1.0 / np.sqrt(fan_in)
+        u = uniform01(seed, i, int(np.prod(shape)))
+        w = ((2.0 * u - 1.0) * bound).astype(np.float32).reshape(shape)
+        if name == "keypoint_head.3.weight":
+            w = (w * np.float32(kp_logit_gain)).astype(np.float32)
+        out[name] = w
+    return out
+
+
+def pack_blob(weights: "dict[str, np.ndarray]") -> bytes:
+    entries = []
+    data = []
+    off = 0
+    for name, shape in TENSORS:
+        a = np.ascontiguousarray(weights[name], dtype=np.float32)
+        if tuple(a.shape) != tuple(shape):
+            raise ValueError(f"{name}: shape {a.shape} != {shape}")
+        dims = list(shape) + [1] * (4 - len(shape))
+        entries.append(struct.pack("<48sI4IQ", name.encode(), len(shape), *dims, off))
+        data.append(a.tobytes())
+        off += a.size
+    head = MAGIC + struct.pack("<II", len(TENSORS), 0)
+    return head + b"".join(entries) + b"".join(data)
+
+
+def unpack_blob(blob: bytes) -> "OrderedDict[str, np.ndarray]":
+    if blob[:8] != MAGIC:
+        raise ValueError("bad magic")
+    n, _ = struct.unpack_from("<II", blob, 8)
+    esz = struct.calcsize("<48sI4IQ")
+    base = 16 + n * esz
+    out: "OrderedDict[str, np.ndarray]" = OrderedDict()
+    for i in range(n):
+        name, ndim, d0, d1, d2, d3, off = struct.unpack_from("<48sI4IQ", blob, 16 + i * esz)
+        shape = (d0, d1, d2, d3)[:ndim]
+        cnt = int(np.prod(shape))
+        out[name.rstrip(b"\0").decode()] = np.frombuffer(
+            blob, dtype="<f4", count=cnt, offset=base + 4 * off).reshape(shape).copy()
+    return out
+
+
+def from_state_dict(sd) -> "OrderedDict[str, np.ndarray]":
+    """Pick the path's tensors out of an upstream-XFeat / libtorch-archive state_dict
+    (any mapping name -> array-like; keys may carry a `net.` prefix).  Used by
+    tools/convert_weights.py once a real xfeat.pt is available."""
+    out: "OrderedDict[str, np.ndarray]" = OrderedDict()
+    for name, shape in TENSORS:
+        src = None
+        for k in (name, "net." + name):
+            if k in sd:
+                src = sd[k]
+                break
+        if src is None:
+            raise KeyError(name)
+        a = np.asarray(src.detach().cpu().numpy() if hasattr(src, "detach") else src, dtype=np.float32)
+        out[name] = a.reshape(shape)
+    return out
