@@ -1,0 +1,172 @@
+/*
+ * xfeat_hip.h -- C ABI of libxfeat_hip.so: the MI355X (gfx950) XFeat feature-extraction
+ * and descriptor-matching front end for xfeatSLAM.
+ *
+ * This is the drop-in boundary.  Each entry point names the reference interface it
+ * replaces (paths relative to udaysankar01/xfeatSLAM).  Plain pointers and sizes only;
+ * no C++ or torch types; nothing throws or aborts across this ABI -- every call returns
+ * an xfh_status (0 = OK) except where noted.  A ctx is single-caller (one HIP stream per
+ * ctx), exactly like the reference's XFextractor object (Tracking.h:265); create one ctx
+ * per GPU for multi-GPU use.  xfh_descriptor_distance is stateless and thread-safe like
+ * the static ORBmatcher::DescriptorDistance.
+ *
+ * The C++ wrappers that restore the reference's class surface on top of this ABI are
+ * include/xfeat/XFextractor.h and include/xfeat/ORBmatcher_xfeat.h; INTEGRATION.md shows
+ * the edits a maintainer makes in the reference tree.
+ */
+#ifndef XFEAT_HIP_H
+#define XFEAT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct xfh_ctx xfh_ctx;
+
+typedef enum {
+    XFH_OK = 0,
+    XFH_ERR_INVALID_ARG = 1,
+    XFH_ERR_EMPTY_IMAGE = 2,      /* reference returns -1 (XFextractor.cc:253-254)            */
+    XFH_ERR_BAD_SIZE = 3,         /* image smaller than 32x32 or larger than the ctx maximum  */
+    XFH_ERR_NO_WEIGHTS = 4,       /* extract called before xfh_load_weights                   */
+    XFH_ERR_BAD_WEIGHTS = 5,      /* blob magic / tensor table / shapes wrong                 */
+    XFH_ERR_HIP = 6,              /* a HIP runtime call failed; see xfh_last_hip_error        */
+    XFH_ERR_NO_DEVICE = 7,        /* no gfx950 device visible: the library never falls back   */
+    XFH_ERR_OUT_OF_MEMORY = 8,
+    XFH_ERR_BATCH_TOO_LARGE = 9,
+    XFH_ERR_IO = 10
+} xfh_status;
+
+/* mirrors cv::KeyPoint field for field (28 bytes): pt.x, pt.y, size, angle, response,
+ * octave, class_id.  Written keypoints are KeyPoint(x, y, 1, -1, score) and unwritten
+ * slots are the default cv::KeyPoint() -- XFextractor.cc:312,329 */
+typedef struct {
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+} xfh_keypoint;
+
+/* BatchNorm behaviour.  BATCH_STATS reproduces the reference (the module is never put in
+ * eval(), so every BasicLayer normalises with the statistics of the current frame --
+ * SURVEY.md Q1).  Statistics are always per frame, also in batched calls. */
+enum { XFH_BN_BATCH_STATS = 0 };
+
+typedef struct {
+    int32_t device;        /* HIP device ordinal                                              */
+    int32_t max_height;    /* largest input image accepted (before the /32 resize)            */
+    int32_t max_width;
+    int32_t nfeatures;     /* rows of every output (XFextractor ctor arg, Tracking.cc:597)    */
+    int32_t max_batch;     /* frames per xfh_extract_batch* call                              */
+    int32_t bn_mode;       /* XFH_BN_*                                                        */
+    float nms_threshold;   /* 0.05 in the reference (XFextractor.cc:277)                      */
+    int32_t reserved[8];
+} xfh_config;
+
+/* fills the defaults: device 0, 480x640, nfeatures 4096, max_batch 1, threshold 0.05 */
+void xfh_config_default(xfh_config* cfg);
+
+/* XFextractor::XFextractor (XFextractor.cc:75-149) minus the host-only scale tables,
+ * which live in the C++ wrapper.  Allocates all device memory up front. */
+int xfh_create(const xfh_config* cfg, xfh_ctx** out);
+int xfh_destroy(xfh_ctx* ctx);
+
+/* Weight loading (replaces InputArchive::load_from + model->load, XFextractor.cc:133-137).
+ * blob format: xfeatslam_amd/weights.py ("XFHWGT01" + tensor table + fp32 OIHW data). */
+int xfh_load_weights(xfh_ctx* ctx, const void* blob, size_t nbytes);
+int xfh_load_weights_file(xfh_ctx* ctx, const char* path);
+
+/* ---- extraction: XFextractor::operator() (XFextractor.cc:250-356) -------------------
+ * gray: H x W CV_8UC1 in host memory, stride_bytes between rows (the reference assumes a
+ * dense Mat, :166).  lap_x0/lap_x1 = vLappingArea (Frame.cc:311 passes {0,0}, :495
+ * {0,1000}).  kps_out: nfeatures records, desc_out: nfeatures x 64 floats row-major; both
+ * fully written (padding = default KeyPoint / zero rows).  *mono_index is operator()'s
+ * return value, *n_valid the number of keypoints with score > 0 that were written. */
+int xfh_extract(xfh_ctx* ctx, const uint8_t* gray, int H, int W, int stride_bytes, int lap_x0, int lap_x1,
+                xfh_keypoint* kps_out, float* desc_out, int* n_valid, int* mono_index);
+
+/* the upstream name of the same call (README.md:9, xfeat_cpp `detectAndCompute`) */
+int xfh_detect_and_compute(xfh_ctx* ctx, const uint8_t* gray, int H, int W, int stride_bytes,
+                           int lap_x0, int lap_x1, xfh_keypoint* kps_out, float* desc_out,
+                           int* n_valid, int* mono_index);
+
+/* One output record per frame, device or host resident, fixed size (the reference output
+ * is already padded to nfeatures rows -- SURVEY.md Q3):
+ *   int32 n_valid, mono_index, n_candidates, reserved;
+ *   xfh_keypoint kps[nfeatures];  float desc[nfeatures*64];                              */
+size_t xfh_record_bytes(int nfeatures);
+size_t xfh_record_kps_offset(void);
+size_t xfh_record_desc_offset(int nfeatures);
+
+/* B dense frames [B][H][W] u8 in HOST memory -> B records in HOST memory */
+int xfh_extract_batch(xfh_ctx* ctx, const uint8_t* gray, int B, int H, int W, int lap_x0, int lap_x1,
+                      void* records_out);
+/* same with DEVICE pointers (frames resident in HBM, records stay in HBM for the matcher or
+ * an RCCL all-gather); asynchronous on the ctx stream -- call xfh_synchronize to wait. */
+int xfh_extract_batch_device(xfh_ctx* ctx, const uint8_t* d_gray, int B, int H, int W, int lap_x0,
+                             int lap_x1, void* d_records_out);
+
+/* ---- matching ----------------------------------------------------------------------
+ * ORBmatcher::match (declared ORBmatcher.h:77; its definition is commented out at
+ * ORBmatcher.cc:340-405; these are the semantics of that code with float descriptors):
+ * rows L2-normalised, cosine similarity, mutual nearest neighbours, first maximum wins
+ * ties, matches in ascending idx1 order, dist = sqrt(2 (1 - cos)).  min_cossim <= 0
+ * disables the gate as the reference does (:361).  idx1/idx2/dist need min(n1,n2) slots. */
+int xfh_match_mnn(xfh_ctx* ctx, const float* d1, int n1, const float* d2, int n2, float min_cossim,
+                  int* idx1, int* idx2, float* dist, int* n_matches);
+/* device-resident variant: d1/d2 device pointers (e.g. the desc block of two records),
+ * outputs device pointers; *d_n_matches is one int in device memory.  Asynchronous. */
+int xfh_match_mnn_device(xfh_ctx* ctx, const float* d_d1, int n1, const float* d_d2, int n2,
+                         float min_cossim, int* d_idx1, int* d_idx2, float* d_dist, int* d_n_matches);
+
+/* ORBmatcher::DescriptorDistance (ORBmatcher.cc:2242-2250), XFeat branch:
+ * (int)(float(cv::norm(a, b, NORM_L2SQR)) * 512).  Scalar host version, stateless. */
+int xfh_descriptor_distance(const float* a, const float* b);
+/* dense n1 x n2 table of the same integer metric, computed on the GPU (host pointers) */
+int xfh_distance_i32(xfh_ctx* ctx, const float* d1, int n1, const float* d2, int n2, int32_t* out);
+int xfh_distance_i32_device(xfh_ctx* ctx, const float* d_d1, int n1, const float* d_d2, int n2, int32_t* d_out);
+
+/* ---- plumbing ----------------------------------------------------------------------- */
+int xfh_synchronize(xfh_ctx* ctx);
+/* run the ctx on an externally owned hipStream_t (e.g. torch's current stream); NULL
+ * restores the ctx's own stream */
+int xfh_set_stream(xfh_ctx* ctx, void* hip_stream);
+const char* xfh_strerror(int status);
+const char* xfh_last_hip_error(xfh_ctx* ctx);
+const char* xfh_version(void);
+int xfh_device_count(void);
+
+/* device-memory helpers so that a host language without a HIP binding can keep inputs and
+ * records resident in HBM (used by bench.py and the tests through ctypes) */
+int xfh_dev_alloc(void** dptr, size_t nbytes);
+int xfh_dev_free(void* dptr);
+int xfh_memcpy_h2d(void* dst, const void* src, size_t nbytes);
+int xfh_memcpy_d2h(void* dst, const void* src, size_t nbytes);
+
+/* ---- measurement and debugging -------------------------------------------------------
+ * Kernel timing: while enabled, every launch of the kernel family `kernel_id` on the ctx
+ * stream is bracketed by hipEvents; xfh_timing_read returns launches and total ms since
+ * the last reset.  bench.py uses it for the roofline line. */
+enum {
+    XFH_K_NONE = 0, XFH_K_MNN_GEMM = 1, XFH_K_CONV_MFMA = 2, XFH_K_CONV_DIRECT = 3,
+    XFH_K_NMS = 4, XFH_K_SELECT = 5, XFH_K_DESC = 6, XFH_K_HEADS = 7, XFH_K_DIST_I32 = 8,
+    XFH_K_PREPROC = 9, XFH_K_COUNT = 10
+};
+int xfh_timing_enable(xfh_ctx* ctx, int kernel_id, int conv_layer /* -1 = all layers */);
+int xfh_timing_read(xfh_ctx* ctx, int* launches, double* total_ms);
+const char* xfh_kernel_name(int kernel_id);
+
+/* intermediate tensors of frame `frame` of the last extract call, copied to host as float
+ * (ids match oracle/xfeat_oracle.h; image-like tensors are NHWC).  count_out = floats. */
+enum {
+    XFH_T_X = 0, XFH_T_XSTAT = 1, XFH_T_SKIP_POOL = 2, XFH_T_XUNFOLD = 3, XFH_T_B2IN = 4,
+    XFH_T_FUSE_IN = 5, XFH_T_FEATS = 6, XFH_T_M1N = 7, XFH_T_H1 = 8, XFH_T_K1H = 9,
+    XFH_T_RAW0 = 16, XFH_T_STAT0 = 48, XFH_T_SEL = 80
+};
+int xfh_debug_tensor(xfh_ctx* ctx, int id, int frame, float* out, size_t capacity, size_t* count_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XFEAT_HIP_H */

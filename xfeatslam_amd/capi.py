@@ -1,0 +1,138 @@
+"""ctypes binding of libxfeat_hip.so (include/xfeat_hip.h).
+
+The shared library is the product; this module only declares its C ABI for the Python
+host-side mirror, the tests and bench.py.  It never falls back to a CPU implementation:
+if the library is missing it raises, and every compute call fails loudly when no HIP
+device is present (XFH_ERR_NO_DEVICE).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_DIR, "libxfeat_hip.so")
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+assert KP_DTYPE.itemsize == 28
+
+OK = 0
+STATUS = {0: "OK", 1: "INVALID_ARG", 2: "EMPTY_IMAGE", 3: "BAD_SIZE", 4: "NO_WEIGHTS", 5: "BAD_WEIGHTS",
+          6: "HIP", 7: "NO_DEVICE", 8: "OUT_OF_MEMORY", 9: "BATCH_TOO_LARGE", 10: "IO"}
+ERR_EMPTY_IMAGE = 2
+ERR_NO_DEVICE = 7
+
+K = dict(NONE=0, MNN_GEMM=1, CONV_MFMA=2, CONV_DIRECT=3, NMS=4, SELECT=5, DESC=6, HEADS=7, DIST_I32=8, PREPROC=9)
+T = dict(X=0, XSTAT=1, SKIP_POOL=2, XUNFOLD=3, B2IN=4, FUSE_IN=5, FEATS=6, M1N=7, H1=8, K1H=9, RAW0=16, STAT0=48, SEL=80)
+
+
+class Config(C.Structure):
+    _fields_ = [("device", C.c_int32), ("max_height", C.c_int32), ("max_width", C.c_int32),
+                ("nfeatures", C.c_int32), ("max_batch", C.c_int32), ("bn_mode", C.c_int32),
+                ("nms_threshold", C.c_float), ("reserved", C.c_int32 * 8)]
+
+
+# every symbol include/xfeat_hip.h declares: (name, restype, argtypes)
+_vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+_pi = C.POINTER(C.c_int)
+SYMBOLS = [
+    ("xfh_config_default", None, [C.POINTER(Config)]),
+    ("xfh_create", _i, [C.POINTER(Config), C.POINTER(_vp)]),
+    ("xfh_destroy", _i, [_vp]),
+    ("xfh_load_weights", _i, [_vp, _vp, _sz]),
+    ("xfh_load_weights_file", _i, [_vp, C.c_char_p]),
+    ("xfh_extract", _i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _pi, _pi]),
+    ("xfh_detect_and_compute", _i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _pi, _pi]),
+    ("xfh_record_bytes", _sz, [_i]),
+    ("xfh_record_kps_offset", _sz, []),
+    ("xfh_record_desc_offset", _sz, [_i]),
+    ("xfh_extract_batch", _i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    ("xfh_extract_batch_device", _i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    ("xfh_match_mnn", _i, [_vp, _vp, _i, _vp, _i, _f, _vp, _vp, _vp, _pi]),
+    ("xfh_match_mnn_device", _i, [_vp, _vp, _i, _vp, _i, _f, _vp, _vp, _vp, _vp]),
+    ("xfh_descriptor_distance", _i, [_vp, _vp]),
+    ("xfh_distance_i32", _i, [_vp, _vp, _i, _vp, _i, _vp]),
+    ("xfh_distance_i32_device", _i, [_vp, _vp, _i, _vp, _i, _vp]),
+    ("xfh_synchronize", _i, [_vp]),
+    ("xfh_set_stream", _i, [_vp, _vp]),
+    ("xfh_strerror", C.c_char_p, [_i]),
+    ("xfh_last_hip_error", C.c_char_p, [_vp]),
+    ("xfh_version", C.c_char_p, []),
+    ("xfh_device_count", _i, []),
+    ("xfh_dev_alloc", _i, [C.POINTER(_vp), _sz]),
+    ("xfh_dev_free", _i, [_vp]),
+    ("xfh_memcpy_h2d", _i, [_vp, _vp, _sz]),
+    ("xfh_memcpy_d2h", _i, [_vp, _vp, _sz]),
+    ("xfh_timing_enable", _i, [_vp, _i, _i]),
+    ("xfh_timing_read", _i, [_vp, _pi, C.POINTER(C.c_double)]),
+    ("xfh_kernel_name", C.c_char_p, [_i]),
+    ("xfh_debug_tensor", _i, [_vp, _i, _i, _vp, _sz, C.POINTER(_sz)]),
+]
+
+_lib = None
+
+
+def lib():
+    """Load libxfeat_hip.so (raises if it has not been built: there is no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(hipcc --offload-arch=gfx950); this package has no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            fn = getattr(L, name)          # AttributeError if the ABI symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+class XfhError(RuntimeError):
+    def __init__(self, status: int, detail: str = ""):
+        self.status = status
+        msg = lib().xfh_strerror(status).decode()
+        super().__init__(f"xfeat_hip status {status} ({STATUS.get(status, '?')}: {msg}) {detail}")
+
+
+def check(status: int, ctx=None):
+    if status != OK:
+        detail = ""
+        if ctx is not None and status == 6:
+            detail = lib().xfh_last_hip_error(ctx).decode()
+        raise XfhError(status, detail)
+
+
+class DeviceBuffer:
+    """HBM allocation owned through the C ABI (no torch needed)."""
+
+    def __init__(self, nbytes: int):
+        p = C.c_void_p()
+        check(lib().xfh_dev_alloc(C.byref(p), nbytes))
+        self.ptr = p.value
+        self.nbytes = nbytes
+
+    def upload(self, arr: np.ndarray):
+        a = np.ascontiguousarray(arr)
+        assert a.nbytes <= self.nbytes
+        check(lib().xfh_memcpy_h2d(self.ptr, a.ctypes.data, a.nbytes))
+        return self
+
+    def download(self, dtype, count: int, offset: int = 0) -> np.ndarray:
+        out = np.empty(count, dtype)
+        check(lib().xfh_memcpy_d2h(out.ctypes.data, self.ptr + offset, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            lib().xfh_dev_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

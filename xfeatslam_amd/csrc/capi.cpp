@@ -1,0 +1,509 @@
+// capi.cpp -- implementation of include/xfeat_hip.h: context, weights, entry points.
+// Built with hipcc for gfx950 only.  There is no CPU path: without a HIP device every
+// compute entry point fails with XFH_ERR_NO_DEVICE / XFH_ERR_HIP.
+#include "ctx.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+int conv_layer_npart(int li, int Hout, int Wout);
+
+#define HIPCK(c, x) do { hipError_t _e = (x); if (_e != hipSuccess) { (c)->hip_err = std::string(#x) + ": " + hipGetErrorString(_e); return XFH_ERR_HIP; } } while (0)
+
+extern "C" {
+
+const char* xfh_version(void) { return "xfeat_hip 0.1 (gfx950)"; }
+
+const char* xfh_strerror(int s) {
+    switch (s) {
+        case XFH_OK: return "ok";
+        case XFH_ERR_INVALID_ARG: return "invalid argument";
+        case XFH_ERR_EMPTY_IMAGE: return "empty image";
+        case XFH_ERR_BAD_SIZE: return "image size unsupported (need >= 32x32 and <= ctx maximum)";
+        case XFH_ERR_NO_WEIGHTS: return "weights not loaded";
+        case XFH_ERR_BAD_WEIGHTS: return "malformed weight blob";
+        case XFH_ERR_HIP: return "HIP runtime error";
+        case XFH_ERR_NO_DEVICE: return "no HIP device";
+        case XFH_ERR_OUT_OF_MEMORY: return "out of memory";
+        case XFH_ERR_BATCH_TOO_LARGE: return "batch larger than ctx max_batch";
+        case XFH_ERR_IO: return "file i/o error";
+        default: return "unknown status";
+    }
+}
+
+const char* xfh_kernel_name(int id) {
+    static const char* n[XFH_K_COUNT] = {"none", "k_mnn_gemm", "k_conv_mfma", "k_conv_direct", "k_nms_score", "k_select",
+                                         "k_desc", "k_heads_final", "k_dist_i32", "k_preproc"};
+    return (id >= 0 && id < XFH_K_COUNT) ? n[id] : "?";
+}
+
+int xfh_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void xfh_config_default(xfh_config* cfg) {
+    memset(cfg, 0, sizeof(*cfg));
+    cfg->device = 0; cfg->max_height = 480; cfg->max_width = 640; cfg->nfeatures = 4096;
+    cfg->max_batch = 1; cfg->bn_mode = XFH_BN_BATCH_STATS; cfg->nms_threshold = 0.05f;
+}
+
+size_t xfh_record_kps_offset(void) { return sizeof(RecordHeader); }
+size_t xfh_record_desc_offset(int nf) { return (sizeof(RecordHeader) + (size_t)nf * sizeof(xfh_keypoint) + 255) & ~(size_t)255; }
+size_t xfh_record_bytes(int nf) { return (xfh_record_desc_offset(nf) + (size_t)nf * 64 * sizeof(float) + 255) & ~(size_t)255; }
+
+static int out_dim(int in, int ks, int st) { return (in + 2 * (ks / 2) - ks) / st + 1; }
+
+static void layer_dims(int H, int W, int* lh, int* lw) {
+    // input of layer i: see run_extract
+    static const int src[XFH_NUM_LAYERS] = {-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 8, 16, 17, 18, -2, 20, 21};
+    for (int i = 0; i < XFH_NUM_LAYERS; ++i) {
+        int hi, wi;
+        if (src[i] == -1) { hi = H; wi = W; }
+        else if (src[i] == -2) { hi = H / 8; wi = W / 8; }
+        else { hi = lh[src[i]]; wi = lw[src[i]]; }
+        lh[i] = out_dim(hi, XFH_LAYERS[i].ks, XFH_LAYERS[i].stride);
+        lw[i] = out_dim(wi, XFH_LAYERS[i].ks, XFH_LAYERS[i].stride);
+    }
+}
+
+int xfh_create(const xfh_config* cfg, xfh_ctx** out) {
+    if (!cfg || !out) return XFH_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (cfg->max_height < 32 || cfg->max_width < 32 || cfg->nfeatures < 1 || cfg->nfeatures > 65536 || cfg->max_batch < 1)
+        return XFH_ERR_INVALID_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return XFH_ERR_NO_DEVICE;
+    if (cfg->device < 0 || cfg->device >= ndev) return XFH_ERR_NO_DEVICE;
+    xfh_ctx* c = new xfh_ctx();
+    c->cfg = *cfg;
+    if (c->cfg.nms_threshold <= 0.f) c->cfg.nms_threshold = 0.05f;
+    c->Hmax = (cfg->max_height / 32) * 32; c->Wmax = (cfg->max_width / 32) * 32;
+    const int B = cfg->max_batch;
+    int rc = XFH_OK;
+    auto fail = [&](int code) { xfh_destroy(c); return code; };
+#define A(ptr, bytes) do { if (hipMalloc((void**)&(ptr), (bytes)) != hipSuccess) return fail(XFH_ERR_OUT_OF_MEMORY); } while (0)
+    if (hipSetDevice(cfg->device) != hipSuccess) return fail(XFH_ERR_HIP);
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) return fail(XFH_ERR_HIP);
+    c->stream = c->own_stream;
+    const size_t xs = (size_t)c->Hmax * c->Wmax;
+    A(c->d_gray, (size_t)B * cfg->max_height * cfg->max_width);
+    A(c->X, sizeof(float) * B * xs);
+    c->pre_npart = (int)((xs + 1023) / 1024);
+    A(c->pre_part, sizeof(double) * B * c->pre_npart * 2);
+    A(c->xstat, sizeof(float) * B * 2);
+    int lh[XFH_NUM_LAYERS], lw[XFH_NUM_LAYERS];
+    layer_dims(c->Hmax, c->Wmax, lh, lw);
+    for (int i = 0; i < XFH_NUM_LAYERS; ++i) {
+        const int C = XFH_LAYERS[i].cout;
+        c->raw_stride[i] = (size_t)lh[i] * lw[i] * C;
+        A(c->raw[i], sizeof(float) * B * c->raw_stride[i]);
+        c->part_stride[i] = (size_t)conv_layer_npart(i, lh[i], lw[i]) * C * 2;
+        A(c->part[i], sizeof(double) * B * c->part_stride[i]);
+        A(c->stat[i], sizeof(float) * B * 2 * C);
+    }
+    A(c->skip_pool, sizeof(float) * B * (xs / 16));
+    A(c->xunfold, sizeof(float) * B * xs);
+    A(c->b2in, sizeof(float) * B * c->raw_stride[3]);
+    A(c->fuse_in, sizeof(float) * B * c->raw_stride[8]);
+    A(c->feats, sizeof(float) * B * c->raw_stride[17]);
+    A(c->m1n, sizeof(float) * B * c->raw_stride[17]);
+    A(c->H1, sizeof(float) * B * (xs / 64));
+    A(c->K1h, sizeof(float) * B * xs);
+    c->cand_cap = 1024;
+    while (c->cand_cap < xs) c->cand_cap <<= 1;
+    A(c->cand, sizeof(u64) * B * c->cand_cap);
+    A(c->cand_count, sizeof(int) * B);
+    A(c->slot_src, sizeof(int) * B * cfg->nfeatures);
+    A(c->sel_key, sizeof(u64) * B * cfg->nfeatures);
+    A(c->sel_n, sizeof(int) * B);
+    const size_t rec = xfh_record_bytes(cfg->nfeatures);
+    A(c->d_records, rec * B);
+    if (hipHostMalloc((void**)&c->h_records, rec * B, hipHostMallocDefault) != hipSuccess) return fail(XFH_ERR_OUT_OF_MEMORY);
+    if (hipHostMalloc((void**)&c->h_gray, (size_t)B * cfg->max_height * cfg->max_width, hipHostMallocDefault) != hipSuccess) return fail(XFH_ERR_OUT_OF_MEMORY);
+#undef A
+    (void)rc;
+    *out = c;
+    return XFH_OK;
+}
+
+int xfh_destroy(xfh_ctx* c) {
+    if (!c) return XFH_OK;
+    if (c->own_stream) hipStreamSynchronize(c->own_stream);
+    auto F = [](void* p) { if (p) hipFree(p); };
+    F(c->d_gray); F(c->X); F(c->pre_part); F(c->xstat);
+    for (int i = 0; i < XFH_NUM_LAYERS; ++i) { F(c->raw[i]); F(c->part[i]); F(c->stat[i]); F(c->w.mfma[i]); }
+    for (int i = 0; i < 4; ++i) F(c->w.direct[i]);
+    F(c->w.fus2); F(c->w.fus2_bias); F(c->w.skip_w); F(c->w.skip_b); F(c->w.heat2_w); F(c->w.heat2_b); F(c->w.kp3_w); F(c->w.kp3_b);
+    F(c->skip_pool); F(c->xunfold); F(c->b2in); F(c->fuse_in); F(c->feats); F(c->m1n); F(c->H1); F(c->K1h);
+    F(c->cand); F(c->cand_count); F(c->slot_src); F(c->sel_key); F(c->sel_n); F(c->d_records);
+    if (c->h_records) hipHostFree(c->h_records);
+    if (c->h_gray) hipHostFree(c->h_gray);
+    MatchWs& w = c->mws;
+    F(w.partR); F(w.best12); F(w.h_d1); F(w.o_idx1); F(w.o_tab);
+    if (c->timer.ev) { for (int i = 0; i < 2 * KTimer::MAXEV; ++i) if (c->timer.ev[i]) hipEventDestroy(c->timer.ev[i]); free(c->timer.ev); }
+    if (c->own_stream) hipStreamDestroy(c->own_stream);
+    delete c;
+    return XFH_OK;
+}
+
+// ------------------------------------------------------------------------- weights
+struct BlobEntry { const float* p; uint32_t dims[4]; uint32_t ndim; };
+static bool blob_find(const void* blob, size_t nbytes, const char* name, BlobEntry* e) {
+    const unsigned char* p = (const unsigned char*)blob;
+    if (nbytes < 16 || memcmp(p, "XFHWGT01", 8) != 0) return false;
+    uint32_t n; memcpy(&n, p + 8, 4);
+    const size_t esz = 48 + 4 + 16 + 8;
+    if (16 + (size_t)n * esz > nbytes) return false;
+    const unsigned char* data = p + 16 + (size_t)n * esz;
+    for (uint32_t i = 0; i < n; ++i) {
+        const unsigned char* q = p + 16 + (size_t)i * esz;
+        if (strncmp((const char*)q, name, 48) == 0) {
+            memcpy(&e->ndim, q + 48, 4); memcpy(e->dims, q + 52, 16);
+            uint64_t off; memcpy(&off, q + 68, 8);
+            size_t cnt = 1; for (uint32_t k = 0; k < e->ndim && k < 4; ++k) cnt *= e->dims[k];
+            if ((size_t)(data - p) + 4 * (off + cnt) > nbytes) return false;
+            e->p = (const float*)(data + 4 * off);
+            return true;
+        }
+    }
+    return false;
+}
+
+static int upload(xfh_ctx* c, float** dst, const std::vector<float>& v) {
+    if (*dst) { hipFree(*dst); *dst = nullptr; }
+    HIPCK(c, hipMalloc((void**)dst, v.size() * sizeof(float)));
+    HIPCK(c, hipMemcpy(*dst, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+    return XFH_OK;
+}
+
+// OIHW -> [chunk = tap*NCB + cb][n (COUTP)][CB] with the k permutation of the MFMA kernels:
+// inside each group of 8 channels, channel e sits at position 4*(e&1) + (e>>1).
+static std::vector<float> pack_mfma(const float* w, int cout, int cin, int ks, int coutp) {
+    const int CB = cin > 64 ? 64 : cin, NCB = cin / CB;
+    std::vector<float> o((size_t)ks * ks * NCB * coutp * CB, 0.f);
+    for (int ky = 0; ky < ks; ++ky) for (int kx = 0; kx < ks; ++kx) for (int cb = 0; cb < NCB; ++cb)
+        for (int n = 0; n < cout; ++n) for (int lc = 0; lc < CB; ++lc) {
+            const int g = lc / 8, e = lc % 8, pos = g * 8 + 4 * (e & 1) + (e >> 1);
+            const int ci = cb * CB + lc;
+            const size_t chunk = (size_t)(ky * ks + kx) * NCB + cb;
+            o[(chunk * coutp + n) * CB + pos] = w[(((size_t)n * cin + ci) * ks + ky) * ks + kx];
+        }
+    return o;
+}
+
+int xfh_load_weights(xfh_ctx* c, const void* blob, size_t nbytes) {
+    if (!c || !blob) return XFH_ERR_INVALID_ARG;
+    HIPCK(c, hipSetDevice(c->cfg.device));
+    BlobEntry e; char nm[64];
+    for (int i = 0; i < XFH_NUM_LAYERS; ++i) {
+        const LayerSpec& L = XFH_LAYERS[i];
+        snprintf(nm, sizeof nm, "%s.layer.0.weight", L.name);
+        if (!blob_find(blob, nbytes, nm, &e) || (int)e.dims[0] != L.cout || (int)e.dims[1] != L.cin || (int)e.dims[2] != L.ks) return XFH_ERR_BAD_WEIGHTS;
+        int rc;
+        if (i < 4) {
+            std::vector<float> o((size_t)9 * L.cin * L.cout);
+            for (int co = 0; co < L.cout; ++co) for (int ci = 0; ci < L.cin; ++ci) for (int ky = 0; ky < 3; ++ky) for (int kx = 0; kx < 3; ++kx)
+                o[(((size_t)ky * 3 + kx) * L.cin + ci) * L.cout + co] = e.p[(((size_t)co * L.cin + ci) * 3 + ky) * 3 + kx];
+            rc = upload(c, &c->w.direct[i], o);
+        } else {
+            const int coutp = (L.cout + 31) / 32 * 32;
+            rc = upload(c, &c->w.mfma[i], pack_mfma(e.p, L.cout, L.cin, L.ks, coutp));
+        }
+        if (rc != XFH_OK) return rc;
+    }
+    int rc;
+    if (!blob_find(blob, nbytes, "block_fusion.2.weight", &e) || e.dims[0] != 64 || e.dims[1] != 64) return XFH_ERR_BAD_WEIGHTS;
+    if ((rc = upload(c, &c->w.fus2, pack_mfma(e.p, 64, 64, 1, 64))) != XFH_OK) return rc;
+    if (!blob_find(blob, nbytes, "block_fusion.2.bias", &e) || e.dims[0] != 64) return XFH_ERR_BAD_WEIGHTS;
+    if ((rc = upload(c, &c->w.fus2_bias, std::vector<float>(e.p, e.p + 64))) != XFH_OK) return rc;
+    if (!blob_find(blob, nbytes, "skip1.1.weight", &e) || e.dims[0] != 24) return XFH_ERR_BAD_WEIGHTS;
+    if ((rc = upload(c, &c->w.skip_w, std::vector<float>(e.p, e.p + 24))) != XFH_OK) return rc;
+    if (!blob_find(blob, nbytes, "skip1.1.bias", &e) || e.dims[0] != 24) return XFH_ERR_BAD_WEIGHTS;
+    if ((rc = upload(c, &c->w.skip_b, std::vector<float>(e.p, e.p + 24))) != XFH_OK) return rc;
+    if (!blob_find(blob, nbytes, "heatmap_head.2.weight", &e) || e.dims[0] != 1 || e.dims[1] != 64) return XFH_ERR_BAD_WEIGHTS;
+    if ((rc = upload(c, &c->w.heat2_w, std::vector<float>(e.p, e.p + 64))) != XFH_OK) return rc;
+    if (!blob_find(blob, nbytes, "heatmap_head.2.bias", &e)) return XFH_ERR_BAD_WEIGHTS;
+    if ((rc = upload(c, &c->w.heat2_b, std::vector<float>(e.p, e.p + 1))) != XFH_OK) return rc;
+    if (!blob_find(blob, nbytes, "keypoint_head.3.weight", &e) || e.dims[0] != 65 || e.dims[1] != 64) return XFH_ERR_BAD_WEIGHTS;
+    {
+        std::vector<float> o((size_t)64 * 68, 0.f);
+        for (int n = 0; n < 65; ++n) for (int k = 0; k < 64; ++k) o[(size_t)k * 68 + n] = e.p[(size_t)n * 64 + k];
+        if ((rc = upload(c, &c->w.kp3_w, o)) != XFH_OK) return rc;
+    }
+    if (!blob_find(blob, nbytes, "keypoint_head.3.bias", &e) || e.dims[0] != 65) return XFH_ERR_BAD_WEIGHTS;
+    if ((rc = upload(c, &c->w.kp3_b, std::vector<float>(e.p, e.p + 65))) != XFH_OK) return rc;
+    c->w.loaded = true;
+    return XFH_OK;
+}
+
+int xfh_load_weights_file(xfh_ctx* c, const char* path) {
+    if (!c || !path) return XFH_ERR_INVALID_ARG;
+    FILE* f = fopen(path, "rb");
+    if (!f) return XFH_ERR_IO;
+    fseek(f, 0, SEEK_END); long n = ftell(f); fseek(f, 0, SEEK_SET);
+    std::vector<unsigned char> buf((size_t)(n > 0 ? n : 0));
+    const size_t got = n > 0 ? fread(buf.data(), 1, (size_t)n, f) : 0;
+    fclose(f);
+    if (n <= 0 || got != (size_t)n) return XFH_ERR_IO;
+    return xfh_load_weights(c, buf.data(), buf.size());
+}
+
+// ------------------------------------------------------------------------- extraction
+static int check_extract(xfh_ctx* c, const void* gray, int B, int H, int W) {
+    if (!c) return XFH_ERR_INVALID_ARG;
+    if (!gray || H <= 0 || W <= 0) return XFH_ERR_EMPTY_IMAGE;
+    if (B < 1) return XFH_ERR_INVALID_ARG;
+    if (B > c->cfg.max_batch) return XFH_ERR_BATCH_TOO_LARGE;
+    if (H < 32 || W < 32 || H > c->cfg.max_height || W > c->cfg.max_width) return XFH_ERR_BAD_SIZE;
+    if (!c->w.loaded) return XFH_ERR_NO_WEIGHTS;
+    return XFH_OK;
+}
+
+int xfh_extract_batch_device(xfh_ctx* c, const uint8_t* d_gray, int B, int H, int W, int lap0, int lap1, void* d_records) {
+    int rc = check_extract(c, d_gray, B, H, W);
+    if (rc != XFH_OK) return rc;
+    if (!d_records) return XFH_ERR_INVALID_ARG;
+    HIPCK(c, hipSetDevice(c->cfg.device));
+    HIPCK(c, run_extract(c, d_gray, B, H, W, lap0, lap1, (uint8_t*)d_records));
+    return XFH_OK;
+}
+
+int xfh_extract_batch(xfh_ctx* c, const uint8_t* gray, int B, int H, int W, int lap0, int lap1, void* records_out) {
+    int rc = check_extract(c, gray, B, H, W);
+    if (rc != XFH_OK) return rc;
+    if (!records_out) return XFH_ERR_INVALID_ARG;
+    HIPCK(c, hipSetDevice(c->cfg.device));
+    const size_t nb = (size_t)B * H * W, rec = xfh_record_bytes(c->cfg.nfeatures);
+    memcpy(c->h_gray, gray, nb);
+    HIPCK(c, hipMemcpyAsync(c->d_gray, c->h_gray, nb, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, run_extract(c, c->d_gray, B, H, W, lap0, lap1, c->d_records));
+    HIPCK(c, hipMemcpyAsync(c->h_records, c->d_records, rec * B, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    memcpy(records_out, c->h_records, rec * B);
+    return XFH_OK;
+}
+
+int xfh_extract(xfh_ctx* c, const uint8_t* gray, int H, int W, int stride, int lap0, int lap1,
+                xfh_keypoint* kps, float* desc, int* n_valid, int* mono_index) {
+    int rc = check_extract(c, gray, 1, H, W);
+    if (rc != XFH_OK) return rc;
+    if (!kps || !desc || stride < W) return XFH_ERR_INVALID_ARG;
+    HIPCK(c, hipSetDevice(c->cfg.device));
+    const int nf = c->cfg.nfeatures;
+    const size_t rec = xfh_record_bytes(nf);
+    for (int y = 0; y < H; ++y) memcpy(c->h_gray + (size_t)y * W, gray + (size_t)y * stride, (size_t)W);
+    HIPCK(c, hipMemcpyAsync(c->d_gray, c->h_gray, (size_t)H * W, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, run_extract(c, c->d_gray, 1, H, W, lap0, lap1, c->d_records));
+    HIPCK(c, hipMemcpyAsync(c->h_records, c->d_records, rec, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    const RecordHeader* h = (const RecordHeader*)c->h_records;
+    memcpy(kps, c->h_records + xfh_record_kps_offset(), (size_t)nf * sizeof(xfh_keypoint));
+    memcpy(desc, c->h_records + xfh_record_desc_offset(nf), (size_t)nf * 64 * sizeof(float));
+    if (n_valid) *n_valid = h->n_valid;
+    if (mono_index) *mono_index = h->mono_index;
+    return XFH_OK;
+}
+
+int xfh_detect_and_compute(xfh_ctx* c, const uint8_t* gray, int H, int W, int stride, int lap0, int lap1,
+                           xfh_keypoint* kps, float* desc, int* n_valid, int* mono_index) {
+    return xfh_extract(c, gray, H, W, stride, lap0, lap1, kps, desc, n_valid, mono_index);
+}
+
+// ------------------------------------------------------------------------- matching
+int xfh_descriptor_distance(const float* a, const float* b) {
+    double s = 0.0;
+    for (int k = 0; k < 64; ++k) { const float d = a[k] - b[k]; s += (double)d * (double)d; }
+    const float nd = (float)s;
+    return (int)(nd * 512);
+}
+
+static int grow(xfh_ctx* c, void** p, size_t* cap, size_t need) {
+    if (*p && *cap >= need) return XFH_OK;
+    if (*p) { hipFree(*p); *p = nullptr; *cap = 0; }
+    HIPCK(c, hipMalloc(p, need));
+    *cap = need;
+    return XFH_OK;
+}
+
+int xfh_match_mnn_device(xfh_ctx* c, const float* d1, int n1, const float* d2, int n2, float min_cossim,
+                         int* idx1, int* idx2, float* dist, int* n_matches) {
+    if (!c || n1 < 0 || n2 < 0 || !n_matches) return XFH_ERR_INVALID_ARG;
+    if ((n1 > 0 && !d1) || (n2 > 0 && !d2)) return XFH_ERR_INVALID_ARG;
+    if ((((uintptr_t)d1) | ((uintptr_t)d2)) & 15) return XFH_ERR_INVALID_ARG;
+    HIPCK(c, hipSetDevice(c->cfg.device));
+    HIPCK(c, launch_mnn(c, d1, n1, d2, n2, min_cossim, idx1, idx2, dist, n_matches));
+    return XFH_OK;
+}
+
+int xfh_match_mnn(xfh_ctx* c, const float* d1, int n1, const float* d2, int n2, float min_cossim,
+                  int* idx1, int* idx2, float* dist, int* n_matches) {
+    if (!c || n1 < 0 || n2 < 0 || !n_matches) return XFH_ERR_INVALID_ARG;
+    if (n1 == 0 || n2 == 0) { *n_matches = 0; return XFH_OK; }
+    if (!d1 || !d2 || !idx1 || !idx2 || !dist) return XFH_ERR_INVALID_ARG;
+    HIPCK(c, hipSetDevice(c->cfg.device));
+    MatchWs& w = c->mws;
+    const size_t b1 = (size_t)n1 * 64 * 4, b2 = (size_t)n2 * 64 * 4;
+    const size_t b1p = (b1 + 255) & ~(size_t)255;
+    int rc = grow(c, (void**)&w.h_d1, &w.cap_in, b1p + b2);
+    if (rc != XFH_OK) return rc;
+    w.h_d2 = (float*)((char*)w.h_d1 + b1p);
+    const int nm = n1 < n2 ? n1 : n2;
+    rc = grow(c, (void**)&w.o_idx1, &w.cap_out, (size_t)nm * 12 + 256);
+    if (rc != XFH_OK) return rc;
+    w.o_idx2 = w.o_idx1 + nm; w.o_dist = (float*)(w.o_idx2 + nm); w.o_n = (int*)(w.o_dist + nm);
+    HIPCK(c, hipMemcpyAsync(w.h_d1, d1, b1, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(w.h_d2, d2, b2, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, launch_mnn(c, w.h_d1, n1, w.h_d2, n2, min_cossim, w.o_idx1, w.o_idx2, w.o_dist, w.o_n));
+    int n = 0;
+    HIPCK(c, hipMemcpyAsync(&n, w.o_n, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    if (n > 0) {
+        HIPCK(c, hipMemcpy(idx1, w.o_idx1, (size_t)n * 4, hipMemcpyDeviceToHost));
+        HIPCK(c, hipMemcpy(idx2, w.o_idx2, (size_t)n * 4, hipMemcpyDeviceToHost));
+        HIPCK(c, hipMemcpy(dist, w.o_dist, (size_t)n * 4, hipMemcpyDeviceToHost));
+    }
+    *n_matches = n;
+    return XFH_OK;
+}
+
+int xfh_distance_i32_device(xfh_ctx* c, const float* d1, int n1, const float* d2, int n2, int32_t* out) {
+    if (!c || n1 < 0 || n2 < 0) return XFH_ERR_INVALID_ARG;
+    HIPCK(c, hipSetDevice(c->cfg.device));
+    HIPCK(c, launch_dist_i32(c, d1, n1, d2, n2, out));
+    return XFH_OK;
+}
+
+int xfh_distance_i32(xfh_ctx* c, const float* d1, int n1, const float* d2, int n2, int32_t* out) {
+    if (!c || n1 < 0 || n2 < 0) return XFH_ERR_INVALID_ARG;
+    if (n1 == 0 || n2 == 0) return XFH_OK;
+    if (!d1 || !d2 || !out) return XFH_ERR_INVALID_ARG;
+    HIPCK(c, hipSetDevice(c->cfg.device));
+    MatchWs& w = c->mws;
+    const size_t b1 = (size_t)n1 * 64 * 4, b2 = (size_t)n2 * 64 * 4;
+    const size_t b1p = (b1 + 255) & ~(size_t)255;
+    int rc = grow(c, (void**)&w.h_d1, &w.cap_in, b1p + b2);
+    if (rc != XFH_OK) return rc;
+    w.h_d2 = (float*)((char*)w.h_d1 + b1p);
+    rc = grow(c, (void**)&w.o_tab, &w.cap_tab, (size_t)n1 * n2 * 4);
+    if (rc != XFH_OK) return rc;
+    HIPCK(c, hipMemcpyAsync(w.h_d1, d1, b1, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(w.h_d2, d2, b2, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, launch_dist_i32(c, w.h_d1, n1, w.h_d2, n2, w.o_tab));
+    HIPCK(c, hipMemcpyAsync(out, w.o_tab, (size_t)n1 * n2 * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return XFH_OK;
+}
+
+// ------------------------------------------------------------------------- plumbing
+int xfh_synchronize(xfh_ctx* c) {
+    if (!c) return XFH_ERR_INVALID_ARG;
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return XFH_OK;
+}
+int xfh_set_stream(xfh_ctx* c, void* s) {
+    if (!c) return XFH_ERR_INVALID_ARG;
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    return XFH_OK;
+}
+const char* xfh_last_hip_error(xfh_ctx* c) { return c ? c->hip_err.c_str() : ""; }
+
+int xfh_dev_alloc(void** p, size_t n) { return hipMalloc(p, n) == hipSuccess ? XFH_OK : XFH_ERR_OUT_OF_MEMORY; }
+int xfh_dev_free(void* p) { return hipFree(p) == hipSuccess ? XFH_OK : XFH_ERR_HIP; }
+int xfh_memcpy_h2d(void* d, const void* s, size_t n) { return hipMemcpy(d, s, n, hipMemcpyHostToDevice) == hipSuccess ? XFH_OK : XFH_ERR_HIP; }
+int xfh_memcpy_d2h(void* d, const void* s, size_t n) { return hipMemcpy(d, s, n, hipMemcpyDeviceToHost) == hipSuccess ? XFH_OK : XFH_ERR_HIP; }
+
+// ------------------------------------------------------------------------- timing
+int xfh_timing_enable(xfh_ctx* c, int kernel_id, int conv_layer) {
+    if (!c || kernel_id < 0 || kernel_id >= XFH_K_COUNT) return XFH_ERR_INVALID_ARG;
+    KTimer& t = c->timer;
+    if (kernel_id != XFH_K_NONE && !t.ev) {
+        t.ev = (hipEvent_t*)calloc(2 * KTimer::MAXEV, sizeof(hipEvent_t));
+        for (int i = 0; i < 2 * KTimer::MAXEV; ++i) HIPCK(c, hipEventCreate(&t.ev[i]));
+    }
+    t.kernel_id = kernel_id; t.conv_layer = conv_layer; t.nev = 0; t.launches = 0;
+    return XFH_OK;
+}
+int xfh_timing_read(xfh_ctx* c, int* launches, double* total_ms) {
+    if (!c) return XFH_ERR_INVALID_ARG;
+    KTimer& t = c->timer;
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    double tot = 0.0;
+    for (int i = 0; i < t.nev; ++i) {
+        float ms = 0.f;
+        HIPCK(c, hipEventElapsedTime(&ms, t.ev[2 * i], t.ev[2 * i + 1]));
+        tot += ms;
+    }
+    if (launches) *launches = t.nev;
+    if (total_ms) *total_ms = tot;
+    t.nev = 0;
+    return XFH_OK;
+}
+
+// ------------------------------------------------------------------------- debug tensors
+int xfh_debug_tensor(xfh_ctx* c, int id, int frame, float* out, size_t cap, size_t* count_out) {
+    if (!c || frame < 0 || frame >= c->B || !count_out) return XFH_ERR_INVALID_ARG;
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    const size_t xs = (size_t)c->Hmax * c->Wmax;
+    const int H = c->H, W = c->W, h8 = H / 8, w8 = W / 8, h4 = H / 4, w4 = W / 4;
+    const float* src = nullptr; size_t n = 0;
+    switch (id) {
+        case XFH_T_X: src = c->X + frame * xs; n = (size_t)H * W; break;
+        case XFH_T_XSTAT: src = c->xstat + frame * 2; n = 2; break;
+        case XFH_T_SKIP_POOL: src = c->skip_pool + frame * (xs / 16); n = (size_t)h4 * w4; break;
+        case XFH_T_XUNFOLD: src = c->xunfold + frame * xs; n = (size_t)h8 * w8 * 64; break;
+        case XFH_T_B2IN: src = c->b2in + frame * c->raw_stride[3]; n = (size_t)h4 * w4 * 24; break;
+        case XFH_T_FUSE_IN: src = c->fuse_in + frame * c->raw_stride[8]; n = (size_t)h8 * w8 * 64; break;
+        case XFH_T_FEATS: src = c->feats + frame * c->raw_stride[17]; n = (size_t)h8 * w8 * 64; break;
+        case XFH_T_M1N: src = c->m1n + frame * c->raw_stride[17]; n = (size_t)h8 * w8 * 64; break;
+        case XFH_T_H1: src = c->H1 + frame * (xs / 64); n = (size_t)h8 * w8; break;
+        case XFH_T_K1H: src = c->K1h + frame * xs; n = (size_t)H * W; break;
+        default:
+            if (id >= XFH_T_RAW0 && id < XFH_T_RAW0 + XFH_NUM_LAYERS) {
+                const int i = id - XFH_T_RAW0;
+                src = c->raw[i] + frame * c->raw_stride[i]; n = (size_t)c->lh[i] * c->lw[i] * XFH_LAYERS[i].cout;
+            } else if (id >= XFH_T_STAT0 && id < XFH_T_STAT0 + XFH_NUM_LAYERS) {
+                const int i = id - XFH_T_STAT0;
+                src = c->stat[i] + (size_t)frame * 2 * XFH_LAYERS[i].cout; n = 2 * (size_t)XFH_LAYERS[i].cout;
+            } else if (id == XFH_T_SEL) {
+                int N = 0;
+                HIPCK(c, hipMemcpy(&N, c->sel_n + frame, sizeof(int), hipMemcpyDeviceToHost));
+                *count_out = (size_t)N * 3;
+                if (!out || cap < (size_t)N * 3) return out ? XFH_ERR_INVALID_ARG : XFH_OK;
+                std::vector<u64> keys((size_t)N);
+                if (N > 0) HIPCK(c, hipMemcpy(keys.data(), c->sel_key + (size_t)frame * c->cfg.nfeatures, (size_t)N * 8, hipMemcpyDeviceToHost));
+                for (int i = 0; i < N; ++i) {
+                    const unsigned idx = (unsigned)(keys[i] & 0xFFFFFFFFull);
+                    out[i * 3 + 0] = (float)(idx % (unsigned)W); out[i * 3 + 1] = (float)(idx / (unsigned)W);
+                    out[i * 3 + 2] = ord2f(~(unsigned)(keys[i] >> 32));
+                }
+                return XFH_OK;
+            } else return XFH_ERR_INVALID_ARG;
+    }
+    *count_out = n;
+    if (!out) return XFH_OK;
+    if (cap < n) return XFH_ERR_INVALID_ARG;
+    HIPCK(c, hipMemcpy(out, src, n * sizeof(float), hipMemcpyDeviceToHost));
+    return XFH_OK;
+}
+
+}  // extern "C"
+
+bool ktimer_begin(xfh_ctx* c, int kernel_id, int layer) {
+    KTimer& t = c->timer;
+    if (t.kernel_id == XFH_K_NONE || t.kernel_id != kernel_id) return false;
+    if (t.conv_layer >= 0 && layer != t.conv_layer) return false;
+    if (t.nev >= KTimer::MAXEV || !t.ev) return false;
+    hipEventRecord(t.ev[2 * t.nev], c->stream);
+    return true;
+}
+void ktimer_end(xfh_ctx* c, bool armed) {
+    if (!armed) return;
+    KTimer& t = c->timer;
+    hipEventRecord(t.ev[2 * t.nev + 1], c->stream);
+    ++t.nev;
+}

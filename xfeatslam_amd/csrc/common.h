@@ -1,0 +1,66 @@
+// common.h -- shared declarations of libxfeat_hip.so (gfx950 only, no CPU fallback).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/xfeat_hip.h"
+
+#define XFH_NUM_LAYERS 23
+#define XFH_DESC_DIM 64
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned long long u64;
+
+// XFeatModel::XFeatModel (reference src/XFeat.cc:41-90): BasicLayer(cin, cout, k, stride)
+struct LayerSpec { int cin, cout, ks, stride; const char* name; };
+static const LayerSpec XFH_LAYERS[XFH_NUM_LAYERS] = {
+    {1, 4, 3, 1, "block1.0"},   {4, 8, 3, 2, "block1.1"},   {8, 8, 3, 1, "block1.2"},
+    {8, 24, 3, 2, "block1.3"},  {24, 24, 3, 1, "block2.0"}, {24, 24, 3, 1, "block2.1"},
+    {24, 64, 3, 2, "block3.0"}, {64, 64, 3, 1, "block3.1"}, {64, 64, 1, 1, "block3.2"},
+    {64, 64, 3, 2, "block4.0"}, {64, 64, 3, 1, "block4.1"}, {64, 64, 3, 1, "block4.2"},
+    {64, 128, 3, 2, "block5.0"}, {128, 128, 3, 1, "block5.1"}, {128, 128, 3, 1, "block5.2"},
+    {128, 64, 1, 1, "block5.3"},
+    {64, 64, 3, 1, "block_fusion.0"}, {64, 64, 3, 1, "block_fusion.1"},
+    {64, 64, 1, 1, "heatmap_head.0"}, {64, 64, 1, 1, "heatmap_head.1"},
+    {64, 64, 1, 1, "keypoint_head.0"}, {64, 64, 1, 1, "keypoint_head.1"},
+    {64, 64, 1, 1, "keypoint_head.2"},
+};
+
+// monotone float -> uint map (larger float => larger uint) and its inverse
+__host__ __device__ inline unsigned f2ord(float f) {
+    unsigned u = __builtin_bit_cast(unsigned, f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__host__ __device__ inline float ord2f(unsigned u) {
+    u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    return __builtin_bit_cast(float, u);
+}
+
+// per-frame output record header (include/xfeat_hip.h, xfh_record_bytes)
+struct RecordHeader { int32_t n_valid, mono_index, n_candidates, reserved; };
+
+// ---- kernel timing hook ---------------------------------------------------------------
+struct KTimer {
+    int kernel_id = 0;
+    int conv_layer = -1;
+    int launches = 0;
+    static const int MAXEV = 4096;
+    hipEvent_t* ev = nullptr;   // 2*MAXEV events, lazily created
+    int nev = 0;
+};
+
+// ---- matcher workspace ----------------------------------------------------------------
+struct MatchWs {
+    u64* partR = nullptr; u64* partC = nullptr; size_t cap_part = 0;   // elements each
+    int* best12 = nullptr; float* val12 = nullptr; int* best21 = nullptr; size_t cap_best = 0;
+    float* h_d1 = nullptr; float* h_d2 = nullptr; size_t cap_in = 0;   // device staging of host inputs
+    int* o_idx1 = nullptr; int* o_idx2 = nullptr; float* o_dist = nullptr; int* o_n = nullptr; size_t cap_out = 0;
+    int32_t* o_tab = nullptr; size_t cap_tab = 0;
+};
+
+// ---- launchers implemented in the .hip files ------------------------------------------
+struct xfh_ctx;
+hipError_t launch_mnn(xfh_ctx* c, const float* d1, int n1, const float* d2, int n2, float min_cossim,
+                      int* idx1, int* idx2, float* dist, int* n_matches);
+hipError_t launch_dist_i32(xfh_ctx* c, const float* d1, int n1, const float* d2, int n2, int32_t* out);

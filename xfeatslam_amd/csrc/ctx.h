@@ -1,0 +1,63 @@
+// ctx.h -- the extractor/matcher context: all device memory is allocated once in xfh_create.
+#pragma once
+#include "common.h"
+#include <string>
+
+// packed device weights
+struct DevWeights {
+    float* direct[4] = {nullptr, nullptr, nullptr, nullptr};   // layers 0..3: [ky][kx][ci][co]
+    float* mfma[XFH_NUM_LAYERS] = {};                          // layers 4..22: [chunk][n][CB], k-permuted
+    float* fus2 = nullptr;                                     // block_fusion.2 packed like an MFMA layer
+    float* fus2_bias = nullptr;                                // [64]
+    float* skip_w = nullptr; float* skip_b = nullptr;          // [24] each
+    float* heat2_w = nullptr; float* heat2_b = nullptr;        // [64], [1]
+    float* kp3_w = nullptr; float* kp3_b = nullptr;            // [64][68] (k-major, 65 used), [65]
+    bool loaded = false;
+};
+
+struct xfh_ctx {
+    xfh_config cfg;
+    int Hmax = 0, Wmax = 0;         // resized maxima (multiples of 32)
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;   // own_stream or an external one
+    std::string hip_err;
+
+    DevWeights w;
+
+    // geometry of the last call
+    int B = 0, H0 = 0, W0 = 0, H = 0, W = 0;
+    int lh[XFH_NUM_LAYERS] = {}, lw[XFH_NUM_LAYERS] = {};     // output dims per layer
+    int npart[XFH_NUM_LAYERS] = {};                            // stat partials per frame per layer
+
+    // device buffers, all [max_batch][...]
+    uint8_t* d_gray = nullptr;                  // staging of host frames
+    float* X = nullptr;                         // [H][W]
+    double* pre_part = nullptr; int pre_npart = 0;
+    float* xstat = nullptr;                     // [B][2]
+    float* raw[XFH_NUM_LAYERS] = {};
+    double* part[XFH_NUM_LAYERS] = {};          // [B][npart][C][2]
+    float* stat[XFH_NUM_LAYERS] = {};           // [B][2*C]
+    size_t raw_stride[XFH_NUM_LAYERS] = {};     // floats per frame (at max size)
+    size_t part_stride[XFH_NUM_LAYERS] = {};    // doubles per frame
+    float* skip_pool = nullptr; float* xunfold = nullptr; float* b2in = nullptr;
+    float* fuse_in = nullptr; float* feats = nullptr; float* m1n = nullptr;
+    float* H1 = nullptr; float* K1h = nullptr;
+    u64* cand = nullptr; size_t cand_cap = 0;   // keys per frame (power of two >= Hmax*Wmax)
+    int* cand_count = nullptr;                  // [B]
+    int* slot_src = nullptr;                    // [B][nfeatures]
+    u64* sel_key = nullptr;                     // [B][nfeatures]
+    int* sel_n = nullptr;                       // [B]
+    uint8_t* d_records = nullptr;               // [B][record_bytes] for the host API
+    uint8_t* h_records = nullptr;               // pinned
+    uint8_t* h_gray = nullptr;                  // pinned
+
+    MatchWs mws;
+    KTimer timer;
+};
+
+// helpers implemented in capi.cpp
+bool ktimer_begin(xfh_ctx* c, int kernel_id, int layer);
+void ktimer_end(xfh_ctx* c, bool armed);
+
+// launchers (kernels_*.hip)
+hipError_t run_extract(xfh_ctx* c, const uint8_t* d_gray, int B, int H0, int W0, int lap0, int lap1, uint8_t* d_records);

@@ -1,0 +1,460 @@
+// kernels_conv.hip -- the XFeat backbone on gfx950 (reference XFeatModel::forward,
+// src/XFeat.cc:135-173; BasicLayer = Conv2d(bias=false) -> BatchNorm2d(batch statistics,
+// SURVEY.md Q1) -> ReLU, src/XFeat.cc:7-28).
+//
+// Data layout: activations are NHWC fp32, one slab per frame, and are stored RAW (conv
+// output before BatchNorm).  Every conv kernel also emits per-workgroup fp64 (sum, sum^2)
+// partials per output channel; k_bn_finalize folds them in a fixed order into (mean, rstd)
+// and the CONSUMER applies relu((x-mean)*rstd) while it stages its input tile.  That keeps
+// one pass over HBM per layer although the normalisation needs a frame-wide reduction.
+//
+//   k_conv_direct : block1 (C_in 1/4/8): one output pixel per lane, weights through the
+//                   scalar cache, input tile (+halo) in LDS.  HBM/latency bound.
+//   k_conv_mfma   : every other conv as an implicit GEMM on v_mfma_f32_32x32x2_f32:
+//                   M = output pixels (32 per wave), N = C_out (32 per MFMA tile),
+//                   K = (ky,kx,ci).  The activated input tile (+halo) sits in LDS for the
+//                   whole K loop; weights stream through a double-buffered LDS chunk.
+//   k_bn_finalize : partials -> mean / rstd.
+//
+// Numerics: each output is ONE fp32 fma chain in (ky,kx,ci) order starting at 0, which is
+// exactly what the f32 MFMA computes when K is walked in order with a single accumulator,
+// and what oracle/xfeat_oracle.c does; statistics are fp64.
+#include "ctx.h"
+
+struct ConvArgs {
+    const float* in;        // raw input slab (or plain input)
+    const float* in_stat;   // [B][2*CIN] mean, rstd of the producer (PRO_BN) / [B][2] (PRO_IN)
+    size_t in_stride;       // floats per frame
+    int Hin, Win;
+    const float* w;         // packed weights
+    const float* bias;      // EPI_BIAS only
+    float* out;             // raw output slab
+    size_t out_stride;
+    int Hout, Wout;
+    double* part;           // [B][npart][COUT][2]
+    size_t part_stride;     // doubles per frame
+    int tiles_x;
+};
+
+enum { PRO_PLAIN = 0, PRO_BN = 1, PRO_IN = 2 };
+enum { EPI_STATS = 0, EPI_BIAS = 1 };
+
+// ------------------------------------------------------------------------------------
+// statistics finalisation: grid = B, block = 256.  thread (c, j): channel c, slice j.
+__global__ __launch_bounds__(256)
+void k_bn_finalize(const double* __restrict__ part, size_t part_stride, int npart, int C, double count,
+                   float* __restrict__ stat /* [B][2*C] */) {
+    __shared__ double red[256 * 2];
+    const int b = blockIdx.x, t = threadIdx.x;
+    const int SL = 256 / C;
+    const int c = t % C, j = t / C;
+    const double* p = part + (size_t)b * part_stride;
+    double s = 0.0, ss = 0.0;
+    if (j < SL) {
+        for (int q = j; q < npart; q += SL) {
+            s += p[((size_t)q * C + c) * 2 + 0];
+            ss += p[((size_t)q * C + c) * 2 + 1];
+        }
+        red[(j * C + c) * 2 + 0] = s;
+        red[(j * C + c) * 2 + 1] = ss;
+    }
+    __syncthreads();
+    if (t < C) {
+        double S = 0.0, SS = 0.0;
+        for (int q = 0; q < SL; ++q) { S += red[(q * C + t) * 2 + 0]; SS += red[(q * C + t) * 2 + 1]; }
+        const double mean = S / count;
+        double var = SS / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        stat[(size_t)b * 2 * C + t] = (float)mean;
+        stat[(size_t)b * 2 * C + C + t] = (float)(1.0 / sqrt(var + 1e-5));
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// direct convolution 3x3 for block1.  16x16 output pixels per workgroup.
+template <int CIN, int COUT, int ST, int PRO>
+__global__ __launch_bounds__(256)
+void k_conv_direct(ConvArgs a) {
+    constexpr int TI = 15 * ST + 3;
+    constexpr int SL = 256 / COUT;
+    __shared__ __attribute__((aligned(16))) float s_in[TI * TI * CIN];
+    __shared__ __attribute__((aligned(16))) float s_out[256 * (COUT + 1)];
+    __shared__ double s_red[SL * COUT * 2];
+    const int t = threadIdx.x, b = blockIdx.z;
+    const int tile = blockIdx.x, tx0 = (tile % a.tiles_x) * 16, ty0 = (tile / a.tiles_x) * 16;
+    const float* in = a.in + (size_t)b * a.in_stride;
+    const float* st = a.in_stat + (size_t)b * 2 * (PRO == PRO_IN ? 1 : CIN);
+
+    // stage the activated input tile, zero outside the image (Conv2d zero padding)
+    constexpr int VEC = (CIN >= 4) ? 4 : 1;
+    constexpr int G = CIN / VEC;
+    for (int item = t; item < TI * TI * G; item += 256) {
+        const int pix = item / G, g = item % G;
+        const int iy = pix / TI, ix = pix % TI;
+        const int gy = ty0 * ST - 1 + iy, gx = tx0 * ST - 1 + ix;
+        const bool ok = gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win;
+        if constexpr (VEC == 4) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ok) {
+                v = *(const f32x4*)(in + ((size_t)gy * a.Win + gx) * CIN + g * 4);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float m = st[g * 4 + q], r = st[CIN + g * 4 + q];
+                    v[q] = fmaxf((v[q] - m) * r, 0.f);
+                }
+            }
+            *(f32x4*)(s_in + pix * CIN + g * 4) = v;
+        } else {
+            float v = 0.f;
+            if (ok) v = (in[(size_t)gy * a.Win + gx] - st[0]) * st[1];    // InstanceNorm, no ReLU
+            s_in[pix] = v;
+        }
+    }
+    __syncthreads();
+
+    const int tx = t & 15, ty = t >> 4;
+    float acc[COUT];
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) acc[co] = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const float* sp = s_in + ((ty * ST + ky) * TI + tx * ST + kx) * CIN;
+            float v[CIN];
+            if constexpr (VEC == 4) {
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const f32x4 q = *(const f32x4*)(sp + g * 4);
+                    v[g * 4 + 0] = q.x; v[g * 4 + 1] = q.y; v[g * 4 + 2] = q.z; v[g * 4 + 3] = q.w;
+                }
+            } else {
+                v[0] = sp[0];
+            }
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) {
+                const float* wr = a.w + ((ky * 3 + kx) * CIN + ci) * COUT;     // wave-uniform: scalar loads
+#pragma unroll
+                for (int co = 0; co < COUT; ++co) acc[co] = fmaf(v[ci], wr[co], acc[co]);
+            }
+        }
+
+    const int oy = ty0 + ty, ox = tx0 + tx;
+    const bool valid = oy < a.Hout && ox < a.Wout;
+    if (valid) {
+        float* o = a.out + (size_t)b * a.out_stride + ((size_t)oy * a.Wout + ox) * COUT;
+#pragma unroll
+        for (int g = 0; g < COUT / 4; ++g)
+            *(f32x4*)(o + g * 4) = f32x4{acc[g * 4], acc[g * 4 + 1], acc[g * 4 + 2], acc[g * 4 + 3]};
+    }
+    // per-channel fp64 partial sums of this tile
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) s_out[t * (COUT + 1) + co] = valid ? acc[co] : 0.f;
+    __syncthreads();
+    if (t < SL * COUT) {
+        const int c = t % COUT, j = t / COUT;
+        double s = 0.0, ss = 0.0;
+        for (int p = j; p < 256; p += SL) {
+            const double v = (double)s_out[p * (COUT + 1) + c];
+            s += v; ss = fma(v, v, ss);
+        }
+        s_red[(j * COUT + c) * 2 + 0] = s;
+        s_red[(j * COUT + c) * 2 + 1] = ss;
+    }
+    __syncthreads();
+    if (t < COUT) {
+        double S = 0.0, SS = 0.0;
+        for (int q = 0; q < SL; ++q) { S += s_red[(q * COUT + t) * 2 + 0]; SS += s_red[(q * COUT + t) * 2 + 1]; }
+        double* p = a.part + (size_t)b * a.part_stride + ((size_t)tile * COUT + t) * 2;
+        p[0] = S; p[1] = SS;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// implicit-GEMM convolution on the f32 matrix cores.
+//   WM x WN waves per workgroup; each wave owns 32 output pixels (WH x WW) and NT tiles of 32
+//   output channels.  COUTP = WN*NT*32 >= COUT (padded weight rows are zero).
+template <int CIN, int COUT, int KS, int ST, int WM, int WN, int NT, int WW, int PRO, int EPI>
+__global__ __launch_bounds__(64 * WM * WN)
+void k_conv_mfma(ConvArgs a) {
+    constexpr int NTHR = 64 * WM * WN;
+    constexpr int WH = 32 / WW, TH = WM * WH, TW = WW;
+    constexpr int COUTP = WN * NT * 32;
+    constexpr int PAD = KS / 2;
+    constexpr int TIH = (TH - 1) * ST + KS, TIW = (TW - 1) * ST + KS;
+    constexpr int CP = CIN + 4;                  // LDS pixel stride (floats)
+    constexpr int CB = CIN > 64 ? 64 : CIN;      // channels per weight chunk
+    constexpr int NCB = CIN / CB;
+    constexpr int NCHUNK = KS * KS * NCB;
+    constexpr int WS = CB + 4;                   // LDS weight row stride
+    constexpr int WCH = COUTP * CB;              // floats per chunk in global memory
+    constexpr int NWLD = (WCH / 4 + NTHR - 1) / NTHR;
+    constexpr int G = CIN / 8;
+    constexpr int IN_FLOATS = TIH * TIW * CP;
+    constexpr int W_FLOATS = COUTP * WS;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_in = smem;
+    float* s_w = smem + IN_FLOATS;               // two buffers of W_FLOATS
+    float* s_stat = s_w + 2 * W_FLOATS;          // 2*CIN floats (PRO_BN)
+
+    const int t = threadIdx.x, b = blockIdx.z;
+    const int tile = blockIdx.x, tx0 = (tile % a.tiles_x) * TW, ty0 = (tile / a.tiles_x) * TH;
+    const float* in = a.in + (size_t)b * a.in_stride;
+
+    // ---- issue the first weight chunk, stage producer statistics ------------------------
+    f32x4 wreg[NWLD];
+#pragma unroll
+    for (int q = 0; q < NWLD; ++q) {
+        const int f = t + q * NTHR;
+        if (f < WCH / 4) wreg[q] = *(const f32x4*)(a.w + (size_t)f * 4);
+    }
+    if constexpr (PRO == PRO_BN) {
+        const float* st = a.in_stat + (size_t)b * 2 * CIN;
+        for (int q = t; q < 2 * CIN; q += NTHR) s_stat[q] = st[q];
+        __syncthreads();
+    }
+    // ---- stage the activated input tile (zero padding outside the image) ----------------
+    for (int item = t; item < TIH * TIW * G; item += NTHR) {
+        const int pix = item / G, g = item % G;
+        const int iy = pix / TIW, ix = pix % TIW;
+        const int gy = ty0 * ST - PAD + iy, gx = tx0 * ST - PAD + ix;
+        f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
+        if (gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win) {
+            const float* p = in + ((size_t)gy * a.Win + gx) * CIN + g * 8;
+            v0 = *(const f32x4*)p;
+            v1 = *(const f32x4*)(p + 4);
+            if constexpr (PRO == PRO_BN) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    v0[q] = fmaxf((v0[q] - s_stat[g * 8 + q]) * s_stat[CIN + g * 8 + q], 0.f);
+                    v1[q] = fmaxf((v1[q] - s_stat[g * 8 + 4 + q]) * s_stat[CIN + g * 8 + 4 + q], 0.f);
+                }
+            }
+        }
+        // k permutation inside each group of 8: position 4*(k&1) + (k>>1)
+        float* d = s_in + pix * CP + g * 8;
+        *(f32x4*)d = f32x4{v0.x, v0.z, v1.x, v1.z};
+        *(f32x4*)(d + 4) = f32x4{v0.y, v0.w, v1.y, v1.w};
+    }
+    // first weight chunk -> LDS buffer 0
+#pragma unroll
+    for (int q = 0; q < NWLD; ++q) {
+        const int f = t + q * NTHR;
+        if (f < WCH / 4) {
+            const int n = f / (CB / 4), c4 = f % (CB / 4);
+            *(f32x4*)(s_w + n * WS + c4 * 4) = wreg[q];
+        }
+    }
+    __syncthreads();
+
+    const int wave = t >> 6, lane = t & 63, i = lane & 31, h = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    const int pr = i / WW, pc = i % WW;                     // pixel of this lane inside the wave tile
+    const int ly = (wm * WH + pr) * ST, lx = pc * ST;        // its top-left input position in the tile
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+
+    for (int ch = 0; ch < NCHUNK; ++ch) {
+        const int tap = ch / NCB, cb = ch % NCB;
+        const int ky = tap / KS, kx = tap % KS;
+        if (ch + 1 < NCHUNK) {
+            const float* wsrc = a.w + (size_t)(ch + 1) * WCH;
+#pragma unroll
+            for (int q = 0; q < NWLD; ++q) {
+                const int f = t + q * NTHR;
+                if (f < WCH / 4) wreg[q] = *(const f32x4*)(wsrc + (size_t)f * 4);
+            }
+        }
+        const float* pa = s_in + ((ly + ky) * TIW + lx + kx) * CP + cb * CB + 4 * h;
+        const float* pw = s_w + (ch & 1) * W_FLOATS + (wn * NT * 32 + i) * WS + 4 * h;
+#pragma unroll
+        for (int kk = 0; kk < CB / 8; ++kk) {
+            const f32x4 av = *(const f32x4*)(pa + kk * 8);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const f32x4 bv = *(const f32x4*)(pw + n * 32 * WS + kk * 8);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc[n], 0, 0, 0);
+            }
+        }
+        if (ch + 1 < NCHUNK) {
+            float* wd = s_w + ((ch + 1) & 1) * W_FLOATS;
+#pragma unroll
+            for (int q = 0; q < NWLD; ++q) {
+                const int f = t + q * NTHR;
+                if (f < WCH / 4) {
+                    const int n = f / (CB / 4), c4 = f % (CB / 4);
+                    *(f32x4*)(wd + n * WS + c4 * 4) = wreg[q];
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue ---------------------------------------------------------------------
+    // C/D layout: lane holds channel (lane&31) of tile n, pixels (r&3) + 8*(r>>2) + 4*h.
+    float* outp = a.out + (size_t)b * a.out_stride;
+    double sum[NT], sq[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int co = (wn * NT + n) * 32 + i;
+        sum[n] = 0.0; sq[n] = 0.0;
+        float bias = 0.f;
+        if constexpr (EPI == EPI_BIAS) bias = (co < COUT) ? a.bias[co] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int px = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int oy = ty0 + wm * WH + px / WW, ox = tx0 + px % WW;
+            if (oy < a.Hout && ox < a.Wout && co < COUT) {
+                float v = acc[n][r];
+                if constexpr (EPI == EPI_BIAS) v += bias;
+                outp[((size_t)oy * a.Wout + ox) * COUT + co] = v;
+                if constexpr (EPI == EPI_STATS) { const double dv = (double)v; sum[n] += dv; sq[n] = fma(dv, dv, sq[n]); }
+            }
+        }
+    }
+    if constexpr (EPI == EPI_STATS) {
+        double* s_red = (double*)smem;        // [WM][COUTP][2], the tiles are no longer needed
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            sum[n] += __shfl_xor(sum[n], 32);
+            sq[n] += __shfl_xor(sq[n], 32);
+            if (h == 0) {
+                const int co = (wn * NT + n) * 32 + i;
+                s_red[(wm * COUTP + co) * 2 + 0] = sum[n];
+                s_red[(wm * COUTP + co) * 2 + 1] = sq[n];
+            }
+        }
+        __syncthreads();
+        for (int co = t; co < COUT; co += NTHR) {
+            double S = 0.0, SS = 0.0;
+#pragma unroll
+            for (int m = 0; m < WM; ++m) { S += s_red[(m * COUTP + co) * 2 + 0]; SS += s_red[(m * COUTP + co) * 2 + 1]; }
+            double* p = a.part + (size_t)b * a.part_stride + ((size_t)tile * COUT + co) * 2;
+            p[0] = S; p[1] = SS;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// host side: layer -> template instance
+template <int CIN, int COUT, int KS, int ST, int WM, int WN, int NT, int WW, int PRO, int EPI>
+static hipError_t conv_mfma_launch(xfh_ctx* c, const ConvArgs& a, int B, int* npart_out) {
+    constexpr int WH = 32 / WW, TH = WM * WH, TW = WW;
+    constexpr int COUTP = WN * NT * 32;
+    constexpr int TIH = (TH - 1) * ST + KS, TIW = (TW - 1) * ST + KS;
+    constexpr int CB = CIN > 64 ? 64 : CIN;
+    constexpr size_t LDS = sizeof(float) * ((size_t)TIH * TIW * (CIN + 4) + 2 * (size_t)COUTP * (CB + 4) + 2 * CIN);
+    static_assert(LDS <= 160 * 1024, "LDS budget");
+    static_assert(sizeof(double) * WM * COUTP * 2 <= LDS, "stat scratch");
+    ConvArgs aa = a;
+    aa.tiles_x = (a.Wout + TW - 1) / TW;
+    const int tiles_y = (a.Hout + TH - 1) / TH;
+    const int ntile = aa.tiles_x * tiles_y;
+    if (npart_out) *npart_out = ntile;
+    auto kern = k_conv_mfma<CIN, COUT, KS, ST, WM, WN, NT, WW, PRO, EPI>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(ntile, 1, B), dim3(64 * WM * WN), LDS, c->stream, aa);
+    return hipGetLastError();
+}
+
+template <int CIN, int COUT, int ST, int PRO>
+static hipError_t conv_direct_launch(xfh_ctx* c, const ConvArgs& a, int B, int* npart_out) {
+    ConvArgs aa = a;
+    aa.tiles_x = (a.Wout + 15) / 16;
+    const int ntile = aa.tiles_x * ((a.Hout + 15) / 16);
+    if (npart_out) *npart_out = ntile;
+    hipLaunchKernelGGL((k_conv_direct<CIN, COUT, ST, PRO>), dim3(ntile, 1, B), dim3(256), 0, c->stream, aa);
+    return hipGetLastError();
+}
+
+// number of statistic partials a layer produces per frame (needed to size buffers up front)
+int conv_layer_npart(int li, int Hout, int Wout) {
+    auto cdiv = [](int a, int b) { return (a + b - 1) / b; };
+    if (li < 4) return cdiv(Wout, 16) * cdiv(Hout, 16);
+    switch (li) {
+        case 9: case 10: case 11: return cdiv(Wout, 8) * cdiv(Hout, 8);      // WM=2, WW=8
+        case 12: case 13: case 14: case 15: return cdiv(Wout, 8) * cdiv(Hout, 4);   // WM=1, WW=8
+        default: return cdiv(Wout, 16) * cdiv(Hout, 8);                       // WM=4, WW=16
+    }
+}
+
+// BasicLayer li: conv + statistics partials + finalize.  `in`/`in_stat`: producer tensors.
+hipError_t launch_basic_layer(xfh_ctx* c, int li, const float* in, size_t in_stride, const float* in_stat,
+                              int pro, int Hin, int Win, int B) {
+    const LayerSpec& L = XFH_LAYERS[li];
+    const int pad = L.ks / 2;
+    const int Hout = (Hin + 2 * pad - L.ks) / L.stride + 1, Wout = (Win + 2 * pad - L.ks) / L.stride + 1;
+    c->lh[li] = Hout; c->lw[li] = Wout;
+    ConvArgs a{};
+    a.in = in; a.in_stat = in_stat; a.in_stride = in_stride; a.Hin = Hin; a.Win = Win;
+    a.w = (li < 4) ? c->w.direct[li] : c->w.mfma[li];
+    a.bias = nullptr;
+    a.out = c->raw[li]; a.out_stride = c->raw_stride[li]; a.Hout = Hout; a.Wout = Wout;
+    a.part = c->part[li]; a.part_stride = c->part_stride[li];
+    int np = 0;
+    hipError_t e = hipSuccess;
+    const bool bn = (pro == PRO_BN);
+    bool armed = ktimer_begin(c, li < 4 ? XFH_K_CONV_DIRECT : XFH_K_CONV_MFMA, li);
+    switch (li) {
+        case 0: e = conv_direct_launch<1, 4, 1, PRO_IN>(c, a, B, &np); break;
+        case 1: e = conv_direct_launch<4, 8, 2, PRO_BN>(c, a, B, &np); break;
+        case 2: e = conv_direct_launch<8, 8, 1, PRO_BN>(c, a, B, &np); break;
+        case 3: e = conv_direct_launch<8, 24, 2, PRO_BN>(c, a, B, &np); break;
+        case 4: e = conv_mfma_launch<24, 24, 3, 1, 4, 1, 1, 16, PRO_PLAIN, EPI_STATS>(c, a, B, &np); break;  // input = b2in
+        case 5: e = conv_mfma_launch<24, 24, 3, 1, 4, 1, 1, 16, PRO_BN, EPI_STATS>(c, a, B, &np); break;
+        case 6: e = conv_mfma_launch<24, 64, 3, 2, 4, 1, 2, 16, PRO_BN, EPI_STATS>(c, a, B, &np); break;
+        case 7: e = conv_mfma_launch<64, 64, 3, 1, 4, 1, 2, 16, PRO_BN, EPI_STATS>(c, a, B, &np); break;
+        case 8: e = conv_mfma_launch<64, 64, 1, 1, 4, 1, 2, 16, PRO_BN, EPI_STATS>(c, a, B, &np); break;
+        case 9: e = conv_mfma_launch<64, 64, 3, 2, 2, 2, 1, 8, PRO_BN, EPI_STATS>(c, a, B, &np); break;
+        case 10: case 11: e = conv_mfma_launch<64, 64, 3, 1, 2, 2, 1, 8, PRO_BN, EPI_STATS>(c, a, B, &np); break;
+        case 12: e = conv_mfma_launch<64, 128, 3, 2, 1, 4, 1, 8, PRO_BN, EPI_STATS>(c, a, B, &np); break;
+        case 13: case 14: e = conv_mfma_launch<128, 128, 3, 1, 1, 4, 1, 8, PRO_BN, EPI_STATS>(c, a, B, &np); break;
+        case 15: e = conv_mfma_launch<128, 64, 1, 1, 1, 2, 1, 8, PRO_BN, EPI_STATS>(c, a, B, &np); break;
+        case 16: e = conv_mfma_launch<64, 64, 3, 1, 4, 1, 2, 16, PRO_PLAIN, EPI_STATS>(c, a, B, &np); break;  // input = fuse_in
+        case 17: e = conv_mfma_launch<64, 64, 3, 1, 4, 1, 2, 16, PRO_BN, EPI_STATS>(c, a, B, &np); break;
+        case 18: case 20:                                                                                      // inputs: feats / unfold(xhat)
+            e = conv_mfma_launch<64, 64, 1, 1, 4, 1, 2, 16, PRO_PLAIN, EPI_STATS>(c, a, B, &np); break;
+        case 19: case 21: case 22:
+            e = conv_mfma_launch<64, 64, 1, 1, 4, 1, 2, 16, PRO_BN, EPI_STATS>(c, a, B, &np); break;
+        default: return hipErrorInvalidValue;
+    }
+    ktimer_end(c, armed);
+    (void)bn;
+    if (e != hipSuccess) return e;
+    c->npart[li] = np;
+    hipLaunchKernelGGL(k_bn_finalize, dim3(B), dim3(256), 0, c->stream, (const double*)c->part[li], c->part_stride[li], np,
+                       L.cout, (double)Hout * (double)Wout, c->stat[li]);
+    return hipGetLastError();
+}
+
+// block_fusion.2: Conv2d(64,64,1) with bias, no BN (src/XFeat.cc:75) -> feats
+hipError_t launch_fusion_out(xfh_ctx* c, int Hh, int Wh, int B) {
+    ConvArgs a{};
+    a.in = c->raw[17]; a.in_stat = c->stat[17]; a.in_stride = c->raw_stride[17]; a.Hin = Hh; a.Win = Wh;
+    a.w = c->w.fus2; a.bias = c->w.fus2_bias;
+    a.out = c->feats; a.out_stride = c->raw_stride[17]; a.Hout = Hh; a.Wout = Wh;
+    a.part = nullptr; a.part_stride = 0;
+    bool armed = ktimer_begin(c, XFH_K_CONV_MFMA, 23);
+    hipError_t e = conv_mfma_launch<64, 64, 1, 1, 4, 1, 2, 16, PRO_BN, EPI_BIAS>(c, a, B, nullptr);
+    ktimer_end(c, armed);
+    return e;
+}
+
+// InstanceNorm statistics of the image reuse the finalize kernel with C = 1
+hipError_t launch_finalize_image(xfh_ctx* c, int B, int npart, double count) {
+    hipLaunchKernelGGL(k_bn_finalize, dim3(B), dim3(256), 0, c->stream, (const double*)c->pre_part,
+                       (size_t)c->pre_npart * 2, npart, 1, count, c->xstat);
+    return hipGetLastError();
+}

@@ -1,0 +1,543 @@
+// kernels_misc.hip -- everything around the convolutions of XFextractor::operator()
+// (reference src/XFextractor.cc:250-356) on gfx950:
+//   k_preproc      parseInput + preprocessTensor (:161-202) and InstanceNorm partial sums
+//   k_norm_aux     InstanceNorm apply, unfold2d(x,8) (XFeat.cc:124-133), AvgPool4 of skip1 (:36-39)
+//   k_b2in         x1 + skip1(x)                       (XFeat.cc:153)
+//   k_fuse_in      x3 + up(x4) + up(x5)                (XFeat.cc:159-166)
+//   k_feats_norm   F::normalize(M1, dim=1)             (XFextractor.cc:273)
+//   k_heads_final  heatmap_head.2 + sigmoid, keypoint_head.3 + softmax + depth-to-space
+//                  (XFeat.cc:81-82,89; XFextractor.cc:204-217)
+//   k_nms_score    5x5 NMS, threshold, nearest*bilinear score (XFextractor.cc:219-248, 280-282)
+//   k_select       top-k by (score desc, index asc), validity, lapping placement (:285-295, 310-343)
+//   k_desc         bilinear descriptor sampling + L2 normalise + record packing (:298-301, 323-343)
+// Compiled with -ffp-contract=off: every fused multiply-add below is written as fmaf().
+#include "ctx.h"
+
+// ---- small helpers -----------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+    v += __shfl_xor(v, 32); v += __shfl_xor(v, 16); v += __shfl_xor(v, 8);
+    v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
+    return v;
+}
+
+// ATen upsample_bilinear2d (align_corners=false) source index / weights; see oracle lin_coeff
+__device__ __forceinline__ void lin_coeff(int in, int out, int d, int& i0, int& i1, float& l0, float& l1) {
+    const float scale = (float)in / (float)out;
+    float src = fmaf(scale, (float)d + 0.5f, -0.5f);
+    if (src < 0.f) src = 0.f;
+    int a = (int)src;
+    if (a > in - 1) a = in - 1;
+    float lam = src - (float)a;
+    lam = fminf(fmaxf(lam, 0.f), 1.f);
+    i0 = a; i1 = a + ((a < in - 1) ? 1 : 0);
+    l1 = lam; l0 = 1.f - lam;
+}
+
+// normgrid (XFeat.cc:181-186) + grid_sample unnormalise (align_corners=false, ATen CPU form)
+__device__ __forceinline__ float grid_coord(int pos, int full, int size) {
+    const float g = 2.0f * ((float)pos / (float)(full - 1)) - 1.0f;
+    return (g + 1.0f) * ((float)size / 2.0f) - 0.5f;
+}
+
+// ---- k_preproc ---------------------------------------------------------------------------
+// grid (ceil(H*W/1024), 1, B), 256 threads, 4 consecutive pixels per thread.
+__global__ __launch_bounds__(256)
+void k_preproc(const uint8_t* __restrict__ gray, size_t gray_stride, int H0, int W0, int H, int W,
+               float* __restrict__ X, size_t x_stride, double* __restrict__ part, int npart) {
+    __shared__ double red[8];
+    const int t = threadIdx.x, b = blockIdx.z;
+    const uint8_t* g = gray + (size_t)b * gray_stride;
+    const int p0 = (blockIdx.x * 256 + t) * 4;
+    double s = 0.0, ss = 0.0;
+    if (p0 < H * W) {
+        const int y = p0 / W, x = p0 % W;
+        f32x4 v;
+        if (H == H0 && W == W0) {
+            const uchar4 u = *(const uchar4*)(g + (size_t)y * W0 + x);
+            v = f32x4{(float)u.x / 255.0f, (float)u.y / 255.0f, (float)u.z / 255.0f, (float)u.w / 255.0f};
+        } else {
+            int y0, y1; float hy0, hy1;
+            lin_coeff(H0, H, y, y0, y1, hy0, hy1);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                int x0, x1; float wx0, wx1;
+                lin_coeff(W0, W, x + q, x0, x1, wx0, wx1);
+                const float p00 = (float)g[(size_t)y0 * W0 + x0] / 255.0f, p01 = (float)g[(size_t)y0 * W0 + x1] / 255.0f;
+                const float p10 = (float)g[(size_t)y1 * W0 + x0] / 255.0f, p11 = (float)g[(size_t)y1 * W0 + x1] / 255.0f;
+                const float top = fmaf(wx0, p00, wx1 * p01), bot = fmaf(wx0, p10, wx1 * p11);
+                v[q] = fmaf(hy0, top, hy1 * bot);
+            }
+        }
+        *(f32x4*)(X + (size_t)b * x_stride + p0) = v;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const double d = (double)v[q]; s += d; ss = fma(d, d, ss); }
+    }
+    s = wave_sum(s); ss = wave_sum(ss);
+    if ((t & 63) == 0) { red[(t >> 6) * 2] = s; red[(t >> 6) * 2 + 1] = ss; }
+    __syncthreads();
+    if (t == 0) {
+        double* p = part + ((size_t)b * npart + blockIdx.x) * 2;
+        p[0] = (red[0] + red[2]) + (red[4] + red[6]);
+        p[1] = (red[1] + red[3]) + (red[5] + red[7]);
+    }
+}
+
+// ---- k_norm_aux: one thread per 4x4 pixel block -------------------------------------------
+__global__ __launch_bounds__(256)
+void k_norm_aux(const float* __restrict__ X, size_t x_stride, const float* __restrict__ xstat, int H, int W,
+                float* __restrict__ xunfold, size_t xu_stride, float* __restrict__ pool, size_t pool_stride) {
+    const int b = blockIdx.z;
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    const int w4 = W / 4, h4 = H / 4;
+    if (q >= w4 * h4) return;
+    const int by = q / w4, bx = q % w4;
+    const float m = xstat[b * 2], r = xstat[b * 2 + 1];
+    const float* x = X + (size_t)b * x_stride;
+    float* xu = xunfold + (size_t)b * xu_stride;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int y = by * 4 + i, xx = bx * 4;
+        f32x4 v = *(const f32x4*)(x + (size_t)y * W + xx);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] = (v[j] - m) * r; s += v[j]; }
+        // unfold2d: cell (y/8, x/8), channel (y%8)*8 + (x%8)
+        *(f32x4*)(xu + ((size_t)(y >> 3) * (W >> 3) + (xx >> 3)) * 64 + (y & 7) * 8 + (xx & 7)) = v;
+    }
+    pool[(size_t)b * pool_stride + q] = s / 16.0f;
+}
+
+// ---- k_b2in: relu(bn(raw3)) + (pool * w + b), one thread per (pixel, 4 channels) ------------
+__global__ __launch_bounds__(256)
+void k_b2in(const float* __restrict__ raw3, size_t raw_stride, const float* __restrict__ stat3,
+            const float* __restrict__ pool, size_t pool_stride, const float* __restrict__ sw, const float* __restrict__ sb,
+            int npix, float* __restrict__ out, size_t out_stride) {
+    const int b = blockIdx.z;
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= npix * 6) return;
+    const int pix = q / 6, g = q % 6;
+    const float* st = stat3 + (size_t)b * 48;
+    f32x4 v = *(const f32x4*)(raw3 + (size_t)b * raw_stride + (size_t)pix * 24 + g * 4);
+    const float p = pool[(size_t)b * pool_stride + pix];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = g * 4 + j;
+        const float a = fmaxf((v[j] - st[c]) * st[24 + c], 0.f);
+        v[j] = a + (p * sw[c] + sb[c]);
+    }
+    *(f32x4*)(out + (size_t)b * out_stride + (size_t)pix * 24 + g * 4) = v;
+}
+
+// ---- k_fuse_in: x3 + up2(x4) + up4(x5), one thread per (pixel, 4 channels) ------------------
+__device__ __forceinline__ f32x4 ld_act4(const float* raw, const float* st, int C, size_t pix, int g) {
+    f32x4 v = *(const f32x4*)(raw + pix * C + g * 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = fmaxf((v[j] - st[g * 4 + j]) * st[C + g * 4 + j], 0.f);
+    return v;
+}
+__device__ __forceinline__ f32x4 up_bilinear4(const float* raw, const float* st, int Hi, int Wi, int Ho, int Wo,
+                                               int y, int x, int g) {
+    int y0, y1, x0, x1; float hy0, hy1, wx0, wx1;
+    lin_coeff(Hi, Ho, y, y0, y1, hy0, hy1);
+    lin_coeff(Wi, Wo, x, x0, x1, wx0, wx1);
+    const f32x4 p00 = ld_act4(raw, st, 64, (size_t)y0 * Wi + x0, g), p01 = ld_act4(raw, st, 64, (size_t)y0 * Wi + x1, g);
+    const f32x4 p10 = ld_act4(raw, st, 64, (size_t)y1 * Wi + x0, g), p11 = ld_act4(raw, st, 64, (size_t)y1 * Wi + x1, g);
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float top = fmaf(wx0, p00[j], wx1 * p01[j]), bot = fmaf(wx0, p10[j], wx1 * p11[j]);
+        o[j] = fmaf(hy0, top, hy1 * bot);
+    }
+    return o;
+}
+__global__ __launch_bounds__(256)
+void k_fuse_in(const float* __restrict__ r3, size_t s3, const float* __restrict__ st3,
+               const float* __restrict__ r4, size_t s4, const float* __restrict__ st4, int H4, int W4,
+               const float* __restrict__ r5, size_t s5, const float* __restrict__ st5, int H5, int W5,
+               int Hh, int Wh, float* __restrict__ out, size_t so) {
+    const int b = blockIdx.z;
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= Hh * Wh * 16) return;
+    const int pix = q >> 4, g = q & 15;
+    const int y = pix / Wh, x = pix % Wh;
+    const f32x4 a = ld_act4(r3 + (size_t)b * s3, st3 + (size_t)b * 128, 64, (size_t)pix, g);
+    const f32x4 u4 = up_bilinear4(r4 + (size_t)b * s4, st4 + (size_t)b * 128, H4, W4, Hh, Wh, y, x, g);
+    const f32x4 u5 = up_bilinear4(r5 + (size_t)b * s5, st5 + (size_t)b * 128, H5, W5, Hh, Wh, y, x, g);
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = (a[j] + u4[j]) + u5[j];
+    *(f32x4*)(out + (size_t)b * so + (size_t)pix * 64 + g * 4) = o;
+}
+
+// ---- k_feats_norm: one wave per 1/8-res pixel, lane = channel -------------------------------
+__global__ __launch_bounds__(256)
+void k_feats_norm(const float* __restrict__ feats, size_t stride, int npix, float* __restrict__ out) {
+    const int b = blockIdx.z;
+    const int pix = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (pix >= npix) return;
+    const float v = feats[(size_t)b * stride + (size_t)pix * 64 + lane];
+    const double ss = wave_sum((double)v * (double)v);
+    const float nrm = fmaxf((float)sqrt(ss), 1e-12f);
+    out[(size_t)b * stride + (size_t)pix * 64 + lane] = v / nrm;
+}
+
+// ---- k_heads_final: 128 pixels per workgroup, one pixel per lane -----------------------------
+#define HF_PX 128
+#define HF_LD 129
+__global__ __launch_bounds__(HF_PX)
+void k_heads_final(const float* __restrict__ rawH, const float* __restrict__ statH,     // heatmap_head.1
+                   const float* __restrict__ rawK, const float* __restrict__ statK,     // keypoint_head.2
+                   size_t raw_stride, const float* __restrict__ wh, const float* __restrict__ bh,
+                   const float* __restrict__ wk /* [64][68] */, const float* __restrict__ bk /* [65] */,
+                   int Hh, int Wh, float* __restrict__ H1, size_t h1_stride, float* __restrict__ K1h, size_t k1h_stride) {
+    __shared__ float sA[64 * HF_LD];
+    const int t = threadIdx.x, b = blockIdx.z;
+    const int npix = Hh * Wh, p0 = blockIdx.x * HF_PX;
+    const int pix = p0 + t;
+    // ---- heatmap head: 64 -> 1, sigmoid (XFeat.cc:81-82)
+    {
+        const float* st = statH + (size_t)b * 128;
+        for (int item = t; item < HF_PX * 16; item += HF_PX) {
+            const int lp = item >> 4, g = item & 15;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (p0 + lp < npix) v = ld_act4(rawH + (size_t)b * raw_stride, st, 64, (size_t)(p0 + lp), g);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sA[(g * 4 + j) * HF_LD + lp] = v[j];
+        }
+        __syncthreads();
+        float acc = 0.f;
+        for (int k = 0; k < 64; ++k) acc = fmaf(sA[k * HF_LD + t], wh[k], acc);
+        acc += bh[0];
+        if (pix < npix) H1[(size_t)b * h1_stride + pix] = 1.0f / (1.0f + expf(-acc));
+        __syncthreads();
+    }
+    // ---- keypoint head: 64 -> 65, softmax, drop dustbin, depth-to-space (XFeat.cc:89, XFextractor.cc:204-217)
+    {
+        const float* st = statK + (size_t)b * 128;
+        for (int item = t; item < HF_PX * 16; item += HF_PX) {
+            const int lp = item >> 4, g = item & 15;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (p0 + lp < npix) v = ld_act4(rawK + (size_t)b * raw_stride, st, 64, (size_t)(p0 + lp), g);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sA[(g * 4 + j) * HF_LD + lp] = v[j];
+        }
+        __syncthreads();
+        float acc[65];
+#pragma unroll
+        for (int n = 0; n < 65; ++n) acc[n] = 0.f;
+#pragma unroll 2
+        for (int k = 0; k < 64; ++k) {
+            const float a = sA[k * HF_LD + t];
+            const float* wr = wk + k * 68;                 // wave-uniform row: scalar loads
+#pragma unroll
+            for (int n = 0; n < 65; ++n) acc[n] = fmaf(a, wr[n], acc[n]);
+        }
+        float mx = -__builtin_huge_valf();
+#pragma unroll
+        for (int n = 0; n < 65; ++n) { acc[n] += bk[n]; mx = fmaxf(mx, acc[n]); }
+        float sum = 0.f;
+#pragma unroll
+        for (int n = 0; n < 65; ++n) { acc[n] = expf(acc[n] - mx); sum += acc[n]; }
+        if (pix < npix) {
+            const int y = pix / Wh, x = pix % Wh;
+            float* o = K1h + (size_t)b * k1h_stride + (size_t)(8 * y) * (8 * Wh) + 8 * x;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                *(f32x4*)(o + (size_t)i * 8 * Wh) = f32x4{acc[i * 8] / sum, acc[i * 8 + 1] / sum, acc[i * 8 + 2] / sum, acc[i * 8 + 3] / sum};
+                *(f32x4*)(o + (size_t)i * 8 * Wh + 4) = f32x4{acc[i * 8 + 4] / sum, acc[i * 8 + 5] / sum, acc[i * 8 + 6] / sum, acc[i * 8 + 7] / sum};
+            }
+        }
+    }
+}
+
+// ---- k_nms_score: 32x32 pixels per workgroup ---------------------------------------------------
+__global__ __launch_bounds__(256)
+void k_nms_score(const float* __restrict__ K1h, size_t k_stride, const float* __restrict__ H1, size_t h_stride,
+                 int H, int W, float thr, u64* __restrict__ cand, size_t cand_cap, int* __restrict__ cand_count) {
+    __shared__ float s[36 * 37];
+    __shared__ float hm[36 * 33];
+    __shared__ u64 keys[1024];
+    __shared__ int cnt, base;
+    const int t = threadIdx.x, b = blockIdx.z;
+    const int tiles_x = (W + 31) / 32;
+    const int tx0 = (blockIdx.x % tiles_x) * 32, ty0 = (blockIdx.x / tiles_x) * 32;
+    const float* k = K1h + (size_t)b * k_stride;
+    const float NEG = -__builtin_huge_valf();
+    if (t == 0) cnt = 0;
+    for (int e = t; e < 36 * 36; e += 256) {
+        const int iy = e / 36, ix = e % 36;
+        const int gy = ty0 - 2 + iy, gx = tx0 - 2 + ix;
+        s[iy * 37 + ix] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? k[(size_t)gy * W + gx] : NEG;   // max_pool2d pads with -inf
+    }
+    __syncthreads();
+    for (int e = t; e < 36 * 32; e += 256) {
+        const int iy = e >> 5, ix = e & 31;
+        const float* r = s + iy * 37 + ix;
+        hm[iy * 33 + ix] = fmaxf(fmaxf(fmaxf(r[0], r[1]), fmaxf(r[2], r[3])), r[4]);
+    }
+    __syncthreads();
+    const int lx = t & 31, ly0 = (t >> 5) * 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int ly = ly0 + q;
+        const int gy = ty0 + ly, gx = tx0 + lx;
+        const float* c = hm + ly * 33 + lx;
+        const float m = fmaxf(fmaxf(fmaxf(c[0], c[33]), fmaxf(c[66], c[99])), c[132]);
+        const float v = s[(ly + 2) * 37 + lx + 2];
+        if (gy < H && gx < W && v == m && v > thr) {
+            // score = nearest(K1h) * bilinear(H1) at (x,y)   (XFextractor.cc:280)
+            const int Wh = W >> 3, Hh = H >> 3;
+            const float fx = nearbyintf(grid_coord(gx, W, W)), fy = nearbyintf(grid_coord(gy, H, H));
+            float nv = 0.f;
+            if (fx >= 0.f && fx <= (float)(W - 1) && fy >= 0.f && fy <= (float)(H - 1))
+                nv = k[(size_t)(int)fy * W + (int)fx];
+            const float ix = grid_coord(gx, W, Wh), iy = grid_coord(gy, H, Hh);
+            const float xw = floorf(ix), yn = floorf(iy);
+            const float w = ix - xw, e = 1.0f - w, n = iy - yn, so = 1.0f - n;
+            const float nw = e * so, ne = w * so, sw = e * n, se = w * n;
+            const int x0 = (int)xw, y0 = (int)yn, x1 = x0 + 1, y1 = y0 + 1;
+            const bool vx0 = x0 >= 0 && x0 < Wh, vx1 = x1 >= 0 && x1 < Wh, vy0 = y0 >= 0 && y0 < Hh, vy1 = y1 >= 0 && y1 < Hh;
+            const float* h1 = H1 + (size_t)b * h_stride;
+            const float a = (vx0 && vy0) ? h1[y0 * Wh + x0] : 0.f, bb = (vx1 && vy0) ? h1[y0 * Wh + x1] : 0.f;
+            const float d = (vx0 && vy1) ? h1[y1 * Wh + x0] : 0.f, g = (vx1 && vy1) ? h1[y1 * Wh + x1] : 0.f;
+            const float hb = ((a * nw + bb * ne) + d * sw) + g * se;
+            float score = nv * hb;
+            if (gx == 0 && gy == 0) score = -1.0f;                       // :281-282
+            const int pos = atomicAdd(&cnt, 1);
+            // ascending key order == descending score, then ascending linear index (stable argsort)
+            keys[pos] = ((u64)(~f2ord(score)) << 32) | (u64)(unsigned)(gy * W + gx);
+        }
+    }
+    __syncthreads();
+    if (t == 0) base = atomicAdd(&cand_count[b], cnt);
+    __syncthreads();
+    for (int e = t; e < cnt; e += 256)
+        if ((size_t)(base + e) < cand_cap) cand[(size_t)b * cand_cap + base + e] = keys[e];
+}
+
+// ---- k_select: one workgroup of 1024 threads per frame -------------------------------------------
+#define SEL_LDS_KEYS 16384
+template <bool LDSMEM>
+__device__ __forceinline__ void bitonic_sort(u64* a, int n, int t) {
+    for (int k = 2; k <= n; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int idx = t; idx < (n >> 1); idx += 1024) {
+                const int i = ((idx & ~(j - 1)) << 1) | (idx & (j - 1));
+                const int l = i | j;
+                const u64 x = a[i], y = a[l];
+                const bool asc = (i & k) == 0;
+                if ((x > y) == asc) { a[i] = y; a[l] = x; }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ __launch_bounds__(1024)
+void k_select(u64* __restrict__ cand, size_t cand_cap, const int* __restrict__ cand_count, int W, int nfeatures,
+              int lap0, int lap1, int* __restrict__ slot_src, u64* __restrict__ sel_key, int* __restrict__ sel_n,
+              uint8_t* __restrict__ records, size_t rec_bytes) {
+    extern __shared__ __attribute__((aligned(16))) u64 skeys[];
+    __shared__ int wsumF[16], wsumB[16], wsumV[16];
+    __shared__ int baseF, baseB, baseV;
+    const int t = threadIdx.x, b = blockIdx.x, lane = t & 63, wave = t >> 6;
+    u64* gk = cand + (size_t)b * cand_cap;
+    int C = cand_count[b];
+    if ((size_t)C > cand_cap) C = (int)cand_cap;
+    int n = 1024;
+    while (n < C) n <<= 1;
+    const u64* sorted;
+    if (n <= SEL_LDS_KEYS) {
+        for (int e = t; e < n; e += 1024) skeys[e] = (e < C) ? gk[e] : ~0ull;
+        __syncthreads();
+        bitonic_sort<true>(skeys, n, t);
+        sorted = skeys;
+    } else {
+        for (int e = C + t; e < n; e += 1024) gk[e] = ~0ull;
+        __syncthreads();
+        bitonic_sort<false>(gk, n, t);
+        sorted = gk;
+    }
+    const int N = C < nfeatures ? C : nfeatures;
+    for (int e = t; e < nfeatures; e += 1024) slot_src[(size_t)b * nfeatures + e] = -1;
+    if (t == 0) { baseF = 0; baseB = 0; baseV = 0; }
+    __syncthreads();
+    for (int i0 = 0; i0 < N; i0 += 1024) {
+        const int i = i0 + t;
+        bool valid = false, back = false;
+        u64 key = 0;
+        if (i < N) {
+            key = sorted[i];
+            const float score = ord2f(~(unsigned)(key >> 32));
+            const int x = (int)((unsigned)(key & 0xFFFFFFFFull) % (unsigned)W);
+            valid = score > 0.f;                                          // XFextractor.cc:313
+            back = valid && (x >= lap0 && x <= lap1);                     // :332
+            sel_key[(size_t)b * nfeatures + i] = key;
+        }
+        const bool front = valid && !back;
+        const u64 mF = __ballot(front), mB = __ballot(back);
+        const u64 lt = (1ull << lane) - 1ull;
+        if (lane == 0) { wsumF[wave] = __popcll(mF); wsumB[wave] = __popcll(mB); }
+        __syncthreads();
+        int oF = baseF, oB = baseB;
+        for (int w = 0; w < wave; ++w) { oF += wsumF[w]; oB += wsumB[w]; }
+        if (front) slot_src[(size_t)b * nfeatures + oF + __popcll(mF & lt)] = i;
+        if (back) slot_src[(size_t)b * nfeatures + (nfeatures - 1 - (oB + __popcll(mB & lt)))] = i;
+        __syncthreads();
+        if (t == 0) {
+            int sF = 0, sB = 0;
+            for (int w = 0; w < 16; ++w) { sF += wsumF[w]; sB += wsumB[w]; }
+            baseF += sF; baseB += sB;
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        sel_n[b] = N;
+        RecordHeader* hdr = (RecordHeader*)(records + (size_t)b * rec_bytes);
+        hdr->n_valid = baseF + baseB; hdr->mono_index = baseF; hdr->n_candidates = cand_count[b]; hdr->reserved = 0;
+    }
+    (void)wsumV; (void)baseV;
+}
+
+// ---- k_desc: one wave per output slot, lane = descriptor channel ---------------------------------
+__global__ __launch_bounds__(256)
+void k_desc(const float* __restrict__ m1n, size_t m_stride, const int* __restrict__ slot_src, const u64* __restrict__ sel_key,
+            int H, int W, int nfeatures, uint8_t* __restrict__ records, size_t rec_bytes, size_t kps_off, size_t desc_off) {
+    const int b = blockIdx.z;
+    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (slot >= nfeatures) return;
+    uint8_t* rec = records + (size_t)b * rec_bytes;
+    float* kp = (float*)(rec + kps_off + (size_t)slot * 28);
+    float* dd = (float*)(rec + desc_off + (size_t)slot * 256);
+    const int src = slot_src[(size_t)b * nfeatures + slot];
+    if (src < 0) {
+        // default cv::KeyPoint(): pt (0,0), size 0, angle -1, response 0, octave 0, class_id -1
+        if (lane < 5) kp[lane] = (lane == 3) ? -1.f : 0.f;
+        else if (lane < 7) ((int*)kp)[lane] = (lane == 5) ? 0 : -1;
+        dd[lane] = 0.f;
+        return;
+    }
+    const u64 key = sel_key[(size_t)b * nfeatures + src];
+    const float score = ord2f(~(unsigned)(key >> 32));
+    const unsigned idx = (unsigned)(key & 0xFFFFFFFFull);
+    const int x = (int)(idx % (unsigned)W), y = (int)(idx / (unsigned)W);
+    const int Wh = W >> 3, Hh = H >> 3;
+    const float ix = grid_coord(x, W, Wh), iy = grid_coord(y, H, Hh);
+    const float xw = floorf(ix), yn = floorf(iy);
+    const float w = ix - xw, e = 1.0f - w, n = iy - yn, so = 1.0f - n;
+    const float nw = e * so, ne = w * so, sw = e * n, se = w * n;
+    const int x0 = (int)xw, y0 = (int)yn, x1 = x0 + 1, y1 = y0 + 1;
+    const bool vx0 = x0 >= 0 && x0 < Wh, vx1 = x1 >= 0 && x1 < Wh, vy0 = y0 >= 0 && y0 < Hh, vy1 = y1 >= 0 && y1 < Hh;
+    const float* m = m1n + (size_t)b * m_stride;
+    const float a = (vx0 && vy0) ? m[((size_t)y0 * Wh + x0) * 64 + lane] : 0.f;
+    const float bb = (vx1 && vy0) ? m[((size_t)y0 * Wh + x1) * 64 + lane] : 0.f;
+    const float d = (vx0 && vy1) ? m[((size_t)y1 * Wh + x0) * 64 + lane] : 0.f;
+    const float g = (vx1 && vy1) ? m[((size_t)y1 * Wh + x1) * 64 + lane] : 0.f;
+    const float v = ((a * nw + bb * ne) + d * sw) + g * se;
+    const double ss = wave_sum((double)v * (double)v);
+    const float nrm = fmaxf((float)sqrt(ss), 1e-12f);
+    dd[lane] = v / nrm;
+    if (lane < 7) {
+        // KeyPoint(x, y, 1, -1, score): octave 0, class_id -1 (XFextractor.cc:329); the Long
+        // rescale at :304-305 multiplies by 1
+        const float val = lane == 0 ? (float)x : lane == 1 ? (float)y : lane == 2 ? 1.f : lane == 3 ? -1.f : score;
+        if (lane < 5) kp[lane] = val;
+        else ((int*)kp)[lane] = (lane == 5) ? 0 : -1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// pipeline
+hipError_t launch_basic_layer(xfh_ctx* c, int li, const float* in, size_t in_stride, const float* in_stat,
+                              int pro, int Hin, int Win, int B);
+hipError_t launch_fusion_out(xfh_ctx* c, int Hh, int Wh, int B);
+hipError_t launch_finalize_image(xfh_ctx* c, int B, int npart, double count);
+
+#define CK(x) do { hipError_t _e = (x); if (_e != hipSuccess) return _e; } while (0)
+enum { PRO_PLAIN = 0, PRO_BN = 1, PRO_IN = 2 };
+
+hipError_t run_extract(xfh_ctx* c, const uint8_t* d_gray, int B, int H0, int W0, int lap0, int lap1, uint8_t* d_records) {
+    const int H = (H0 / 32) * 32, W = (W0 / 32) * 32;
+    c->B = B; c->H0 = H0; c->W0 = W0; c->H = H; c->W = W;
+    const int h4 = H / 4, w4 = W / 4, h8 = H / 8, w8 = W / 8;
+    hipStream_t s = c->stream;
+    const size_t xs = (size_t)c->Hmax * c->Wmax;
+    const int nf = c->cfg.nfeatures;
+    const size_t rec = xfh_record_bytes(nf);
+
+    CK(hipMemsetAsync(c->cand_count, 0, sizeof(int) * B, s));
+    // image -> float, resize, InstanceNorm statistics
+    const int npre = (H * W + 1023) / 1024;
+    bool armed = ktimer_begin(c, XFH_K_PREPROC, -1);
+    hipLaunchKernelGGL(k_preproc, dim3(npre, 1, B), dim3(256), 0, s, d_gray, (size_t)H0 * W0, H0, W0, H, W, c->X, xs, c->pre_part, c->pre_npart);
+    ktimer_end(c, armed);
+    CK(hipGetLastError());
+    CK(launch_finalize_image(c, B, npre, (double)H * (double)W));
+    hipLaunchKernelGGL(k_norm_aux, dim3((h4 * w4 + 255) / 256, 1, B), dim3(256), 0, s, c->X, xs, c->xstat, H, W,
+                       c->xunfold, xs, c->skip_pool, xs / 16);
+    CK(hipGetLastError());
+    // block1
+    CK(launch_basic_layer(c, 0, c->X, xs, c->xstat, PRO_IN, H, W, B));
+    CK(launch_basic_layer(c, 1, c->raw[0], c->raw_stride[0], c->stat[0], PRO_BN, c->lh[0], c->lw[0], B));
+    CK(launch_basic_layer(c, 2, c->raw[1], c->raw_stride[1], c->stat[1], PRO_BN, c->lh[1], c->lw[1], B));
+    CK(launch_basic_layer(c, 3, c->raw[2], c->raw_stride[2], c->stat[2], PRO_BN, c->lh[2], c->lw[2], B));
+    // x1 + skip1(x)
+    hipLaunchKernelGGL(k_b2in, dim3((h4 * w4 * 6 + 255) / 256, 1, B), dim3(256), 0, s, c->raw[3], c->raw_stride[3], c->stat[3],
+                       c->skip_pool, xs / 16, c->w.skip_w, c->w.skip_b, h4 * w4, c->b2in, c->raw_stride[3]);
+    CK(hipGetLastError());
+    // block2, block3
+    CK(launch_basic_layer(c, 4, c->b2in, c->raw_stride[3], nullptr, PRO_PLAIN, h4, w4, B));
+    CK(launch_basic_layer(c, 5, c->raw[4], c->raw_stride[4], c->stat[4], PRO_BN, h4, w4, B));
+    CK(launch_basic_layer(c, 6, c->raw[5], c->raw_stride[5], c->stat[5], PRO_BN, h4, w4, B));
+    CK(launch_basic_layer(c, 7, c->raw[6], c->raw_stride[6], c->stat[6], PRO_BN, h8, w8, B));
+    CK(launch_basic_layer(c, 8, c->raw[7], c->raw_stride[7], c->stat[7], PRO_BN, h8, w8, B));
+    // block4, block5
+    CK(launch_basic_layer(c, 9, c->raw[8], c->raw_stride[8], c->stat[8], PRO_BN, h8, w8, B));
+    CK(launch_basic_layer(c, 10, c->raw[9], c->raw_stride[9], c->stat[9], PRO_BN, c->lh[9], c->lw[9], B));
+    CK(launch_basic_layer(c, 11, c->raw[10], c->raw_stride[10], c->stat[10], PRO_BN, c->lh[10], c->lw[10], B));
+    CK(launch_basic_layer(c, 12, c->raw[11], c->raw_stride[11], c->stat[11], PRO_BN, c->lh[11], c->lw[11], B));
+    CK(launch_basic_layer(c, 13, c->raw[12], c->raw_stride[12], c->stat[12], PRO_BN, c->lh[12], c->lw[12], B));
+    CK(launch_basic_layer(c, 14, c->raw[13], c->raw_stride[13], c->stat[13], PRO_BN, c->lh[13], c->lw[13], B));
+    CK(launch_basic_layer(c, 15, c->raw[14], c->raw_stride[14], c->stat[14], PRO_BN, c->lh[14], c->lw[14], B));
+    // pyramid fusion input
+    hipLaunchKernelGGL(k_fuse_in, dim3((h8 * w8 * 16 + 255) / 256, 1, B), dim3(256), 0, s,
+                       c->raw[8], c->raw_stride[8], c->stat[8], c->raw[11], c->raw_stride[11], c->stat[11], c->lh[11], c->lw[11],
+                       c->raw[15], c->raw_stride[15], c->stat[15], c->lh[15], c->lw[15], h8, w8, c->fuse_in, c->raw_stride[8]);
+    CK(hipGetLastError());
+    CK(launch_basic_layer(c, 16, c->fuse_in, c->raw_stride[8], nullptr, PRO_PLAIN, h8, w8, B));
+    CK(launch_basic_layer(c, 17, c->raw[16], c->raw_stride[16], c->stat[16], PRO_BN, h8, w8, B));
+    CK(launch_fusion_out(c, h8, w8, B));
+    hipLaunchKernelGGL(k_feats_norm, dim3((h8 * w8 + 3) / 4, 1, B), dim3(256), 0, s, c->feats, c->raw_stride[17], h8 * w8, c->m1n);
+    CK(hipGetLastError());
+    // heatmap head
+    CK(launch_basic_layer(c, 18, c->feats, c->raw_stride[17], nullptr, PRO_PLAIN, h8, w8, B));
+    CK(launch_basic_layer(c, 19, c->raw[18], c->raw_stride[18], c->stat[18], PRO_BN, h8, w8, B));
+    // keypoint head
+    CK(launch_basic_layer(c, 20, c->xunfold, xs, nullptr, PRO_PLAIN, h8, w8, B));
+    CK(launch_basic_layer(c, 21, c->raw[20], c->raw_stride[20], c->stat[20], PRO_BN, h8, w8, B));
+    CK(launch_basic_layer(c, 22, c->raw[21], c->raw_stride[21], c->stat[21], PRO_BN, h8, w8, B));
+    armed = ktimer_begin(c, XFH_K_HEADS, -1);
+    hipLaunchKernelGGL(k_heads_final, dim3((h8 * w8 + HF_PX - 1) / HF_PX, 1, B), dim3(HF_PX), 0, s,
+                       c->raw[19], c->stat[19], c->raw[22], c->stat[22], c->raw_stride[19], c->w.heat2_w, c->w.heat2_b,
+                       c->w.kp3_w, c->w.kp3_b, h8, w8, c->H1, xs / 64, c->K1h, xs);
+    ktimer_end(c, armed);
+    CK(hipGetLastError());
+    // NMS + score, top-k + placement, descriptors
+    armed = ktimer_begin(c, XFH_K_NMS, -1);
+    hipLaunchKernelGGL(k_nms_score, dim3(((W + 31) / 32) * ((H + 31) / 32), 1, B), dim3(256), 0, s, c->K1h, xs, c->H1, xs / 64,
+                       H, W, c->cfg.nms_threshold, c->cand, c->cand_cap, c->cand_count);
+    ktimer_end(c, armed);
+    CK(hipGetLastError());
+    static bool attr = false;
+    if (!attr) { CK(hipFuncSetAttribute((const void*)k_select, hipFuncAttributeMaxDynamicSharedMemorySize, SEL_LDS_KEYS * 8)); attr = true; }
+    armed = ktimer_begin(c, XFH_K_SELECT, -1);
+    hipLaunchKernelGGL(k_select, dim3(B), dim3(1024), SEL_LDS_KEYS * 8, s, c->cand, c->cand_cap, c->cand_count, W, nf, lap0, lap1,
+                       c->slot_src, c->sel_key, c->sel_n, d_records, rec);
+    ktimer_end(c, armed);
+    CK(hipGetLastError());
+    armed = ktimer_begin(c, XFH_K_DESC, -1);
+    hipLaunchKernelGGL(k_desc, dim3((nf + 3) / 4, 1, B), dim3(256), 0, s, c->m1n, c->raw_stride[17], c->slot_src, c->sel_key, H, W, nf,
+                       d_records, rec, xfh_record_kps_offset(), xfh_record_desc_offset(nf));
+    ktimer_end(c, armed);
+    return hipGetLastError();
+}
