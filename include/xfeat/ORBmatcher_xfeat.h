@@ -1,0 +1,72 @@
+/*
+ * ORBmatcher_xfeat.h -- the XFeat half of the reference's ORB_SLAM3::ORBmatcher
+ * (include/ORBmatcher.h:43,77) on top of include/xfeat_hip.h.
+ *
+ *   static int DescriptorDistance(const cv::Mat& a, const cv::Mat& b)   -- ORBmatcher.cc:2242-2250
+ *   void match(cv::Mat d1, cv::Mat d2, std::vector<cv::DMatch>& out)    -- declared :77, the
+ *        definition is commented out in the reference (ORBmatcher.cc:340-405); this supplies it.
+ *   TH_LOW / TH_HIGH                                                    -- ORBmatcher.cc:34-35
+ *
+ * Drop the two member definitions into src/ORBmatcher.cc or use this
+ * class directly.  Without OpenCV the cvlite mirrors of XFextractor.h are used.
+ */
+#ifndef XFEAT_ORBMATCHER_XFEAT_H
+#define XFEAT_ORBMATCHER_XFEAT_H
+
+#include "XFextractor.h"
+
+namespace xfeat {
+#if !XFEAT_HAVE_OPENCV
+namespace cvlite {
+struct DMatch {
+    int queryIdx = -1, trainIdx = -1, imgIdx = -1; float distance = 3.402823466e+38f;
+    DMatch() = default;
+    DMatch(int q, int t, float d) : queryIdx(q), trainIdx(t), distance(d) {}
+};
+}  // namespace cvlite
+#endif
+}  // namespace xfeat
+
+namespace ORB_SLAM3 {
+
+class XFmatcher {
+public:
+    using Mat = xfeat::cvx::Mat;
+    using DMatch = xfeat::cvx::DMatch;
+
+    static constexpr int TH_HIGH = 1000;   // ORBmatcher.cc:34, USE_ORB unset
+    static constexpr int TH_LOW = 100;     // ORBmatcher.cc:35
+
+    explicit XFmatcher(xfh_ctx* shared_ctx, float nnratio = 0.6f, bool checkOri = true)
+        : mfNNratio(nnratio), mbCheckOrientation(checkOri), ctx(shared_ctx) {}
+
+    // stateless and thread-safe like the reference's static member
+    static int DescriptorDistance(const Mat& a, const Mat& b) {
+        return xfh_descriptor_distance(a.template ptr<float>(0), b.template ptr<float>(0));
+    }
+
+    // mutual-nearest-neighbour cosine matching on the GPU
+    void match(const Mat& _frame1_desc, const Mat& _frame2_desc, std::vector<DMatch>& _matches, float min_cossim = -1.f) {
+        const int n1 = _frame1_desc.rows, n2 = _frame2_desc.rows;
+        _matches.clear();
+        if (n1 == 0 || n2 == 0) return;
+        const int nm = n1 < n2 ? n1 : n2;
+        i1.resize(nm); i2.resize(nm); d.resize(nm);
+        int n = 0;
+        const int rc = xfh_match_mnn(ctx, _frame1_desc.template ptr<float>(0), n1, _frame2_desc.template ptr<float>(0), n2,
+                                     min_cossim, i1.data(), i2.data(), d.data(), &n);
+        if (rc != XFH_OK) throw std::runtime_error(std::string("XFmatcher::match: ") + xfh_strerror(rc));
+        _matches.reserve(n);
+        for (int k = 0; k < n; ++k) _matches.emplace_back(DMatch(i1[k], i2[k], d[k]));   // :401
+    }
+
+protected:
+    float mfNNratio;
+    bool mbCheckOrientation;
+    xfh_ctx* ctx;
+    std::vector<int> i1, i2;
+    std::vector<float> d;
+};
+
+}  // namespace ORB_SLAM3
+#endif
