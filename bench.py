@@ -1,0 +1,227 @@
+#!/usr/bin/env python
+"""bench.py -- XFeat front-end throughput on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--height 480 --width 640]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the extraction hot path (XFextractor::operator(), reference
+src/XFextractor.cc:250-356) over one batch of B synthetic VGA frames per GPU, with the frames
+already resident in HBM and the 4096-row (keypoints, descriptors) records left in HBM; with
+N > 1 the step also all-gathers the records over RCCL (frame i -> GPU i mod N).
+`value` = frames/s over all GPUs.  The matching half of the metric (4096 x 4096 descriptor MNN
+match, pairs/s) is timed right after on descriptors of two extracted frames and reported in
+"match", with its own MFMA roofline line for k_mnn_gemm.  Rank 0 prints ONE JSON line.
+
+The CPU baseline is the oracle (oracle/, a C restatement of the reference; "port") timed on
+the host cores on a bounded sample of the same frames; the first frame's GPU output is checked
+against it (parity verdict in the JSON).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, dense f32 MFMA
+NFEATURES = 4096
+KP_GAIN = 6.0                     # "dense" synthetic weights: > 4096 NMS candidates at VGA
+DOMINANT_LAYERS = (7, 17)         # k_conv_mfma<64,64,3,1,4,1,2,16,PRO_BN,EPI_STATS>: block3.1, block_fusion.1
+
+
+def conv_flops(H, W):
+    """algorithmic flops per frame of the 3x3 64->64 layer at 1/8 resolution"""
+    return 2.0 * (H // 8) * (W // 8) * 64 * 64 * 9
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=16, help="frames per GPU per step")
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--match-iters", type=int, default=100)
+    ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the bounded CPU-baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0)); local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    N = max(world, 1)
+    torch = dist = None
+    if N > 1:
+        # torch only for the process group / RCCL; it must be imported before the HIP library
+        # so that both share one HIP runtime
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    from xfeatslam_amd import capi, synth, weights as WT
+    from xfeatslam_amd.extractor import Context
+    lib = capi.lib()
+    if lib.xfh_device_count() <= 0:
+        raise SystemExit("bench.py needs an MI355X: libxfeat_hip.so has no CPU fallback")
+
+    B, H, W, K = args.batch, args.height, args.width, args.steps
+    blob = WT.pack_blob(WT.make_synthetic(1234, KP_GAIN))
+    ctx = Context(nfeatures=NFEATURES, max_height=H, max_width=W, max_batch=B, device=local_rank if N > 1 else 0)
+    ctx.load_weights(blob)
+    # frame i of the global batch goes to rank i mod N  (weak scaling: B frames per GPU)
+    base = synth.frames(min(B, 8), H, W, seed=42 + 100 * rank)
+    frames = np.concatenate([base] * ((B + len(base) - 1) // len(base)))[:B]
+    rec_bytes = ctx.rec_bytes
+
+    if N > 1:
+        d_in = torch.from_numpy(frames).cuda()
+        d_rec = torch.empty(B * rec_bytes, dtype=torch.uint8, device="cuda")
+        d_all = torch.empty(N * B * rec_bytes, dtype=torch.uint8, device="cuda")
+        in_ptr, rec_ptr = d_in.data_ptr(), d_rec.data_ptr()
+        capi.check(lib.xfh_set_stream(ctx.h, C.c_void_p(torch.cuda.current_stream().cuda_stream)), ctx.h)
+    else:
+        d_in = capi.DeviceBuffer(frames.nbytes).upload(frames)
+        d_rec = capi.DeviceBuffer(B * rec_bytes)
+        in_ptr, rec_ptr = d_in.ptr, d_rec.ptr
+
+    def step():
+        capi.check(lib.xfh_extract_batch_device(ctx.h, in_ptr, B, H, W, 0, 0, rec_ptr), ctx.h)
+        if N > 1:
+            dist.all_gather_into_tensor(d_all, d_rec)
+
+    def sync():
+        if N > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+        ctx.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    layer_mask = sum(1 << l for l in DOMINANT_LAYERS)
+    ctx.timing_enable(capi.K["CONV_MFMA"], layer_mask)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    n_conv, ms_conv = ctx.timing_read()
+    ctx.timing_enable(0)
+    if N > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    frames_per_s = N * B * K / elapsed
+
+    # ---- matching leg: 4096 x 4096 MNN on the descriptors of frame 0 vs frame 1 (device resident) --------
+    nf = NFEATURES
+    d1p = rec_ptr + ctx.desc_off
+    d2p = rec_ptr + (rec_bytes if B > 1 else 0) + ctx.desc_off
+    mout = capi.DeviceBuffer(12 * nf + 64)
+
+    def match():
+        capi.check(lib.xfh_match_mnn_device(ctx.h, d1p, nf, d2p, nf, -1.0, mout.ptr, mout.ptr + 4 * nf, mout.ptr + 8 * nf, mout.ptr + 12 * nf), ctx.h)
+    for _ in range(5):
+        match()
+    ctx.synchronize()
+    ctx.timing_enable(capi.K["MNN_GEMM"])
+    t0 = time.perf_counter()
+    for _ in range(args.match_iters):
+        match()
+    ctx.synchronize()
+    match_dt = (time.perf_counter() - t0) / args.match_iters
+    n_gemm, ms_gemm = ctx.timing_read()
+    ctx.timing_enable(0)
+    n_matches = int(mout.download(np.int32, 1, 12 * nf)[0])
+
+    if rank != 0:
+        if N > 1:
+            dist.barrier(); dist.destroy_process_group()
+        return
+
+    # ---- roofline lines ------------------------------------------------------------------------------
+    conv_us = ms_conv / max(n_conv, 1) * 1e3
+    conv_tf = conv_flops(H, W) * B / (conv_us * 1e-6) / 1e12 if n_conv else 0.0
+    gemm_us = ms_gemm / max(n_gemm, 1) * 1e3
+    gemm_tf = 2.0 * nf * nf * 64 / (gemm_us * 1e-6) / 1e12 if n_gemm else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")     # written by tools/collect_profiles.sh from --pmc passes
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath))
+        except Exception:
+            traffic = None
+
+    # ---- CPU baseline + parity verdict (rank 0, N == 1 only) -------------------------------------------
+    cpu = None
+    parity = None
+    if N == 1 and args.cpu_frames > 0:
+        from oracle import oracle as O
+        orc = O.Oracle(blob)
+        nthr = O.get_threads()
+        recs = ctx.parse_records(d_rec.download(np.uint8, rec_bytes * B), B)
+        orc.extract(frames[0], nf, (0, 0))                          # warm-up + parity reference
+        t0 = time.perf_counter()
+        for i in range(args.cpu_frames):
+            ok, od, onv, omono = orc.extract(frames[i % B], nf, (0, 0))
+        cpu_dt = (time.perf_counter() - t0) / args.cpu_frames
+        ok, od, onv, omono = orc.extract(frames[0], nf, (0, 0))
+        hk, hd, hnv, hmono, hnc = recs[0]
+        vo, vh = ok["size"] > 0, hk["size"] > 0
+        so = set(zip(ok["x"][vo].astype(int).tolist(), ok["y"][vo].astype(int).tolist()))
+        sh = set(zip(hk["x"][vh].astype(int).tolist(), hk["y"][vh].astype(int).tolist()))
+        po = {(int(k["x"]), int(k["y"])): i for i, k in enumerate(ok) if k["size"] > 0}
+        ph = {(int(k["x"]), int(k["y"])): i for i, k in enumerate(hk) if k["size"] > 0}
+        common = [k for k in po if k in ph]
+        ddesc = max((float(np.abs(od[po[k]] - hd[ph[k]]).max()) for k in common), default=0.0)
+        d1h, d2h = recs[0][1], recs[min(1, B - 1)][1]
+        t0 = time.perf_counter()
+        om = O.match_mnn(d1h, d2h)
+        cpu_match_dt = time.perf_counter() - t0
+        hm = (mout.download(np.int32, n_matches), mout.download(np.int32, n_matches, 4 * nf))
+        parity = {"keypoint_sets_equal": so == sh, "n_valid": [int(onv), int(hnv)], "max_abs_desc_diff": ddesc,
+                  "match_pairs_equal": bool(np.array_equal(om[0], hm[0]) and np.array_equal(om[1], hm[1])),
+                  "n_candidates": int(hnc)}
+        cpu = {"value": 1.0 / cpu_dt, "unit": "frames/s", "cores": nthr, "kind": "port",
+               "sample": f"{args.cpu_frames} of the same {H}x{W} frames through oracle/xfeat_oracle.c (OpenMP, {nthr} threads); "
+                         f"4096x4096 MNN once: {nf * nf / cpu_match_dt:.3e} pairs/s",
+               "match_pairs_per_s": nf * nf / cpu_match_dt}
+
+    out = {
+        "metric": "XFeat frames/s (VGA, 4096 kpts) + 4096x4096 desc-match pairs/s",
+        "value": frames_per_s, "unit": "frames/s", "n_gpus": N, "steps": K, "warmup": args.warmup,
+        "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"configs[1]: {H}x{W} u8 frames, XFeat extract, nfeatures {nf}, {B} frames per GPU per step "
+                               f"(per-frame BatchNorm statistics), inputs and 4096-row records resident in HBM"
+                               + (", RCCL all-gather of records" if N > 1 else ""),
+                   "frames_per_gpu_per_step": B, "height": H, "width": W, "nfeatures": nf,
+                   "weights": f"synthetic seed 1234, keypoint-logit gain {KP_GAIN}", "parallelism": f"frames x{N}"},
+        "roofline": {"kernel": "k_conv_mfma<64,64,3,1,4,1,2,16,1,0> (block3.1, block_fusion.1: 3x3 64->64 at 1/8 res)",
+                     "bound": "mfma", "achieved": conv_tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                     "frac": conv_tf / PEAK_F32_MFMA_TFLOPS, "traffic": (traffic or {}).get("conv_bytes_per_launch"),
+                     "avg_launch_us": conv_us, "launches": n_conv, "flops_per_launch": conv_flops(H, W) * B},
+        "match": {"pairs_per_s": nf * nf / match_dt, "us_per_call": match_dt * 1e6, "n1": nf, "n2": nf, "n_matches": n_matches,
+                  "roofline": {"kernel": "k_mnn_gemm", "bound": "mfma", "achieved": gemm_tf, "peak": PEAK_F32_MFMA_TFLOPS,
+                               "unit": "TFLOP/s", "frac": gemm_tf / PEAK_F32_MFMA_TFLOPS,
+                               "traffic": (traffic or {}).get("gemm_bytes_per_launch"), "avg_launch_us": gemm_us,
+                               "launches": n_gemm, "flops_per_launch": 2.0 * nf * nf * 64}},
+        "cpu_baseline": cpu, "parity": parity,
+    }
+    print(json.dumps(out))
+    if N > 1:
+        dist.barrier(); dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

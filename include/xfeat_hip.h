@@ -153,7 +153,9 @@ enum {
     XFH_K_NMS = 4, XFH_K_SELECT = 5, XFH_K_DESC = 6, XFH_K_HEADS = 7, XFH_K_DIST_I32 = 8,
     XFH_K_PREPROC = 9, XFH_K_COUNT = 10
 };
-int xfh_timing_enable(xfh_ctx* ctx, int kernel_id, int conv_layer /* -1 = all layers */);
+/* layer_mask selects conv layers for XFH_K_CONV_*: 0 = every layer, else bit i = BasicLayer i
+ * (0..22 in XFeatModel order) and bit 23 = block_fusion.2 */
+int xfh_timing_enable(xfh_ctx* ctx, int kernel_id, unsigned layer_mask);
 int xfh_timing_read(xfh_ctx* ctx, int* launches, double* total_ms);
 const char* xfh_kernel_name(int kernel_id);
 

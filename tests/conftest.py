@@ -1,0 +1,63 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle_mod():
+    """the CPU oracle (test infrastructure only), built on demand"""
+    from oracle import oracle as O
+    O.build()
+    return O
+
+
+@pytest.fixture(scope="session")
+def weights_std():
+    from xfeatslam_amd import weights as WT
+    w = WT.make_synthetic(1234, 1.0)
+    return w, WT.pack_blob(w)
+
+
+@pytest.fixture(scope="session")
+def weights_dense():
+    from xfeatslam_amd import weights as WT
+    w = WT.make_synthetic(1234, 6.0)
+    return w, WT.pack_blob(w)
+
+
+def kp_set(kps):
+    v = kps["size"] > 0
+    return set(zip(kps["x"][v].astype(int).tolist(), kps["y"][v].astype(int).tolist()))
+
+
+def joined_desc_diff(k1, d1, k2, d2):
+    """max |desc| / |score| difference over keypoints present in both outputs (position join,
+    SURVEY.md Q10: keypoint order among near-tied scores is not defined by the reference)"""
+    a = {(int(k["x"]), int(k["y"])): i for i, k in enumerate(k1) if k["size"] > 0}
+    b = {(int(k["x"]), int(k["y"])): i for i, k in enumerate(k2) if k["size"] > 0}
+    common = [k for k in a if k in b]
+    if not common:
+        return 0.0, 0.0, 0
+    ia = np.array([a[k] for k in common]); ib = np.array([b[k] for k in common])
+    return (float(np.abs(d1[ia] - d2[ib]).max()), float(np.abs(k1["response"][ia] - k2["response"][ib]).max()), len(common))
+
+
+@pytest.fixture(scope="session")
+def gpu_lib():
+    """libxfeat_hip.so on a box with a GPU; fails loudly (no fallback) if it is not usable"""
+    from xfeatslam_amd import capi
+    L = capi.lib()
+    assert L.xfh_device_count() > 0, "no HIP device visible: gpu tests need an MI355X"
+    return L

@@ -1,0 +1,93 @@
+"""CPU tests: the C-ABI library loads and exports every symbol include/xfeat_hip.h declares
+(no compute without a GPU), host-side logic, C++ drop-in wrapper compiles."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from xfeatslam_amd import capi, synth, weights as WT
+
+
+def test_header_symbols_exported_and_bound():
+    hdr = open(os.path.join(ROOT, "include", "xfeat_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(xfh_[a-z0-9_]+)\s*\(", hdr))
+    bound = {s[0] for s in capi.SYMBOLS}
+    assert declared == bound, (declared ^ bound)
+    L = capi.lib()
+    for name in declared:
+        assert hasattr(L, name), name
+
+
+def test_abi_struct_layout_and_helpers():
+    L = capi.lib()
+    assert capi.KP_DTYPE.itemsize == 28 and C.sizeof(capi.Config) == 7 * 4 + 8 * 4
+    cfg = capi.Config(); L.xfh_config_default(C.byref(cfg))
+    assert (cfg.max_height, cfg.max_width, cfg.nfeatures, cfg.max_batch) == (480, 640, 4096, 1)
+    assert abs(cfg.nms_threshold - 0.05) < 1e-7
+    assert L.xfh_record_kps_offset() == 16
+    assert L.xfh_record_desc_offset(4096) % 256 == 0 and L.xfh_record_desc_offset(4096) >= 16 + 28 * 4096
+    assert L.xfh_record_bytes(4096) >= L.xfh_record_desc_offset(4096) + 4096 * 256
+    assert L.xfh_strerror(2) == b"empty image" and b"gfx950" in L.xfh_version()
+    for k in range(10):
+        assert L.xfh_kernel_name(k)
+
+
+def test_no_device_fails_loudly():
+    L = capi.lib()
+    if L.xfh_device_count() > 0:
+        pytest.skip("a GPU is present")
+    cfg = capi.Config(); L.xfh_config_default(C.byref(cfg))
+    h = C.c_void_p()
+    assert L.xfh_create(C.byref(cfg), C.byref(h)) == capi.ERR_NO_DEVICE      # never a CPU fallback
+    from xfeatslam_amd.extractor import Context
+    with pytest.raises(capi.XfhError):
+        Context()
+
+
+def test_descriptor_distance_host(oracle_mod):
+    from xfeatslam_amd.extractor import ORBmatcher
+    d1, d2 = synth.descriptor_sets(64, 64, noise=0.4, zero_rows=2)
+    for i in range(64):
+        assert ORBmatcher.DescriptorDistance(d1[i], d2[i]) == oracle_mod.descriptor_distance(d1[i], d2[i])
+    assert ORBmatcher.TH_LOW == 100 and ORBmatcher.TH_HIGH == 1000
+
+
+def test_weight_blob_roundtrip_and_determinism():
+    w = WT.make_synthetic(1234)
+    assert sum(v.size for v in w.values()) == WT.N_PARAMS == 657910
+    blob = WT.pack_blob(w)
+    w2 = WT.unpack_blob(blob)
+    assert list(w2) == [n for n, _ in WT.TENSORS]
+    assert all(np.array_equal(w[k], w2[k]) for k in w)
+    assert WT.pack_blob(WT.make_synthetic(1234)) == blob
+    assert float(np.abs(w["block3.1.layer.0.weight"]).max()) <= 1.0 / np.sqrt(576) + 1e-7
+    sd = {"net." + k: v for k, v in w.items()}
+    assert all(np.array_equal(WT.from_state_dict(sd)[k], w[k]) for k in w)
+    img = synth.image(64, 96, 5)
+    assert img.dtype == np.uint8 and img.min() == 0 and img.max() == 255 and np.array_equal(img, synth.image(64, 96, 5))
+
+
+def test_scale_tables_match_reference_formula():
+    # XFextractor.cc:80-96 with the TUM1.yaml values (scaleFactor 1.2, 8 levels), fp32 arithmetic
+    from xfeatslam_amd.extractor import scale_tables
+    sf, isf, s2, is2 = scale_tables(8, 1.2)
+    ref = [np.float32(1.0)]
+    for _ in range(7):
+        ref.append(np.float32(ref[-1] * np.float32(1.2)))
+    assert np.array_equal(sf, np.array(ref, np.float32)) and np.array_equal(s2, sf * sf)
+    assert np.array_equal(isf, np.float32(1.0) / sf) and np.array_equal(is2, np.float32(1.0) / s2)
+    assert sf.dtype == np.float32 and len(sf) == 8
+
+
+def test_cpp_dropin_compiles_and_links():
+    out = "/tmp/xfh_dropin_test"
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-I" + os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "cpp", "dropin_test.cpp"), "-L" + os.path.join(ROOT, "xfeatslam_amd"), "-lxfeat_hip",
+           "-Wl,-rpath," + os.path.join(ROOT, "xfeatslam_amd"), "-Wl,-rpath,/opt/rocm/lib", "-o", out]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr

@@ -1,0 +1,157 @@
+"""GPU parity tests of XFextractor::operator() through the C ABI against the oracle and the
+goldens: identical keypoint sets and placement, descriptors within 1e-4 (north_star), plus
+stage-by-stage tensors, batching, edge cases and size-independent properties."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, joined_desc_diff, kp_set
+from xfeatslam_amd import capi, synth, weights as WT
+
+pytestmark = pytest.mark.gpu
+DESC_TOL = 1e-4
+
+
+def _ctx(nf, H, W, B=1):
+    from xfeatslam_amd.extractor import Context
+    return Context(nfeatures=nf, max_height=H, max_width=W, max_batch=B)
+
+
+@pytest.mark.parametrize("H,W,gain,nf,lap", [(96, 128, 1.0, 256, (0, 0)), (480, 640, 1.0, 4096, (0, 0)),
+                                              (480, 640, 6.0, 4096, (0, 1000)), (480, 640, 6.0, 1000, (200, 400)),
+                                              (720, 1280, 1.0, 4096, (0, 1000)), (170, 230, 2.0, 300, (100, 150))])
+def test_extract_matches_oracle(gpu_lib, oracle_mod, H, W, gain, nf, lap):
+    blob = WT.pack_blob(WT.make_synthetic(1234, gain))
+    img = synth.image(H, W, 42)
+    ok, od, onv, omono = oracle_mod.Oracle(blob).extract(img, nf, lap)
+    ctx = _ctx(nf, H, W)
+    ctx.load_weights(blob)
+    (hk, hd, hnv, hmono, hnc), = ctx.extract_batch(img[None], lap)
+    ctx.close()
+    assert (hnv, hmono) == (onv, omono)
+    assert kp_set(hk) == kp_set(ok)                                   # identical keypoint index sets
+    dd, ds, n = joined_desc_diff(hk, hd, ok, od)
+    assert n == onv and dd < DESC_TOL and ds < 1e-6
+    pad = hk["size"] == 0
+    assert np.array_equal(pad, ok["size"] == 0)                        # same slots filled (front / back)
+    assert np.all(hd[pad] == 0) and np.array_equal(hk[pad], ok[pad])   # padding = default KeyPoint, zero rows
+    nrm = np.linalg.norm(hd[~pad].astype(np.float64), axis=1)
+    assert np.all(np.abs(nrm - 1.0) < 1e-5)                            # unit descriptors
+
+
+@pytest.mark.parametrize("name", ["extract_96x128", "extract_vga", "extract_vga_dense_mono", "extract_720p", "extract_odd_170x230"])
+def test_extract_matches_golden(gpu_lib, name):
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    H, W, nf = int(g["H"]), int(g["W"]), int(g["nfeatures"])
+    ctx = _ctx(nf, H, W)
+    ctx.load_weights(WT.pack_blob(WT.make_synthetic(1234, float(g["gain"]))))
+    (kps, desc, nv, mono, nc), = ctx.extract_batch(synth.image(H, W, int(g["seed"]))[None], tuple(int(v) for v in g["lap"]))
+    ctx.close()
+    assert (nv, mono, nc) == (int(g["n_valid"]), int(g["mono_index"]), int(g["n_candidates"]))
+    assert kp_set(kps) == set(map(tuple, g["xy"].tolist()))
+    pos = {(int(k["x"]), int(k["y"])): i for i, k in enumerate(kps) if k["size"] > 0}
+    idx = np.array([pos[tuple(p)] for p in g["xy"].tolist()])
+    assert np.abs(kps["response"][idx] - g["score"]).max() < 1e-5
+    ridx = np.array([pos[tuple(p)] for p in g["desc_rows_xy"].tolist()])
+    assert np.abs(desc[ridx] - g["desc_rows"]).max() < DESC_TOL
+
+
+def test_stage_tensors_match_oracle(gpu_lib, oracle_mod, weights_std):
+    """every intermediate of the forward pass; convolutions and statistics are the same fp32/fp64
+    expression on both sides (one fma chain in (ky,kx,ci) order) -> expected bit exact"""
+    _, blob = weights_std
+    img = synth.image(160, 224, 9)
+    orc = oracle_mod.Oracle(blob); orc.extract(img, 512, (0, 0))
+    ctx = _ctx(512, 160, 224); ctx.load_weights(blob); ctx.extract_batch(img[None])
+    T, OT = capi.T, oracle_mod.T
+    for nm in ["X", "XSTAT", "SKIP_POOL", "XUNFOLD", "B2IN", "FUSE_IN", "FEATS", "M1N"]:
+        assert np.array_equal(ctx.debug_tensor(T[nm]), orc.tensor(OT[nm])), nm
+    for i in range(23):
+        a, b = ctx.debug_tensor(T["RAW0"] + i), orc.tensor(OT["RAW0"] + i)
+        assert a.shape == b.shape and np.abs(a - b).max() <= 1e-5, f"raw {i}"
+        assert np.abs(ctx.debug_tensor(T["STAT0"] + i) - orc.tensor(OT["STAT0"] + i)).max() <= 1e-5, f"stat {i}"
+    assert np.abs(ctx.debug_tensor(T["H1"]) - orc.tensor(OT["H1"])).max() < 1e-6        # expf differs by <= 1 ulp
+    assert np.abs(ctx.debug_tensor(T["K1H"]) - orc.tensor(OT["K1H"])).max() < 1e-6
+    hs, os_ = ctx.debug_tensor(T["SEL"]).reshape(-1, 3), orc.tensor(OT["SEL"]).reshape(-1, 3)
+    assert set(map(tuple, hs[:, :2].astype(int))) == set(map(tuple, os_[:, :2].astype(int)))
+    ctx.close()
+
+
+def test_batch_is_per_frame(gpu_lib, oracle_mod, weights_dense):
+    """frames in one batch are normalised with their OWN statistics (the reference is always B=1):
+    a batched call equals single-frame calls bit for bit, and is deterministic run to run"""
+    _, blob = weights_dense
+    fr = synth.frames(5, 96, 160, seed=11)
+    fr[3] = 200                                              # a constant frame in the middle of the batch
+    ctx = _ctx(200, 96, 160, B=5); ctx.load_weights(blob)
+    batch = ctx.extract_batch(fr, (0, 50))
+    again = ctx.extract_batch(fr, (0, 50))
+    for b in range(5):
+        single, = ctx.extract_batch(fr[b:b + 1], (0, 50))
+        for x, y, z in zip(batch[b], single, again[b]):
+            assert np.array_equal(x, y) and np.array_equal(x, z)
+        ok, od, onv, omono = oracle_mod.Oracle(blob).extract(fr[b], 200, (0, 50))
+        assert (batch[b][2], batch[b][3]) == (onv, omono) and kp_set(batch[b][0]) == kp_set(ok)
+    assert batch[3][2] == 0 and np.all(batch[3][1] == 0)     # constant frame: no keypoints, all padding
+    ctx.close()
+
+
+def test_status_codes_and_api_surface(gpu_lib, weights_std):
+    L = gpu_lib
+    _, blob = weights_std
+    from xfeatslam_amd.extractor import XFextractor
+    ex = XFextractor.__new__(XFextractor)
+    ctx = _ctx(100, 64, 96)
+    img = synth.image(64, 96, 1)
+    kps = np.zeros(100, capi.KP_DTYPE); desc = np.zeros((100, 64), np.float32)
+    nv, mono = C.c_int(), C.c_int()
+    args = (img.ctypes.data, 64, 96, 96, 0, 0, kps.ctypes.data, desc.ctypes.data, C.byref(nv), C.byref(mono))
+    assert L.xfh_extract(ctx.h, *args) == 4                                   # no weights yet
+    assert L.xfh_load_weights(ctx.h, b"garbage" * 10, 70) == 5
+    ctx.load_weights(blob)
+    assert L.xfh_extract(ctx.h, None, 64, 96, 96, 0, 0, kps.ctypes.data, desc.ctypes.data, C.byref(nv), C.byref(mono)) == 2   # empty image
+    assert L.xfh_extract(ctx.h, img.ctypes.data, 16, 16, 16, 0, 0, kps.ctypes.data, desc.ctypes.data, C.byref(nv), C.byref(mono)) == 3
+    assert L.xfh_extract(ctx.h, img.ctypes.data, 640, 640, 640, 0, 0, kps.ctypes.data, desc.ctypes.data, C.byref(nv), C.byref(mono)) == 3
+    assert L.xfh_extract(ctx.h, *args) == 0 and L.xfh_detect_and_compute(ctx.h, *args) == 0
+    # strided input (cv::Mat with padding) gives the same result as the dense one
+    k0, d0 = kps.copy(), desc.copy()
+    padded = np.zeros((64, 128), np.uint8); padded[:, :96] = img
+    assert L.xfh_extract(ctx.h, padded.ctypes.data, 64, 96, 128, 0, 0, kps.ctypes.data, desc.ctypes.data, C.byref(nv), C.byref(mono)) == 0
+    assert np.array_equal(k0, kps) and np.array_equal(d0, desc)
+    ctx.close()
+    # python mirror of the reference class: -1 on empty image, nfeatures rows, getters
+    ex = XFextractor(100, 1.2, 8, 20, 7, weights=blob, max_height=64, max_width=96)
+    assert ex(np.zeros((0, 0), np.uint8))[0] == -1
+    ret, k, d = ex(img, None, (0, 0))
+    assert ret == nv.value and len(k) == 100 and d.shape == (100, 64) and ex.GetLevels() == 8
+    assert abs(ex.GetScaleFactors()[7] - 1.2 ** 7) < 1e-4 and len(ex.mvImagePyramid) == 8
+    ret, k, d = ex(np.full((64, 96), 7, np.uint8))
+    assert ret == 0 and d is None                                              # _descriptors.release()
+
+
+def test_extract_to_match_device_resident(gpu_lib, oracle_mod, weights_dense):
+    """records stay in HBM between xfh_extract_batch_device and xfh_match_mnn_device"""
+    L = gpu_lib
+    _, blob = weights_dense
+    nf = 512
+    fr = np.stack([synth.image(128, 160, 3), np.roll(synth.image(128, 160, 3), 2, axis=1)])
+    ctx = _ctx(nf, 128, 160, B=2); ctx.load_weights(blob)
+    din = capi.DeviceBuffer(fr.nbytes).upload(fr)
+    rec = capi.DeviceBuffer(ctx.rec_bytes * 2)
+    capi.check(L.xfh_extract_batch_device(ctx.h, din.ptr, 2, 128, 160, 0, 0, rec.ptr), ctx.h)
+    out = capi.DeviceBuffer(12 * nf + 64)
+    d1p, d2p = rec.ptr + ctx.desc_off, rec.ptr + ctx.rec_bytes + ctx.desc_off
+    capi.check(L.xfh_match_mnn_device(ctx.h, d1p, nf, d2p, nf, -1.0, out.ptr, out.ptr + 4 * nf, out.ptr + 8 * nf, out.ptr + 12 * nf), ctx.h)
+    ctx.synchronize()
+    k = int(out.download(np.int32, 1, 12 * nf)[0])
+    i1, i2 = out.download(np.int32, k), out.download(np.int32, k, 4 * nf)
+    recs = ctx.parse_records(rec.download(np.uint8, ctx.rec_bytes * 2), 2)
+    a = oracle_mod.match_mnn(recs[0][1], recs[1][1])
+    assert np.array_equal(a[0], i1) and np.array_equal(a[1], i2)
+    # most matched keypoints are the 2-pixel shift of each other
+    dx = recs[1][0]["x"][i2] - recs[0][0]["x"][i1]; dy = recs[1][0]["y"][i2] - recs[0][0]["y"][i1]
+    good = (recs[0][0]["size"][i1] > 0) & (recs[1][0]["size"][i2] > 0)
+    assert good.sum() > 50 and np.mean((dx[good] == 2) & (dy[good] == 0)) > 0.5
+    ctx.close()

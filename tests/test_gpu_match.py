@@ -1,0 +1,103 @@
+"""GPU parity tests of the matching half through the C ABI (xfh_match_mnn*, xfh_distance_i32*)
+against the oracle and the committed goldens.  Pair lists must be identical; distances are the
+same fp32 expression on both sides (bit exact)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from xfeatslam_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mctx(gpu_lib):
+    from xfeatslam_amd.extractor import Context
+    c = Context(nfeatures=64, max_height=32, max_width=32)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("n1,n2,zero,noise", [(256, 256, 0, 0.3), (300, 200, 7, 0.3), (1, 5, 0, 0.3), (5, 1, 0, 0.3),
+                                               (129, 127, 0, 0.5), (128, 128, 0, 0.3), (1000, 4096, 0, 0.4),
+                                               (4096, 4096, 0, 0.3), (4096, 4096, 100, 0.3)])
+def test_mnn_matches_oracle(mctx, oracle_mod, n1, n2, zero, noise):
+    d1, d2 = synth.descriptor_sets(n1, n2, zero_rows=zero, noise=noise)
+    a = oracle_mod.match_mnn(d1, d2)
+    b = mctx.match_mnn(d1, d2)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert np.array_equal(a[2], b[2], equal_nan=True)            # same fp32 expression: bit exact
+    assert np.all(np.diff(b[0]) > 0)                             # ascending queryIdx, one match per row
+
+
+@pytest.mark.parametrize("name", ["match_256", "match_300x200_zero7", "match_4096", "match_4096_zero100"])
+def test_mnn_matches_golden(mctx, name):
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    d1, d2 = synth.descriptor_sets(int(g["n1"]), int(g["n2"]), zero_rows=int(g["zero_rows"]), noise=float(g["noise"]))
+    i1, i2, dist = mctx.match_mnn(d1, d2)
+    assert np.array_equal(i1, g["idx1"]) and np.array_equal(i2, g["idx2"])      # identical match pairs
+    assert np.allclose(dist, g["dist"], atol=2e-6, equal_nan=True)
+    assert np.array_equal(mctx.distance_i32(d1[:48], d2[:40]), g["dist_i32_corner"])
+
+
+def test_mnn_edge_cases(mctx, oracle_mod):
+    d1, d2 = synth.descriptor_sets(200, 180, noise=0.2)
+    # duplicate rows => exact ties; first maximum (lowest index) wins on both axes
+    d2[10] = d2[3]; d2[77] = d2[3]; d1[50] = d1[20]
+    a = oracle_mod.match_mnn(d1, d2); b = mctx.match_mnn(d1, d2)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert 10 not in b[1].tolist() and 77 not in b[1].tolist() and 50 not in b[0].tolist()
+    # zero-padded rows take part: (0,0) is reported with dist sqrt(2)
+    z1 = d1.copy(); z2 = d2.copy(); z1[0] = 0; z2[0] = 0
+    z1[1:] = np.abs(z1[1:]); z2[1:] = -np.abs(z2[1:])
+    a = oracle_mod.match_mnn(z1, z2); b = mctx.match_mnn(z1, z2)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and (0, 0) in list(zip(b[0].tolist(), b[1].tolist()))
+    # min_cossim gate
+    for thr in (0.5, 0.9, 0.99):
+        a = oracle_mod.match_mnn(d1, d2, thr); b = mctx.match_mnn(d1, d2, thr)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    # empty sides, unnormalised inputs (normalisation is part of match())
+    assert len(mctx.match_mnn(d1[:0], d2)[0]) == 0 and len(mctx.match_mnn(d1, d2[:0])[0]) == 0
+    s = (np.arange(200, dtype=np.float32) + 1)[:, None]
+    a = oracle_mod.match_mnn(d1 * s, d2 * 3.0); b = mctx.match_mnn(d1 * s, d2 * 3.0)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2], equal_nan=True)
+    # permutation property: matching against a permuted copy of itself recovers the permutation
+    perm = np.random.RandomState(0).permutation(200)
+    i1, i2, dist = mctx.match_mnn(d1[:200], d1[:200][perm])
+    inv = np.argsort(perm)
+    ok = [k for k in range(200) if k not in (20, 50)]            # rows 20 and 50 are duplicates
+    got = dict(zip(i1.tolist(), i2.tolist()))
+    assert all(got.get(k) == inv[k] for k in ok)
+
+
+def test_distance_i32_exact(mctx, oracle_mod):
+    for n1, n2, z in [(512, 384, 0), (70, 33, 3), (1, 1, 0), (64, 65, 0)]:
+        d1, d2 = synth.descriptor_sets(n1, n2, noise=0.3, zero_rows=z)
+        assert np.array_equal(mctx.distance_i32(d1, d2), oracle_mod.distance_i32(d1, d2))       # integer: bit exact
+    # consistency with the scalar host metric that ORBmatcher::DescriptorDistance replaces
+    L = capi.lib()
+    t = mctx.distance_i32(d1, d2)
+    for (i, j) in [(0, 0), (5, 7), (63, 64)]:
+        assert t[i, j] == L.xfh_descriptor_distance(d1[i].ctypes.data, d2[j].ctypes.data)
+
+
+def test_mnn_device_resident_and_deterministic(mctx):
+    L = capi.lib()
+    n = 4096
+    d1, d2 = synth.descriptor_sets(n, n, noise=0.3)
+    b1 = capi.DeviceBuffer(d1.nbytes).upload(d1); b2 = capi.DeviceBuffer(d2.nbytes).upload(d2)
+    out = capi.DeviceBuffer(12 * n + 64)
+    res = []
+    for _ in range(3):
+        capi.check(L.xfh_match_mnn_device(mctx.h, b1.ptr, n, b2.ptr, n, -1.0, out.ptr, out.ptr + 4 * n, out.ptr + 8 * n, out.ptr + 12 * n), mctx.h)
+        mctx.synchronize()
+        k = int(out.download(np.int32, 1, 12 * n)[0])
+        res.append((out.download(np.int32, k), out.download(np.int32, k, 4 * n), out.download(np.float32, k, 8 * n)))
+    host = mctx.match_mnn(d1, d2)
+    for r in res:
+        assert np.array_equal(r[0], host[0]) and np.array_equal(r[1], host[1]) and np.array_equal(r[2], host[2], equal_nan=True)
+    # misaligned device pointer is rejected, not read
+    assert L.xfh_match_mnn_device(mctx.h, b1.ptr + 4, n - 1, b2.ptr, n, -1.0, out.ptr, out.ptr, out.ptr, out.ptr) == 1

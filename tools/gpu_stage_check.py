@@ -184,7 +184,7 @@ def extract_timing(B, H=480, W=640, gain=6.0, iters=30):
         P(f"    {kname:12s} {ms / 5:.3f} ms/batch over {nl // 5} launches")
     if B <= 8:
         for li in range(24):
-            ctx.timing_enable(capi.K["CONV_MFMA"] if li >= 4 else capi.K["CONV_DIRECT"], li)
+            ctx.timing_enable(capi.K["CONV_MFMA"] if li >= 4 else capi.K["CONV_DIRECT"], 1 << li)
             for _ in range(5): run()
             nl, ms = ctx.timing_read()
             P(f"      conv layer {li:2d} {ms / 5 * 1e3:.1f} us/batch")

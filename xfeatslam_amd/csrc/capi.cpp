@@ -144,7 +144,7 @@ int xfh_destroy(xfh_ctx* c) {
     if (c->h_records) hipHostFree(c->h_records);
     if (c->h_gray) hipHostFree(c->h_gray);
     MatchWs& w = c->mws;
-    F(w.partR); F(w.best12); F(w.h_d1); F(w.o_idx1); F(w.o_tab);
+    F(w.partR); F(w.best12); F(w.h_d1); F(w.o_idx1); F(w.o_tab); F(w.norm1);
     if (c->timer.ev) { for (int i = 0; i < 2 * KTimer::MAXEV; ++i) if (c->timer.ev[i]) hipEventDestroy(c->timer.ev[i]); free(c->timer.ev); }
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
@@ -418,14 +418,14 @@ int xfh_memcpy_h2d(void* d, const void* s, size_t n) { return hipMemcpy(d, s, n,
 int xfh_memcpy_d2h(void* d, const void* s, size_t n) { return hipMemcpy(d, s, n, hipMemcpyDeviceToHost) == hipSuccess ? XFH_OK : XFH_ERR_HIP; }
 
 // ------------------------------------------------------------------------- timing
-int xfh_timing_enable(xfh_ctx* c, int kernel_id, int conv_layer) {
+int xfh_timing_enable(xfh_ctx* c, int kernel_id, unsigned layer_mask) {
     if (!c || kernel_id < 0 || kernel_id >= XFH_K_COUNT) return XFH_ERR_INVALID_ARG;
     KTimer& t = c->timer;
     if (kernel_id != XFH_K_NONE && !t.ev) {
         t.ev = (hipEvent_t*)calloc(2 * KTimer::MAXEV, sizeof(hipEvent_t));
         for (int i = 0; i < 2 * KTimer::MAXEV; ++i) HIPCK(c, hipEventCreate(&t.ev[i]));
     }
-    t.kernel_id = kernel_id; t.conv_layer = conv_layer; t.nev = 0; t.launches = 0;
+    t.kernel_id = kernel_id; t.layer_mask = layer_mask; t.nev = 0; t.launches = 0;
     return XFH_OK;
 }
 int xfh_timing_read(xfh_ctx* c, int* launches, double* total_ms) {
@@ -496,7 +496,7 @@ int xfh_debug_tensor(xfh_ctx* c, int id, int frame, float* out, size_t cap, size
 bool ktimer_begin(xfh_ctx* c, int kernel_id, int layer) {
     KTimer& t = c->timer;
     if (t.kernel_id == XFH_K_NONE || t.kernel_id != kernel_id) return false;
-    if (t.conv_layer >= 0 && layer != t.conv_layer) return false;
+    if (t.layer_mask != 0 && layer >= 0 && !((t.layer_mask >> layer) & 1u)) return false;
     if (t.nev >= KTimer::MAXEV || !t.ev) return false;
     hipEventRecord(t.ev[2 * t.nev], c->stream);
     return true;

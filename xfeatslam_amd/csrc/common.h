@@ -43,7 +43,7 @@ struct RecordHeader { int32_t n_valid, mono_index, n_candidates, reserved; };
 // ---- kernel timing hook ---------------------------------------------------------------
 struct KTimer {
     int kernel_id = 0;
-    int conv_layer = -1;
+    unsigned layer_mask = 0;
     int launches = 0;
     static const int MAXEV = 4096;
     hipEvent_t* ev = nullptr;   // 2*MAXEV events, lazily created
@@ -57,6 +57,7 @@ struct MatchWs {
     float* h_d1 = nullptr; float* h_d2 = nullptr; size_t cap_in = 0;   // device staging of host inputs
     int* o_idx1 = nullptr; int* o_idx2 = nullptr; float* o_dist = nullptr; int* o_n = nullptr; size_t cap_out = 0;
     int32_t* o_tab = nullptr; size_t cap_tab = 0;
+    float* norm1 = nullptr; float* norm2 = nullptr; size_t cap_norm = 0;   // normalised, k-permuted rows
 };
 
 // ---- launchers implemented in the .hip files ------------------------------------------

@@ -22,45 +22,58 @@ __device__ __forceinline__ u64 pack_key(float v, unsigned idx) {
 }
 __device__ __forceinline__ u64 umax64(u64 a, u64 b) { return a > b ? a : b; }
 
-// load one 128 x 64 tile, L2-normalise each row (F::normalize eps 1e-12), store to LDS with
-// the k permutation p = 8g + 4(k&1) + ((k&7)>>1) so that lane-half h reads k = 8g+2j+h for
-// MFMA j out of one ds_read_b128.
-__device__ __forceinline__ void load_norm_tile(const float* __restrict__ d, int n, int row0, float* __restrict__ s, int t) {
-    const int sub = t & 15, r0 = t >> 4;
-    f32x4 v[8];
-#pragma unroll
-    for (int p = 0; p < 8; ++p) {
-        const int row = row0 + p * 16 + r0;
-        if (row < n) v[p] = *(const f32x4*)(d + (size_t)row * 64 + sub * 4);
-        else v[p] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-#pragma unroll
-    for (int p = 0; p < 8; ++p) {
-        double ss = (double)v[p].x * (double)v[p].x + (double)v[p].y * (double)v[p].y +
-                    (double)v[p].z * (double)v[p].z + (double)v[p].w * (double)v[p].w;
-        ss += __shfl_xor(ss, 1); ss += __shfl_xor(ss, 2); ss += __shfl_xor(ss, 4); ss += __shfl_xor(ss, 8);
-        float nrm = (float)sqrt(ss);
-        nrm = fmaxf(nrm, 1e-12f);
-        const int g = sub >> 1, e0 = (sub & 1) * 4;
-        float* dst = s + (p * 16 + r0) * LDK + g * 8;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int e = e0 + q;
-            dst[4 * (e & 1) + (e >> 1)] = v[p][q] / nrm;
-        }
-    }
+// k_rownorm: L2-normalise every descriptor row once (F::normalize, eps 1e-12: fp64 sum of
+// squares, fp32 sqrt / max / divide) and store it with the k permutation the MFMA loop wants:
+// inside each group of 8, element e sits at position 4*(e&1) + (e>>1), so that lane-half h
+// reads k = 8g+2j+h for MFMA j out of one ds_read_b128.  16 lanes per row, 16 rows per block.
+__global__ __launch_bounds__(256)
+void k_rownorm(const float* __restrict__ d1, int n1, const float* __restrict__ d2, int n2,
+               float* __restrict__ o1, float* __restrict__ o2) {
+    const int t = threadIdx.x, sub = t & 15;
+    int row = blockIdx.x * 16 + (t >> 4);
+    const float* d; float* o;
+    if (row < n1) { d = d1; o = o1; }
+    else { row -= n1; if (row >= n2) return; d = d2; o = o2; }      // 16-lane groups exit together
+    const f32x4 v = *(const f32x4*)(d + (size_t)row * 64 + sub * 4);
+    double ss = (double)v.x * (double)v.x + (double)v.y * (double)v.y + (double)v.z * (double)v.z + (double)v.w * (double)v.w;
+    ss += __shfl_xor(ss, 1); ss += __shfl_xor(ss, 2); ss += __shfl_xor(ss, 4); ss += __shfl_xor(ss, 8);
+    const float nrm = fmaxf((float)sqrt(ss), 1e-12f);
+    const float a = v.x / nrm, b = v.y / nrm, c = v.z / nrm, e = v.w / nrm;
+    // this lane holds elements e0..e0+3 of group g; its pair lane (sub^1) holds the other four.
+    // positions 0..3 = even-half lane's {0,2} + odd-half lane's {0,2} ... resolved with one exchange:
+    //   group positions: [e0 e2 e4 e6 | e1 e3 e5 e7]
+    const bool odd = sub & 1;
+    // even lane keeps (a,c) -> pos 0,1 and gets partner's (a,c) -> pos 2,3 ; odd lane: (b,e) pairs -> pos 4..7
+    const float sx = odd ? a : b, sy = odd ? c : e;            // what the partner needs from me
+    const float rx = __shfl_xor(sx, 1), ry = __shfl_xor(sy, 1);
+    const f32x4 outv = odd ? f32x4{rx, ry, b, e} : f32x4{a, c, rx, ry};
+    *(f32x4*)(o + (size_t)row * 64 + (sub >> 1) * 8 + (odd ? 4 : 0)) = outv;
 }
 
 __global__ __launch_bounds__(256, 2)
 void k_mnn_gemm(const float* __restrict__ d1, int n1, const float* __restrict__ d2, int n2,
                 u64* __restrict__ partR, u64* __restrict__ partC, int n1pad, int n2pad) {
+    // d1/d2: normalised, k-permuted rows from k_rownorm
     __shared__ __attribute__((aligned(16))) float smem[2 * MT * LDK];
     float* sA = smem;
     float* sB = smem + MT * LDK;
     const int t = threadIdx.x;
     const int bx = blockIdx.x, by = blockIdx.y;
-    load_norm_tile(d1, n1, by * MT, sA, t);
-    load_norm_tile(d2, n2, bx * MT, sB, t);
+    {
+        const int sub = t & 15, r0 = t >> 4;
+        f32x4 va[8], vb[8];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int ra = by * MT + p * 16 + r0, rb = bx * MT + p * 16 + r0;
+            va[p] = (ra < n1) ? *(const f32x4*)(d1 + (size_t)ra * 64 + sub * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            vb[p] = (rb < n2) ? *(const f32x4*)(d2 + (size_t)rb * 64 + sub * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            *(f32x4*)(sA + (p * 16 + r0) * LDK + sub * 4) = va[p];
+            *(f32x4*)(sB + (p * 16 + r0) * LDK + sub * 4) = vb[p];
+        }
+    }
     __syncthreads();
 
     const int wave = t >> 6, lane = t & 63, i = lane & 31, h = lane >> 5;
@@ -90,72 +103,87 @@ void k_mnn_gemm(const float* __restrict__ d1, int n1, const float* __restrict__ 
         }
     }
 
-    // ---- epilogue: arg-max over columns per row, over rows per column -------------------
+    // ---- epilogue -----------------------------------------------------------------------
     // C/D layout of 32x32: lane holds column (lane&31), rows (r&3) + 8*(r>>2) + 4*(lane>>5).
-    const int gc0 = bx * MT + wc * 64 + i, gc1 = gc0 + 32;
-    const bool vc0 = gc0 < n2, vc1 = gc1 < n2;
+    // Column arg-max (over rows) is lane-local; for the row arg-max the 64x64 wave tile goes
+    // through LDS once so that lane l can scan row l in ascending column order.
     const float NEG = -__builtin_huge_valf();
-
-    // column best (over this wave's 64 rows), ascending row order + strict '>' = lowest row
-    float cbv[2] = {NEG, NEG};
-    unsigned cbr[2] = {0u, 0u};
-    u64 rk[32];
+    const int grow0 = by * MT + wr * 64, gcol0 = bx * MT + wc * 64;
+    const bool full = (by * MT + MT <= n1) && (bx * MT + MT <= n2);     // block-uniform
+    if (!full) {
+        // mask rows/columns outside the problem with -inf (never selected against a finite value)
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const bool vr = grow0 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h < n1;
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) {
+                    const bool vc = gcol0 + ct * 32 + i < n2;
+                    if (!(vr && vc)) acc[rt][ct][r] = NEG;
+                }
+            }
+    }
+    // column best: ascending row order + strict '>' keeps the lowest row among equals
+    float cbv[2] = {NEG, NEG};
+    int cbr[2] = {0, 0};
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int grow = by * MT + wr * 64 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            const bool vr = grow < n1;
-            const float v0 = acc[rt][0][r], v1 = acc[rt][1][r];
-            if (vr && v0 > cbv[0]) { cbv[0] = v0; cbr[0] = (unsigned)grow; }
-            if (vr && v1 > cbv[1]) { cbv[1] = v1; cbr[1] = (unsigned)grow; }
-            // row candidate of this lane: the better of its two columns (lower column on ties)
-            u64 k0 = vc0 ? pack_key(v0, (unsigned)gc0) : 0ull;
-            u64 k1 = vc1 ? pack_key(v1, (unsigned)gc1) : 0ull;
-            rk[rt * 16 + r] = umax64(k0, k1);
-        }
-    }
-    // rows: reduce-scatter butterfly over the 32 lanes of each half; lane i ends with entry q = i
+            const int lrow = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
 #pragma unroll
-    for (int s = 16; s >= 1; s >>= 1) {
-        const bool up = (lane & s) != 0;
-#pragma unroll
-        for (int q = 0; q < s; ++q) {
-            const u64 keep = up ? rk[q + s] : rk[q];
-            const u64 send = up ? rk[q] : rk[q + s];
-            const u64 recv = __shfl_xor(send, s);
-            rk[q] = umax64(keep, recv);
+            for (int ct = 0; ct < 2; ++ct) {
+                const float v = acc[rt][ct][r];
+                const bool gt = v > cbv[ct];
+                cbv[ct] = gt ? v : cbv[ct];
+                cbr[ct] = gt ? lrow : cbr[ct];
+            }
         }
-    }
-    // columns: merge the two halves (rows +4 interleaved)
     u64 ck[2];
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
-        u64 k = (cbv[ct] > NEG) ? pack_key(cbv[ct], cbr[ct]) : 0ull;
-        if (cbv[ct] == NEG) {
-            // every valid value could legitimately be -inf only for NaN/inf inputs; treat as no candidate
-            k = 0ull;
-        }
+        const u64 k = (cbv[ct] > NEG) ? pack_key(cbv[ct], (unsigned)(grow0 + cbr[ct])) : 0ull;
         ck[ct] = umax64(k, __shfl_xor(k, 32));
     }
 
-    __syncthreads();                       // all waves are done with sA/sB: reuse as scratch
+    __syncthreads();                       // every wave is done with sA/sB: reuse as scratch
+    float* sT = smem + wave * (64 * LDK);  // this wave's 64 x 64 tile, row stride LDK
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int lrow = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            sT[lrow * LDK + i] = acc[rt][0][r];
+            sT[lrow * LDK + 32 + i] = acc[rt][1][r];
+        }
+    // the tile is private to the wave: a wave-level fence is enough
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    float rbv = NEG; int rbc = 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const f32x4 v = *(const f32x4*)(sT + lane * LDK + q * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool gt = v[e] > rbv;
+            rbv = gt ? v[e] : rbv;
+            rbc = gt ? (q * 4 + e) : rbc;
+        }
+    }
+    const u64 rkey = (rbv > NEG) ? pack_key(rbv, (unsigned)(gcol0 + rbc)) : 0ull;
+    __syncthreads();                       // all tiles consumed: reuse the head of smem for the merges
     u64* sRow = (u64*)smem;                // [4 waves][64]
     u64* sCol = sRow + 4 * 64;             // [4 waves][64]
-    sRow[wave * 64 + lane] = rk[0];
+    sRow[wave * 64 + lane] = rkey;         // lane = local row
     if (lane < 32) { sCol[wave * 64 + lane] = ck[0]; sCol[wave * 64 + 32 + lane] = ck[1]; }
     __syncthreads();
     if (wc == 0) {
-        // lane (i,h) holds row q=i of half h: R = wr*64 + (q>>4)*32 + (q&3) + 8*((q&15)>>2) + 4h
-        const int q = i;
-        const int R = wr * 64 + (q >> 4) * 32 + (q & 3) + 8 * ((q & 15) >> 2) + 4 * h;
         const u64 k = umax64(sRow[wave * 64 + lane], sRow[(wave + 1) * 64 + lane]);
-        partR[(size_t)bx * n1pad + by * MT + R] = k;
+        partR[(size_t)bx * n1pad + by * MT + wr * 64 + lane] = k;
     }
     if (wr == 0) {
-        const int c = wc * 64 + lane;      // lane 0..63 -> column ct*32+i of this wave pair
         const u64 k = umax64(sCol[wave * 64 + lane], sCol[(wave + 2) * 64 + lane]);
-        partC[(size_t)by * n2pad + bx * MT + c] = k;
+        partC[(size_t)by * n2pad + bx * MT + wc * 64 + lane] = k;
     }
 }
 
@@ -290,8 +318,17 @@ hipError_t launch_mnn(xfh_ctx* c, const float* d1, int n1, const float* d2, int 
     w.val12 = (float*)(w.best12 + w.cap_best);
     w.best21 = (int*)(w.val12 + w.cap_best);
 
+    const size_t need_norm = ((size_t)n1 + n2) * 64;
+    if (w.cap_norm < need_norm) {
+        if (w.norm1) hipFree(w.norm1);
+        if ((e = hipMalloc((void**)&w.norm1, need_norm * sizeof(float))) != hipSuccess) return e;
+        w.cap_norm = need_norm;
+    }
+    w.norm2 = w.norm1 + (size_t)n1 * 64;
+    hipLaunchKernelGGL(k_rownorm, dim3((n1 + n2 + 15) / 16 + 1), dim3(256), 0, c->stream, d1, n1, d2, n2, w.norm1, w.norm2);
     bool armed = ktimer_begin(c, XFH_K_MNN_GEMM, -1);
-    hipLaunchKernelGGL(k_mnn_gemm, dim3(nbC, nbR), dim3(256), 0, c->stream, d1, n1, d2, n2, w.partR, w.partC, n1pad, n2pad);
+    hipLaunchKernelGGL(k_mnn_gemm, dim3(nbC, nbR), dim3(256), 0, c->stream, (const float*)w.norm1, n1, (const float*)w.norm2, n2,
+                       w.partR, w.partC, n1pad, n2pad);
     ktimer_end(c, armed);
     const int nthr = n1pad + n2pad;
     hipLaunchKernelGGL(k_mnn_reduce, dim3((nthr + 255) / 256), dim3(256), 0, c->stream, w.partR, w.partC, nbR, nbC,

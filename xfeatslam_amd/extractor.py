@@ -96,13 +96,23 @@ class Context:
         return out
 
     # -- timing ---------------------------------------------------------------------------
-    def timing_enable(self, kernel_id: int, conv_layer: int = -1):
-        check(lib().xfh_timing_enable(self.h, kernel_id, conv_layer), self.h)
+    def timing_enable(self, kernel_id: int, layer_mask: int = 0):
+        check(lib().xfh_timing_enable(self.h, kernel_id, layer_mask), self.h)
 
     def timing_read(self):
         n = C.c_int(0); ms = C.c_double(0.0)
         check(lib().xfh_timing_read(self.h, C.byref(n), C.byref(ms)), self.h)
         return n.value, ms.value
+
+
+def scale_tables(nlevels: int, scaleFactor: float):
+    """mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2 (XFextractor.cc:80-96),
+    fp32 arithmetic as in the reference"""
+    sf = np.ones(nlevels, np.float32); s2 = np.ones(nlevels, np.float32)
+    for i in range(1, nlevels):
+        sf[i] = np.float32(sf[i - 1] * np.float32(scaleFactor))
+        s2[i] = np.float32(sf[i] * sf[i])
+    return sf, (np.float32(1.0) / sf).astype(np.float32), s2, (np.float32(1.0) / s2).astype(np.float32)
 
 
 class XFextractor:
@@ -112,14 +122,7 @@ class XFextractor:
                  weights: bytes | None = None, max_height: int = 480, max_width: int = 640, device: int = 0):
         self.nfeatures, self.scaleFactor, self.nlevels = nfeatures, float(np.float32(scaleFactor)), nlevels
         self.iniThFAST, self.minThFAST = iniThFAST, minThFAST
-        # scale tables, XFextractor.cc:80-96 (fp32 arithmetic as in the reference)
-        sf = np.ones(nlevels, np.float32); s2 = np.ones(nlevels, np.float32)
-        for i in range(1, nlevels):
-            sf[i] = np.float32(sf[i - 1] * np.float32(scaleFactor))
-            s2[i] = np.float32(sf[i] * sf[i])
-        self.mvScaleFactor, self.mvLevelSigma2 = sf, s2
-        self.mvInvScaleFactor = (np.float32(1.0) / sf).astype(np.float32)
-        self.mvInvLevelSigma2 = (np.float32(1.0) / s2).astype(np.float32)
+        self.mvScaleFactor, self.mvInvScaleFactor, self.mvLevelSigma2, self.mvInvLevelSigma2 = scale_tables(nlevels, scaleFactor)
         self.mvImagePyramid = [None] * nlevels          # sized, never filled (XFextractor.cc:98)
         self.ctx = Context(nfeatures, max_height, max_width, 1, device)
         if weights is not None:
