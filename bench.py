@@ -58,7 +58,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     N = max(world, 1)
     torch = dist = None
-    if N > 1:
+    use_dist = N > 1 or bool(os.environ.get("XFH_FORCE_DIST"))     # the env var exercises the RCCL path on one GPU
+    if use_dist:
         # torch only for the process group / RCCL; it must be imported before the HIP library
         # so that both share one HIP runtime
         import torch
@@ -75,14 +76,14 @@ def main():
 
     B, H, W, K = args.batch, args.height, args.width, args.steps
     blob = WT.pack_blob(WT.make_synthetic(1234, KP_GAIN))
-    ctx = Context(nfeatures=NFEATURES, max_height=H, max_width=W, max_batch=B, device=local_rank if N > 1 else 0)
+    ctx = Context(nfeatures=NFEATURES, max_height=H, max_width=W, max_batch=B, device=local_rank if use_dist else 0)
     ctx.load_weights(blob)
     # frame i of the global batch goes to rank i mod N  (weak scaling: B frames per GPU)
     base = synth.frames(min(B, 8), H, W, seed=42 + 100 * rank)
     frames = np.concatenate([base] * ((B + len(base) - 1) // len(base)))[:B]
     rec_bytes = ctx.rec_bytes
 
-    if N > 1:
+    if use_dist:
         d_in = torch.from_numpy(frames).cuda()
         d_rec = torch.empty(B * rec_bytes, dtype=torch.uint8, device="cuda")
         d_all = torch.empty(N * B * rec_bytes, dtype=torch.uint8, device="cuda")
@@ -95,11 +96,11 @@ def main():
 
     def step():
         capi.check(lib.xfh_extract_batch_device(ctx.h, in_ptr, B, H, W, 0, 0, rec_ptr), ctx.h)
-        if N > 1:
+        if use_dist:
             dist.all_gather_into_tensor(d_all, d_rec)
 
     def sync():
-        if N > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
         ctx.synchronize()
@@ -117,7 +118,7 @@ def main():
     elapsed = time.perf_counter() - t0
     n_conv, ms_conv = ctx.timing_read()
     ctx.timing_enable(0)
-    if N > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -145,8 +146,7 @@ def main():
     n_matches = int(mout.download(np.int32, 1, 12 * nf)[0])
 
     if rank != 0:
-        if N > 1:
-            dist.barrier(); dist.destroy_process_group()
+        dist.barrier(); dist.destroy_process_group()
         return
 
     # ---- roofline lines ------------------------------------------------------------------------------
@@ -169,7 +169,8 @@ def main():
         from oracle import oracle as O
         orc = O.Oracle(blob)
         nthr = O.get_threads()
-        recs = ctx.parse_records(d_rec.download(np.uint8, rec_bytes * B), B)
+        raw = d_rec.cpu().numpy() if use_dist else d_rec.download(np.uint8, rec_bytes * B)
+        recs = ctx.parse_records(raw, B)
         orc.extract(frames[0], nf, (0, 0))                          # warm-up + parity reference
         t0 = time.perf_counter()
         for i in range(args.cpu_frames):
@@ -204,7 +205,7 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"configs[1]: {H}x{W} u8 frames, XFeat extract, nfeatures {nf}, {B} frames per GPU per step "
                                f"(per-frame BatchNorm statistics), inputs and 4096-row records resident in HBM"
-                               + (", RCCL all-gather of records" if N > 1 else ""),
+                               + (", RCCL all-gather of records" if use_dist else ""),
                    "frames_per_gpu_per_step": B, "height": H, "width": W, "nfeatures": nf,
                    "weights": f"synthetic seed 1234, keypoint-logit gain {KP_GAIN}", "parallelism": f"frames x{N}"},
         "roofline": {"kernel": "k_conv_mfma<64,64,3,1,4,1,2,16,1,0> (block3.1, block_fusion.1: 3x3 64->64 at 1/8 res)",
@@ -219,7 +220,7 @@ def main():
         "cpu_baseline": cpu, "parity": parity,
     }
     print(json.dumps(out))
-    if N > 1:
+    if use_dist:
         dist.barrier(); dist.destroy_process_group()
 
 

@@ -194,12 +194,15 @@ def extract_timing(B, H=480, W=640, gain=6.0, iters=30):
 
 if __name__ == "__main__":
     quick = "--quick" in sys.argv
+    tonly = "--timing-only" in sys.argv
     P("lib:", capi.lib().xfh_version().decode(), "devices:", capi.lib().xfh_device_count())
-    section("match parity", match_checks)
+    if not tonly:
+        section("match parity", match_checks)
     section("match timing", match_timing)
-    section("extract 96x128", lambda: extract_checks(96, 128, 1.0, nf=256))
-    section("extract VGA gain1", lambda: extract_checks(480, 640, 1.0))
-    if not quick:
+    if not tonly:
+        section("extract 96x128", lambda: extract_checks(96, 128, 1.0, nf=256))
+        section("extract VGA gain1", lambda: extract_checks(480, 640, 1.0))
+    if not quick and not tonly:
         section("extract VGA dense", lambda: extract_checks(480, 640, 6.0, lap=(0, 1000)))
         section("extract 720p", lambda: extract_checks(720, 1280, 1.0, lap=(0, 1000)))
     section("extract timing B=1", lambda: extract_timing(1))
