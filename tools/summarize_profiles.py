@@ -1,0 +1,55 @@
+#!/usr/bin/env python
+"""gpurun_out/{prof,pmc_fetch,pmc_write} (rocprofv3 CSV) -> profiles/<tag>_*.csv + profiles/pmc_traffic.json.
+HBM traffic follows /opt/skills/guides/MI355X_MICROARCH.md §HBM: FETCH_SIZE and WRITE_SIZE come from
+separate --pmc passes, are in KiB, and on gfx950 FETCH_SIZE counts 128-B requests as 64 B -> doubled."""
+import collections, csv, glob, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+G = os.path.join(ROOT, "gpurun_out"); P = os.path.join(ROOT, "profiles"); os.makedirs(P, exist_ok=True)
+
+def kernel_trace(d):
+    f = glob.glob(os.path.join(G, d, "*kernel_trace.csv"))
+    rows = list(csv.DictReader(open(f[0]))) if f else []
+    agg = collections.defaultdict(list)
+    for r in rows:
+        agg[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    return agg
+
+agg = kernel_trace("prof")
+if agg:
+    tot = sum(sum(v) for v in agg.values())
+    with open(os.path.join(P, f"{tag}_bench_kernel_stats.csv"), "w") as f:
+        w = csv.writer(f); w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs", "Percentage"])
+        for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+            w.writerow([k, len(v), sum(v), round(sum(v) / len(v), 1), min(v), max(v), round(100.0 * sum(v) / tot, 2)])
+    print("wrote kernel stats:", len(agg), "kernels")
+for f in glob.glob(os.path.join(G, "prof", "*kernel_stats.csv")):
+    os.replace(f, os.path.join(P, f"{tag}_rocprofv3_kernel_stats.csv"))
+
+def pmc(d, name):
+    f = glob.glob(os.path.join(G, d, "*counter_collection.csv"))
+    out = collections.defaultdict(list)
+    if f:
+        for r in csv.DictReader(open(f[0])):
+            if r["Counter_Name"] == name:
+                out[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return out
+
+fetch, write = pmc("pmc_fetch", "FETCH_SIZE"), pmc("pmc_write", "WRITE_SIZE")
+if fetch or write:
+    per = {}
+    for k in set(fetch) | set(write):
+        fe = sum(fetch[k]) / len(fetch[k]) if fetch.get(k) else 0.0
+        wr = sum(write[k]) / len(write[k]) if write.get(k) else 0.0
+        per[k] = {"fetch_kib_raw": fe, "write_kib_raw": wr, "hbm_bytes_per_launch": (2.0 * fe + wr) * 1024.0, "launches": len(fetch.get(k, write.get(k, [])))}
+    def pick(sub):
+        for k, v in per.items():
+            if sub in k:
+                return v["hbm_bytes_per_launch"]
+        return None
+    js = {"method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch "
+                    "(gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md §HBM; WRITE_SIZE uncalibrated)",
+          "conv_bytes_per_launch": pick("k_conv_mfma<64, 64, 3, 1, 4, 1, 2, 16, 1, 0>"),
+          "gemm_bytes_per_launch": pick("k_mnn_gemm"), "per_kernel": per}
+    json.dump(js, open(os.path.join(P, "pmc_traffic.json"), "w"), indent=1)
+    print("wrote pmc_traffic.json; conv", js["conv_bytes_per_launch"], "gemm", js["gemm_bytes_per_launch"])

@@ -493,17 +493,12 @@ int xfh_debug_tensor(xfh_ctx* c, int id, int frame, float* out, size_t cap, size
 
 }  // extern "C"
 
-bool ktimer_begin(xfh_ctx* c, int kernel_id, int layer) {
+bool ktimer_slot(xfh_ctx* c, int kernel_id, int layer, hipEvent_t* e0, hipEvent_t* e1) {
     KTimer& t = c->timer;
     if (t.kernel_id == XFH_K_NONE || t.kernel_id != kernel_id) return false;
     if (t.layer_mask != 0 && layer >= 0 && !((t.layer_mask >> layer) & 1u)) return false;
     if (t.nev >= KTimer::MAXEV || !t.ev) return false;
-    hipEventRecord(t.ev[2 * t.nev], c->stream);
-    return true;
-}
-void ktimer_end(xfh_ctx* c, bool armed) {
-    if (!armed) return;
-    KTimer& t = c->timer;
-    hipEventRecord(t.ev[2 * t.nev + 1], c->stream);
+    *e0 = t.ev[2 * t.nev]; *e1 = t.ev[2 * t.nev + 1];
     ++t.nev;
+    return true;
 }

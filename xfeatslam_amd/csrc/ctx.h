@@ -1,6 +1,7 @@
 // ctx.h -- the extractor/matcher context: all device memory is allocated once in xfh_create.
 #pragma once
 #include "common.h"
+#include <hip/hip_ext.h>
 #include <string>
 
 // packed device weights
@@ -56,8 +57,17 @@ struct xfh_ctx {
 };
 
 // helpers implemented in capi.cpp
-bool ktimer_begin(xfh_ctx* c, int kernel_id, int layer);
-void ktimer_end(xfh_ctx* c, bool armed);
+// kernel timing: when the timer is armed for (kernel_id, layer) the launch goes through
+// hipExtLaunchKernelGGL with a start/stop event pair attached to the dispatch itself, so the
+// measured time is the kernel's own begin..end (what rocprofv3 --kernel-trace reports), not the
+// gap between two stream markers.
+bool ktimer_slot(xfh_ctx* c, int kernel_id, int layer, hipEvent_t* e0, hipEvent_t* e1);
+template <typename K, typename... Args>
+inline void launch_k(xfh_ctx* c, int kernel_id, int layer, K kern, dim3 grid, dim3 block, size_t shmem, Args... args) {
+    hipEvent_t e0, e1;
+    if (ktimer_slot(c, kernel_id, layer, &e0, &e1)) hipExtLaunchKernelGGL(kern, grid, block, (unsigned)shmem, c->stream, e0, e1, 0, args...);
+    else hipLaunchKernelGGL(kern, grid, block, shmem, c->stream, args...);
+}
 
 // launchers (kernels_*.hip)
 hipError_t run_extract(xfh_ctx* c, const uint8_t* d_gray, int B, int H0, int W0, int lap0, int lap1, uint8_t* d_records);

@@ -345,7 +345,7 @@ void k_conv_mfma(ConvArgs a) {
 // ------------------------------------------------------------------------------------
 // host side: layer -> template instance
 template <int CIN, int COUT, int KS, int ST, int WM, int WN, int NT, int WW, int PRO, int EPI>
-static hipError_t conv_mfma_launch(xfh_ctx* c, const ConvArgs& a, int B, int* npart_out) {
+static hipError_t conv_mfma_launch(xfh_ctx* c, const ConvArgs& a, int B, int* npart_out, int layer) {
     constexpr int WH = 32 / WW, TH = WM * WH, TW = WW;
     constexpr int COUTP = WN * NT * 32;
     constexpr int TIH = (TH - 1) * ST + KS, TIW = (TW - 1) * ST + KS;
@@ -365,17 +365,17 @@ static hipError_t conv_mfma_launch(xfh_ctx* c, const ConvArgs& a, int B, int* np
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(ntile, 1, B), dim3(64 * WM * WN), LDS, c->stream, aa);
+    launch_k(c, XFH_K_CONV_MFMA, layer, kern, dim3(ntile, 1, B), dim3(64 * WM * WN), LDS, aa);
     return hipGetLastError();
 }
 
 template <int CIN, int COUT, int ST, int PRO>
-static hipError_t conv_direct_launch(xfh_ctx* c, const ConvArgs& a, int B, int* npart_out) {
+static hipError_t conv_direct_launch(xfh_ctx* c, const ConvArgs& a, int B, int* npart_out, int layer) {
     ConvArgs aa = a;
     aa.tiles_x = (a.Wout + 15) / 16;
     const int ntile = aa.tiles_x * ((a.Hout + 15) / 16);
     if (npart_out) *npart_out = ntile;
-    hipLaunchKernelGGL((k_conv_direct<CIN, COUT, ST, PRO>), dim3(ntile, 1, B), dim3(256), 0, c->stream, aa);
+    launch_k(c, XFH_K_CONV_DIRECT, layer, k_conv_direct<CIN, COUT, ST, PRO>, dim3(ntile, 1, B), dim3(256), 0, aa);
     return hipGetLastError();
 }
 
@@ -406,31 +406,29 @@ hipError_t launch_basic_layer(xfh_ctx* c, int li, const float* in, size_t in_str
     int np = 0;
     hipError_t e = hipSuccess;
     const bool bn = (pro == PRO_BN);
-    bool armed = ktimer_begin(c, li < 4 ? XFH_K_CONV_DIRECT : XFH_K_CONV_MFMA, li);
     switch (li) {
-        case 0: e = conv_direct_launch<1, 4, 1, PRO_IN>(c, a, B, &np); break;
-        case 1: e = conv_direct_launch<4, 8, 2, PRO_BN>(c, a, B, &np); break;
-        case 2: e = conv_direct_launch<8, 8, 1, PRO_BN>(c, a, B, &np); break;
-        case 3: e = conv_direct_launch<8, 24, 2, PRO_BN>(c, a, B, &np); break;
-        case 4: e = conv_mfma_launch<24, 24, 3, 1, 4, 1, 1, 16, PRO_PLAIN, EPI_STATS>(c, a, B, &np); break;  // input = b2in
-        case 5: e = conv_mfma_launch<24, 24, 3, 1, 4, 1, 1, 16, PRO_BN, EPI_STATS>(c, a, B, &np); break;
-        case 6: e = conv_mfma_launch<24, 64, 3, 2, 4, 1, 2, 16, PRO_BN, EPI_STATS>(c, a, B, &np); break;
-        case 7: e = conv_mfma_launch<64, 64, 3, 1, 4, 1, 2, 16, PRO_BN, EPI_STATS>(c, a, B, &np); break;
-        case 8: e = conv_mfma_launch<64, 64, 1, 1, 4, 1, 2, 16, PRO_BN, EPI_STATS>(c, a, B, &np); break;
-        case 9: e = conv_mfma_launch<64, 64, 3, 2, 2, 2, 1, 8, PRO_BN, EPI_STATS>(c, a, B, &np); break;
-        case 10: case 11: e = conv_mfma_launch<64, 64, 3, 1, 2, 2, 1, 8, PRO_BN, EPI_STATS>(c, a, B, &np); break;
-        case 12: e = conv_mfma_launch<64, 128, 3, 2, 1, 4, 1, 8, PRO_BN, EPI_STATS>(c, a, B, &np); break;
-        case 13: case 14: e = conv_mfma_launch<128, 128, 3, 1, 1, 4, 1, 8, PRO_BN, EPI_STATS>(c, a, B, &np); break;
-        case 15: e = conv_mfma_launch<128, 64, 1, 1, 1, 2, 1, 8, PRO_BN, EPI_STATS>(c, a, B, &np); break;
-        case 16: e = conv_mfma_launch<64, 64, 3, 1, 4, 1, 2, 16, PRO_PLAIN, EPI_STATS>(c, a, B, &np); break;  // input = fuse_in
-        case 17: e = conv_mfma_launch<64, 64, 3, 1, 4, 1, 2, 16, PRO_BN, EPI_STATS>(c, a, B, &np); break;
+        case 0: e = conv_direct_launch<1, 4, 1, PRO_IN>(c, a, B, &np, li); break;
+        case 1: e = conv_direct_launch<4, 8, 2, PRO_BN>(c, a, B, &np, li); break;
+        case 2: e = conv_direct_launch<8, 8, 1, PRO_BN>(c, a, B, &np, li); break;
+        case 3: e = conv_direct_launch<8, 24, 2, PRO_BN>(c, a, B, &np, li); break;
+        case 4: e = conv_mfma_launch<24, 24, 3, 1, 4, 1, 1, 16, PRO_PLAIN, EPI_STATS>(c, a, B, &np, li); break;  // input = b2in
+        case 5: e = conv_mfma_launch<24, 24, 3, 1, 4, 1, 1, 16, PRO_BN, EPI_STATS>(c, a, B, &np, li); break;
+        case 6: e = conv_mfma_launch<24, 64, 3, 2, 4, 1, 2, 16, PRO_BN, EPI_STATS>(c, a, B, &np, li); break;
+        case 7: e = conv_mfma_launch<64, 64, 3, 1, 4, 1, 2, 16, PRO_BN, EPI_STATS>(c, a, B, &np, li); break;
+        case 8: e = conv_mfma_launch<64, 64, 1, 1, 4, 1, 2, 16, PRO_BN, EPI_STATS>(c, a, B, &np, li); break;
+        case 9: e = conv_mfma_launch<64, 64, 3, 2, 2, 2, 1, 8, PRO_BN, EPI_STATS>(c, a, B, &np, li); break;
+        case 10: case 11: e = conv_mfma_launch<64, 64, 3, 1, 2, 2, 1, 8, PRO_BN, EPI_STATS>(c, a, B, &np, li); break;
+        case 12: e = conv_mfma_launch<64, 128, 3, 2, 1, 4, 1, 8, PRO_BN, EPI_STATS>(c, a, B, &np, li); break;
+        case 13: case 14: e = conv_mfma_launch<128, 128, 3, 1, 1, 4, 1, 8, PRO_BN, EPI_STATS>(c, a, B, &np, li); break;
+        case 15: e = conv_mfma_launch<128, 64, 1, 1, 1, 2, 1, 8, PRO_BN, EPI_STATS>(c, a, B, &np, li); break;
+        case 16: e = conv_mfma_launch<64, 64, 3, 1, 4, 1, 2, 16, PRO_PLAIN, EPI_STATS>(c, a, B, &np, li); break;  // input = fuse_in
+        case 17: e = conv_mfma_launch<64, 64, 3, 1, 4, 1, 2, 16, PRO_BN, EPI_STATS>(c, a, B, &np, li); break;
         case 18: case 20:                                                                                      // inputs: feats / unfold(xhat)
-            e = conv_mfma_launch<64, 64, 1, 1, 4, 1, 2, 16, PRO_PLAIN, EPI_STATS>(c, a, B, &np); break;
+            e = conv_mfma_launch<64, 64, 1, 1, 4, 1, 2, 16, PRO_PLAIN, EPI_STATS>(c, a, B, &np, li); break;
         case 19: case 21: case 22:
-            e = conv_mfma_launch<64, 64, 1, 1, 4, 1, 2, 16, PRO_BN, EPI_STATS>(c, a, B, &np); break;
+            e = conv_mfma_launch<64, 64, 1, 1, 4, 1, 2, 16, PRO_BN, EPI_STATS>(c, a, B, &np, li); break;
         default: return hipErrorInvalidValue;
     }
-    ktimer_end(c, armed);
     (void)bn;
     if (e != hipSuccess) return e;
     c->npart[li] = np;
@@ -446,10 +444,7 @@ hipError_t launch_fusion_out(xfh_ctx* c, int Hh, int Wh, int B) {
     a.w = c->w.fus2; a.bias = c->w.fus2_bias;
     a.out = c->feats; a.out_stride = c->raw_stride[17]; a.Hout = Hh; a.Wout = Wh;
     a.part = nullptr; a.part_stride = 0;
-    bool armed = ktimer_begin(c, XFH_K_CONV_MFMA, 23);
-    hipError_t e = conv_mfma_launch<64, 64, 1, 1, 4, 1, 2, 16, PRO_BN, EPI_BIAS>(c, a, B, nullptr);
-    ktimer_end(c, armed);
-    return e;
+    return conv_mfma_launch<64, 64, 1, 1, 4, 1, 2, 16, PRO_BN, EPI_BIAS>(c, a, B, nullptr, 23);
 }
 
 // InstanceNorm statistics of the image reuse the finalize kernel with C = 1

@@ -13,6 +13,8 @@
 // the f32 MFMA computes), so the arg-max decisions including ties agree by construction.
 // Ties resolve to the lowest index through the packed key (ordered(value) << 32 | ~index).
 #include "ctx.h"
+#include <utility>
+#include <stdlib.h>
 
 #define MT 128          // tile edge (rows of d1 / rows of d2 per workgroup)
 #define LDK 68          // padded LDS row (floats): 64 + 4 keeps ds_read_b128 conflict free
@@ -50,21 +52,52 @@ void k_rownorm(const float* __restrict__ d1, int n1, const float* __restrict__ d
     *(f32x4*)(o + (size_t)row * 64 + (sub >> 1) * 8 + (odd ? 4 : 0)) = outv;
 }
 
+// reduce-scatter butterfly step on packed keys, expanded with an integer_sequence fold: with
+// ordinary (pragma-unrolled) loops the compiler turns `up ? k[q+s] : k[q]` into a dynamically
+// indexed array read, i.e. a select chain over the whole array.
+template <int S, int N, int... Q>
+__device__ __forceinline__ void bfly_step(u64 (&k)[N], bool up, std::integer_sequence<int, Q...>) {
+    ((k[Q] = umax64(up ? k[Q + S] : k[Q], __shfl_xor(up ? k[Q] : k[Q + S], S))), ...);
+}
+
+template <int... Q>
+__device__ __forceinline__ void pack_rows(u64 (&rk)[32], const float (&rbv)[32], const int (&rbc)[32], std::integer_sequence<int, Q...>) {
+    ((rk[Q] = (rbv[Q] > -__builtin_huge_valf()) ? pack_key(rbv[Q], (unsigned)rbc[Q]) : 0ull), ...);
+}
+
+// k_mnn_gemm: one workgroup = 128 rows of d1 against TPW = 2 consecutive 128-row blocks of d2.
+//   - the second d2 block is prefetched into registers while the first one is on the MFMAs, so
+//     only the first global load of a workgroup is exposed;
+//   - grid = (ceil(nbC/2), nbR): 512 workgroups at 4096 x 4096, all resident at 2 per CU;
+//   - per tile, every wave owns 64 x 64 outputs as 2 x 2 MFMA tiles (four independent chains);
+//   - column arg-max (over rows) is lane-local in the C/D layout; the row arg-max is carried
+//     lane-locally across both tiles (value + column per row slot) and reduced across lanes ONCE
+//     at the end with a packed-key butterfly.
+// Measured on gfx950 (tools/probes/mfma_probe.hip, profiles/r01_gemm_notes.md): the f32 MFMA and
+// the ordinary VALU instructions of a SIMD do not overlap -- every epilogue instruction costs
+// matrix time -- which is why the arg-max is kept at 3 VALU per value and direction.  Variants
+// with the epilogue interleaved between MFMAs, 8-wave and persistent 4-tile workgroups were
+// measured slower (DESIGN.md "Match kernel: what was tried").
+#define TPW 2
 __global__ __launch_bounds__(256, 2)
 void k_mnn_gemm(const float* __restrict__ d1, int n1, const float* __restrict__ d2, int n2,
-                u64* __restrict__ partR, u64* __restrict__ partC, int n1pad, int n2pad) {
+                u64* __restrict__ partR, u64* __restrict__ partC, int n1pad, int n2pad, int nbC) {
     // d1/d2: normalised, k-permuted rows from k_rownorm
-    __shared__ __attribute__((aligned(16))) float smem[2 * MT * LDK];
+    __shared__ __attribute__((aligned(16))) float smem[2 * MT * LDK + 2 * 4 * 64 * 2];
     float* sA = smem;
     float* sB = smem + MT * LDK;
+    u64* sRow = (u64*)(smem + 2 * MT * LDK);     // [4 waves][64]
+    u64* sCol = sRow + 4 * 64;                    // [4 waves][64]
     const int t = threadIdx.x;
-    const int bx = blockIdx.x, by = blockIdx.y;
+    const int bx2 = blockIdx.x, by = blockIdx.y;
+    const int sub = t & 15, r0 = t >> 4;
+    const bool has_b1 = bx2 * 2 + 1 < nbC;
+    f32x4 vb[8];
     {
-        const int sub = t & 15, r0 = t >> 4;
-        f32x4 va[8], vb[8];
+        f32x4 va[8];
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
-            const int ra = by * MT + p * 16 + r0, rb = bx * MT + p * 16 + r0;
+            const int ra = by * MT + p * 16 + r0, rb = bx2 * 2 * MT + p * 16 + r0;
             va[p] = (ra < n1) ? *(const f32x4*)(d1 + (size_t)ra * 64 + sub * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
             vb[p] = (rb < n2) ? *(const f32x4*)(d2 + (size_t)rb * 64 + sub * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
@@ -75,133 +108,146 @@ void k_mnn_gemm(const float* __restrict__ d1, int n1, const float* __restrict__ 
         }
     }
     __syncthreads();
-
-    const int wave = t >> 6, lane = t & 63, i = lane & 31, h = lane >> 5;
-    const int wr = wave >> 1, wc = wave & 1;
-    f32x16 acc[2][2];
+    if (has_b1) {
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-    const float* pa = sA + (wr * 64 + i) * LDK + 4 * h;
-    const float* pb = sB + (wc * 64 + i) * LDK + 4 * h;
-#pragma unroll
-    for (int g = 0; g < 8; ++g) {
-        const f32x4 a0 = *(const f32x4*)(pa + g * 8);
-        const f32x4 a1 = *(const f32x4*)(pa + 32 * LDK + g * 8);
-        const f32x4 b0 = *(const f32x4*)(pb + g * 8);
-        const f32x4 b1 = *(const f32x4*)(pb + 32 * LDK + g * 8);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[j], acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b1[j], acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b0[j], acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1[j], acc[1][1], 0, 0, 0);
+        for (int p = 0; p < 8; ++p) {
+            const int rb = (bx2 * 2 + 1) * MT + p * 16 + r0;
+            vb[p] = (rb < n2) ? *(const f32x4*)(d2 + (size_t)rb * 64 + sub * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
 
-    // ---- epilogue -----------------------------------------------------------------------
-    // C/D layout of 32x32: lane holds column (lane&31), rows (r&3) + 8*(r>>2) + 4*(lane>>5).
-    // Column arg-max (over rows) is lane-local; for the row arg-max the 64x64 wave tile goes
-    // through LDS once so that lane l can scan row l in ascending column order.
+    const int wave = t >> 6, lane = t & 63, i = lane & 31, h = lane >> 5;
+    const int wr = wave >> 1, wc = wave & 1;
     const float NEG = -__builtin_huge_valf();
-    const int grow0 = by * MT + wr * 64, gcol0 = bx * MT + wc * 64;
-    const bool full = (by * MT + MT <= n1) && (bx * MT + MT <= n2);     // block-uniform
-    if (!full) {
-        // mask rows/columns outside the problem with -inf (never selected against a finite value)
+    const int grow0 = by * MT + wr * 64;
+    const float* pa = sA + (wr * 64 + i) * LDK + 4 * h;
+    const float* pb = sB + (wc * 64 + i) * LDK + 4 * h;
+
+    // running row best of this lane: slot q = rt*16 + r  <->  row rt*32 + (r&3) + 8*(r>>2) + 4h
+    float rbv[32];
+    int rbc[32];
+#pragma unroll
+    for (int q = 0; q < 32; ++q) { rbv[q] = NEG; rbc[q] = 0; }
+
+#pragma unroll
+    for (int tile = 0; tile < 2; ++tile) {
+        if (tile == 1 && !has_b1) break;
+        const int bx = bx2 * 2 + tile;
+        const int gcol0 = bx * MT + wc * 64;
+        const bool full = (by * MT + MT <= n1) && (bx * MT + MT <= n2);     // block-uniform
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const f32x4 a0 = *(const f32x4*)(pa + g * 8);
+            const f32x4 a1 = *(const f32x4*)(pa + 32 * LDK + g * 8);
+            const f32x4 b0 = *(const f32x4*)(pb + g * 8);
+            const f32x4 b1 = *(const f32x4*)(pb + 32 * LDK + g * 8);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[j], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b1[j], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b0[j], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1[j], acc[1][1], 0, 0, 0);
+            }
+        }
+        // ---- tile epilogue: C/D layout = column (lane&31), rows (r&3) + 8*(r>>2) + 4*(lane>>5)
+        if (!full) {
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const bool vr = grow0 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h < n1;
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct)
+                        if (!(vr && gcol0 + ct * 32 + i < n2)) acc[rt][ct][r] = NEG;
+                }
+        }
+        float cbv[2] = {NEG, NEG};
+        int cbr[2] = {0, 0};
+        const int c0 = gcol0 + i, c1 = gcol0 + 32 + i;
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const bool vr = grow0 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h < n1;
-#pragma unroll
-                for (int ct = 0; ct < 2; ++ct) {
-                    const bool vc = gcol0 + ct * 32 + i < n2;
-                    if (!(vr && vc)) acc[rt][ct][r] = NEG;
-                }
+                const int lrow = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float v0 = acc[rt][0][r], v1 = acc[rt][1][r];
+                // columns: ascending row order + strict '>' keeps the lowest row among equals
+                bool gt = v0 > cbv[0]; cbv[0] = gt ? v0 : cbv[0]; cbr[0] = gt ? lrow : cbr[0];
+                gt = v1 > cbv[1]; cbv[1] = gt ? v1 : cbv[1]; cbr[1] = gt ? lrow : cbr[1];
+                // rows: ascending column order (tile 0 before tile 1, c0 < c1) + strict '>'
+                const int q = rt * 16 + r;
+                gt = v0 > rbv[q]; rbv[q] = gt ? v0 : rbv[q]; rbc[q] = gt ? c0 : rbc[q];
+                gt = v1 > rbv[q]; rbv[q] = gt ? v1 : rbv[q]; rbc[q] = gt ? c1 : rbc[q];
             }
-    }
-    // column best: ascending row order + strict '>' keeps the lowest row among equals
-    float cbv[2] = {NEG, NEG};
-    int cbr[2] = {0, 0};
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int lrow = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct) {
-                const float v = acc[rt][ct][r];
-                const bool gt = v > cbv[ct];
-                cbv[ct] = gt ? v : cbv[ct];
-                cbr[ct] = gt ? lrow : cbr[ct];
-            }
+        for (int ct = 0; ct < 2; ++ct) {
+            const u64 k = (cbv[ct] > NEG) ? pack_key(cbv[ct], (unsigned)(grow0 + cbr[ct])) : 0ull;
+            const u64 kk = umax64(k, __shfl_xor(k, 32));
+            if (lane < 32) sCol[wave * 64 + ct * 32 + lane] = kk;
         }
-    u64 ck[2];
+        __syncthreads();                   // sB is free, column keys are visible
+        if (wr == 0) {
+            const u64 k = umax64(sCol[wave * 64 + lane], sCol[(wave + 2) * 64 + lane]);
+            partC[(size_t)by * n2pad + bx * MT + wc * 64 + lane] = k;
+        }
+        if (tile == 0 && has_b1) {
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-        const u64 k = (cbv[ct] > NEG) ? pack_key(cbv[ct], (unsigned)(grow0 + cbr[ct])) : 0ull;
-        ck[ct] = umax64(k, __shfl_xor(k, 32));
+            for (int p = 0; p < 8; ++p) *(f32x4*)(sB + (p * 16 + r0) * LDK + sub * 4) = vb[p];
+            __syncthreads();
+        }
     }
 
-    __syncthreads();                       // every wave is done with sA/sB: reuse as scratch
-    float* sT = smem + wave * (64 * LDK);  // this wave's 64 x 64 tile, row stride LDK
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int lrow = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            sT[lrow * LDK + i] = acc[rt][0][r];
-            sT[lrow * LDK + 32 + i] = acc[rt][1][r];
-        }
-    // the tile is private to the wave: a wave-level fence is enough
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    float rbv = NEG; int rbc = 0;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const f32x4 v = *(const f32x4*)(sT + lane * LDK + q * 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const bool gt = v[e] > rbv;
-            rbv = gt ? v[e] : rbv;
-            rbc = gt ? (q * 4 + e) : rbc;
-        }
+    // ---- rows: one packed-key reduce-scatter over the 32 lanes of each half --------------
+    u64 rk[32];
+    pack_rows(rk, rbv, rbc, std::make_integer_sequence<int, 32>{});
+    bfly_step<16>(rk, (lane & 16) != 0, std::make_integer_sequence<int, 16>{});
+    bfly_step<8>(rk, (lane & 8) != 0, std::make_integer_sequence<int, 8>{});
+    bfly_step<4>(rk, (lane & 4) != 0, std::make_integer_sequence<int, 4>{});
+    bfly_step<2>(rk, (lane & 2) != 0, std::make_integer_sequence<int, 2>{});
+    bfly_step<1>(rk, (lane & 1) != 0, std::make_integer_sequence<int, 1>{});
+    {
+        // lane (i,h) now holds slot q = i: row (q>>4)*32 + (q&3) + 8*((q&15)>>2) + 4h
+        const int q = i;
+        const int lr = (q >> 4) * 32 + (q & 3) + 8 * ((q & 15) >> 2) + 4 * h;
+        sRow[wave * 64 + lr] = rk[0];
     }
-    const u64 rkey = (rbv > NEG) ? pack_key(rbv, (unsigned)(gcol0 + rbc)) : 0ull;
-    __syncthreads();                       // all tiles consumed: reuse the head of smem for the merges
-    u64* sRow = (u64*)smem;                // [4 waves][64]
-    u64* sCol = sRow + 4 * 64;             // [4 waves][64]
-    sRow[wave * 64 + lane] = rkey;         // lane = local row
-    if (lane < 32) { sCol[wave * 64 + lane] = ck[0]; sCol[wave * 64 + 32 + lane] = ck[1]; }
     __syncthreads();
     if (wc == 0) {
         const u64 k = umax64(sRow[wave * 64 + lane], sRow[(wave + 1) * 64 + lane]);
-        partR[(size_t)bx * n1pad + by * MT + wr * 64 + lane] = k;
-    }
-    if (wr == 0) {
-        const u64 k = umax64(sCol[wave * 64 + lane], sCol[(wave + 2) * 64 + lane]);
-        partC[(size_t)by * n2pad + bx * MT + wc * 64 + lane] = k;
+        partR[(size_t)bx2 * n1pad + by * MT + wr * 64 + lane] = k;
     }
 }
 
-__global__ void k_mnn_reduce(const u64* __restrict__ partR, const u64* __restrict__ partC, int nbR, int nbC,
-                             int n1, int n2, int n1pad, int n2pad,
-                             int* __restrict__ best12, float* __restrict__ val12, int* __restrict__ best21) {
+__global__ __launch_bounds__(256)
+void k_mnn_reduce(const u64* __restrict__ partR, const u64* __restrict__ partC, int nbR, int nbC,
+                  int n1, int n2, int n1pad, int n2pad,
+                  int* __restrict__ best12, float* __restrict__ val12, int* __restrict__ best21) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < n1) {
-        u64 k = 0;
-        for (int b = 0; b < nbC; ++b) k = umax64(k, partR[(size_t)b * n1pad + t]);
-        best12[t] = (int)(0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull));
-        val12[t] = ord2f((unsigned)(k >> 32));
-    } else if (t >= n1pad && t - n1pad < n2) {
-        const int c = t - n1pad;
-        u64 k = 0;
-        for (int b = 0; b < nbR; ++b) k = umax64(k, partC[(size_t)b * n2pad + c]);
-        best21[c] = (int)(0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull));
+    const bool isrow = t < n1pad;
+    const int idx = isrow ? t : t - n1pad;
+    const int n = isrow ? n1 : n2, nb = isrow ? nbC : nbR;
+    const size_t stride = isrow ? (size_t)n1pad : (size_t)n2pad;
+    const u64* p = (isrow ? partR : partC) + idx;
+    if (idx >= n) return;
+    u64 k = 0;
+    int b = 0;
+    for (; b + 8 <= nb; b += 8) {
+        u64 v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = p[(size_t)(b + q) * stride];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) k = umax64(k, v[q]);
     }
+    for (; b < nb; ++b) k = umax64(k, p[(size_t)b * stride]);
+    const int bi = (int)(0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull));
+    if (isrow) { best12[idx] = bi; val12[idx] = ord2f((unsigned)(k >> 32)); }
+    else best21[idx] = bi;
 }
 
 // one workgroup: mutual check + gate + ordered compaction (ascending idx1)
@@ -299,16 +345,16 @@ hipError_t launch_mnn(xfh_ctx* c, const float* d1, int n1, const float* d2, int 
                       int* idx1, int* idx2, float* dist, int* n_matches) {
     hipError_t e;
     if (n1 <= 0 || n2 <= 0) return hipMemsetAsync(n_matches, 0, sizeof(int), c->stream);
-    const int nbR = (n1 + MT - 1) / MT, nbC = (n2 + MT - 1) / MT;
+    const int nbR = (n1 + MT - 1) / MT, nbC = (n2 + MT - 1) / MT, nbC2 = (nbC + TPW - 1) / TPW;
     const int n1pad = nbR * MT, n2pad = nbC * MT;
     MatchWs& w = c->mws;
-    const size_t need_part = (size_t)nbC * n1pad + (size_t)nbR * n2pad;
+    const size_t need_part = (size_t)nbC2 * n1pad + (size_t)nbR * n2pad;
     if (w.cap_part < need_part) {
         if (w.partR) hipFree(w.partR);
         if ((e = hipMalloc((void**)&w.partR, need_part * sizeof(u64))) != hipSuccess) return e;
         w.cap_part = need_part;
     }
-    w.partC = w.partR + (size_t)nbC * n1pad;
+    w.partC = w.partR + (size_t)nbC2 * n1pad;
     const size_t need_best = (size_t)n1pad + n2pad;
     if (w.cap_best < need_best) {
         if (w.best12) hipFree(w.best12);
@@ -326,12 +372,10 @@ hipError_t launch_mnn(xfh_ctx* c, const float* d1, int n1, const float* d2, int 
     }
     w.norm2 = w.norm1 + (size_t)n1 * 64;
     hipLaunchKernelGGL(k_rownorm, dim3((n1 + n2 + 15) / 16 + 1), dim3(256), 0, c->stream, d1, n1, d2, n2, w.norm1, w.norm2);
-    bool armed = ktimer_begin(c, XFH_K_MNN_GEMM, -1);
-    hipLaunchKernelGGL(k_mnn_gemm, dim3(nbC, nbR), dim3(256), 0, c->stream, (const float*)w.norm1, n1, (const float*)w.norm2, n2,
-                       w.partR, w.partC, n1pad, n2pad);
-    ktimer_end(c, armed);
+    launch_k(c, XFH_K_MNN_GEMM, -1, k_mnn_gemm, dim3(nbC2, nbR), dim3(256), 0, (const float*)w.norm1, n1, (const float*)w.norm2, n2,
+             w.partR, w.partC, n1pad, n2pad, nbC);
     const int nthr = n1pad + n2pad;
-    hipLaunchKernelGGL(k_mnn_reduce, dim3((nthr + 255) / 256), dim3(256), 0, c->stream, w.partR, w.partC, nbR, nbC,
+    hipLaunchKernelGGL(k_mnn_reduce, dim3((nthr + 255) / 256), dim3(256), 0, c->stream, w.partR, w.partC, nbR, nbC2,
                        n1, n2, n1pad, n2pad, w.best12, w.val12, w.best21);
     hipLaunchKernelGGL(k_mnn_final, dim3(1), dim3(1024), 0, c->stream, w.best12, w.val12, w.best21, n1, min_cossim,
                        idx1, idx2, dist, n_matches);
@@ -340,8 +384,6 @@ hipError_t launch_mnn(xfh_ctx* c, const float* d1, int n1, const float* d2, int 
 
 hipError_t launch_dist_i32(xfh_ctx* c, const float* d1, int n1, const float* d2, int n2, int32_t* out) {
     if (n1 <= 0 || n2 <= 0) return hipSuccess;
-    bool armed = ktimer_begin(c, XFH_K_DIST_I32, -1);
-    hipLaunchKernelGGL(k_dist_i32, dim3((n2 + 63) / 64, (n1 + 63) / 64), dim3(256), 0, c->stream, d1, n1, d2, n2, out);
-    ktimer_end(c, armed);
+    launch_k(c, XFH_K_DIST_I32, -1, k_dist_i32, dim3((n2 + 63) / 64, (n1 + 63) / 64), dim3(256), 0, d1, n1, d2, n2, out);
     return hipGetLastError();
 }

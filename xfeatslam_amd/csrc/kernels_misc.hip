@@ -468,9 +468,7 @@ hipError_t run_extract(xfh_ctx* c, const uint8_t* d_gray, int B, int H0, int W0,
     CK(hipMemsetAsync(c->cand_count, 0, sizeof(int) * B, s));
     // image -> float, resize, InstanceNorm statistics
     const int npre = (H * W + 1023) / 1024;
-    bool armed = ktimer_begin(c, XFH_K_PREPROC, -1);
-    hipLaunchKernelGGL(k_preproc, dim3(npre, 1, B), dim3(256), 0, s, d_gray, (size_t)H0 * W0, H0, W0, H, W, c->X, xs, c->pre_part, c->pre_npart);
-    ktimer_end(c, armed);
+    launch_k(c, XFH_K_PREPROC, -1, k_preproc, dim3(npre, 1, B), dim3(256), 0, d_gray, (size_t)H0 * W0, H0, W0, H, W, c->X, xs, c->pre_part, c->pre_npart);
     CK(hipGetLastError());
     CK(launch_finalize_image(c, B, npre, (double)H * (double)W));
     hipLaunchKernelGGL(k_norm_aux, dim3((h4 * w4 + 255) / 256, 1, B), dim3(256), 0, s, c->X, xs, c->xstat, H, W,
@@ -516,28 +514,20 @@ hipError_t run_extract(xfh_ctx* c, const uint8_t* d_gray, int B, int H0, int W0,
     CK(launch_basic_layer(c, 20, c->xunfold, xs, nullptr, PRO_PLAIN, h8, w8, B));
     CK(launch_basic_layer(c, 21, c->raw[20], c->raw_stride[20], c->stat[20], PRO_BN, h8, w8, B));
     CK(launch_basic_layer(c, 22, c->raw[21], c->raw_stride[21], c->stat[21], PRO_BN, h8, w8, B));
-    armed = ktimer_begin(c, XFH_K_HEADS, -1);
-    hipLaunchKernelGGL(k_heads_final, dim3((h8 * w8 + HF_PX - 1) / HF_PX, 1, B), dim3(HF_PX), 0, s,
+    launch_k(c, XFH_K_HEADS, -1, k_heads_final, dim3((h8 * w8 + HF_PX - 1) / HF_PX, 1, B), dim3(HF_PX), 0,
                        c->raw[19], c->stat[19], c->raw[22], c->stat[22], c->raw_stride[19], c->w.heat2_w, c->w.heat2_b,
                        c->w.kp3_w, c->w.kp3_b, h8, w8, c->H1, xs / 64, c->K1h, xs);
-    ktimer_end(c, armed);
     CK(hipGetLastError());
     // NMS + score, top-k + placement, descriptors
-    armed = ktimer_begin(c, XFH_K_NMS, -1);
-    hipLaunchKernelGGL(k_nms_score, dim3(((W + 31) / 32) * ((H + 31) / 32), 1, B), dim3(256), 0, s, c->K1h, xs, c->H1, xs / 64,
+    launch_k(c, XFH_K_NMS, -1, k_nms_score, dim3(((W + 31) / 32) * ((H + 31) / 32), 1, B), dim3(256), 0, c->K1h, xs, c->H1, xs / 64,
                        H, W, c->cfg.nms_threshold, c->cand, c->cand_cap, c->cand_count);
-    ktimer_end(c, armed);
     CK(hipGetLastError());
     static bool attr = false;
     if (!attr) { CK(hipFuncSetAttribute((const void*)k_select, hipFuncAttributeMaxDynamicSharedMemorySize, SEL_LDS_KEYS * 8)); attr = true; }
-    armed = ktimer_begin(c, XFH_K_SELECT, -1);
-    hipLaunchKernelGGL(k_select, dim3(B), dim3(1024), SEL_LDS_KEYS * 8, s, c->cand, c->cand_cap, c->cand_count, W, nf, lap0, lap1,
+    launch_k(c, XFH_K_SELECT, -1, k_select, dim3(B), dim3(1024), SEL_LDS_KEYS * 8, c->cand, c->cand_cap, c->cand_count, W, nf, lap0, lap1,
                        c->slot_src, c->sel_key, c->sel_n, d_records, rec);
-    ktimer_end(c, armed);
     CK(hipGetLastError());
-    armed = ktimer_begin(c, XFH_K_DESC, -1);
-    hipLaunchKernelGGL(k_desc, dim3((nf + 3) / 4, 1, B), dim3(256), 0, s, c->m1n, c->raw_stride[17], c->slot_src, c->sel_key, H, W, nf,
+    launch_k(c, XFH_K_DESC, -1, k_desc, dim3((nf + 3) / 4, 1, B), dim3(256), 0, c->m1n, c->raw_stride[17], c->slot_src, c->sel_key, H, W, nf,
                        d_records, rec, xfh_record_kps_offset(), xfh_record_desc_offset(nf));
-    ktimer_end(c, armed);
     return hipGetLastError();
 }
