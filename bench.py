@@ -34,7 +34,7 @@ sys.path.insert(0, ROOT)
 PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, dense f32 MFMA
 NFEATURES = 4096
 KP_GAIN = 6.0                     # "dense" synthetic weights: > 4096 NMS candidates at VGA
-DOMINANT_LAYERS = (7, 17)         # k_conv_mfma<64,64,3,1,4,1,2,16,PRO_BN,EPI_STATS>: block3.1, block_fusion.1
+DOMINANT_LAYERS = (7, 17)         # k_conv_mfma<64,64,3,1,4,2,1,16,PRO_BN,EPI_STATS,32>: block3.1, block_fusion.1
 
 
 def conv_flops(H, W):
@@ -50,6 +50,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16, help="frames per GPU per step")
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--streams", type=int, default=3, help="independent sub-batches in flight (one ctx + HIP stream each)")
     ap.add_argument("--match-iters", type=int, default=100)
     ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the bounded CPU-baseline sample (0 = skip)")
     args = ap.parse_args()
@@ -76,8 +77,11 @@ def main():
 
     B, H, W, K = args.batch, args.height, args.width, args.steps
     blob = WT.pack_blob(WT.make_synthetic(1234, KP_GAIN))
-    ctx = Context(nfeatures=NFEATURES, max_height=H, max_width=W, max_batch=B, device=local_rank if use_dist else 0)
-    ctx.load_weights(blob)
+    S = 1 if use_dist else max(1, args.streams)
+    ctxs = [Context(nfeatures=NFEATURES, max_height=H, max_width=W, max_batch=B, device=local_rank if use_dist else 0) for _ in range(S)]
+    for c_ in ctxs:
+        c_.load_weights(blob)
+    ctx = ctxs[0]
     # frame i of the global batch goes to rank i mod N  (weak scaling: B frames per GPU)
     base = synth.frames(min(B, 8), H, W, seed=42 + 100 * rank)
     frames = np.concatenate([base] * ((B + len(base) - 1) // len(base)))[:B]
@@ -93,9 +97,14 @@ def main():
         d_in = capi.DeviceBuffer(frames.nbytes).upload(frames)
         d_rec = capi.DeviceBuffer(B * rec_bytes)
         in_ptr, rec_ptr = d_in.ptr, d_rec.ptr
+    extra_rec = [capi.DeviceBuffer(B * rec_bytes) for _ in range(S - 1)]
+    rec_ptrs = [rec_ptr] + [b_.ptr for b_ in extra_rec]
 
     def step():
-        capi.check(lib.xfh_extract_batch_device(ctx.h, in_ptr, B, H, W, 0, 0, rec_ptr), ctx.h)
+        # S sub-batches of B frames, each on its own ctx/stream: the latency-bound tail kernels of
+        # one sub-batch (top-k, statistics, the 15x20 layers) overlap the convolutions of another
+        for c_, rp in zip(ctxs, rec_ptrs):
+            capi.check(lib.xfh_extract_batch_device(c_.h, in_ptr, B, H, W, 0, 0, rp), c_.h)
         if use_dist:
             dist.all_gather_into_tensor(d_all, d_rec)
 
@@ -103,7 +112,8 @@ def main():
         if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
-        ctx.synchronize()
+        for c_ in ctxs:
+            c_.synchronize()
 
     for _ in range(args.warmup):
         step()
@@ -122,7 +132,7 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    frames_per_s = N * B * K / elapsed
+    frames_per_s = N * B * S * K / elapsed
 
     # ---- matching leg: 4096 x 4096 MNN on the descriptors of frame 0 vs frame 1 (device resident) --------
     nf = NFEATURES
@@ -204,12 +214,12 @@ def main():
         "value": frames_per_s, "unit": "frames/s", "n_gpus": N, "steps": K, "warmup": args.warmup,
         "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"configs[1]: {H}x{W} u8 frames, XFeat extract, nfeatures {nf}, {B} frames per GPU per step "
+        "config": {"workload": f"configs[1]: {H}x{W} u8 frames, XFeat extract, nfeatures {nf}, {B * S} frames per GPU per step ({S} sub-batch(es) of {B} on separate HIP streams) "
                                f"(per-frame BatchNorm statistics), inputs and 4096-row records resident in HBM"
                                + (", RCCL all-gather of records" if use_dist else ""),
-                   "frames_per_gpu_per_step": B, "height": H, "width": W, "nfeatures": nf,
+                   "frames_per_gpu_per_step": B * S, "sub_batches_in_flight": S, "height": H, "width": W, "nfeatures": nf,
                    "weights": f"synthetic seed 1234, keypoint-logit gain {KP_GAIN}", "parallelism": f"frames x{N}"},
-        "roofline": {"kernel": "k_conv_mfma<64,64,3,1,4,1,2,16,1,0> (block3.1, block_fusion.1: 3x3 64->64 at 1/8 res)",
+        "roofline": {"kernel": "k_conv_mfma<64,64,3,1,4,2,1,16,1,0,32> (block3.1, block_fusion.1: 3x3 64->64 at 1/8 res)", "concurrent_streams": S,
                      "bound": "mfma", "achieved": conv_tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": conv_tf / PEAK_F32_MFMA_TFLOPS, "traffic": (traffic or {}).get("conv_bytes_per_launch"),
                      "avg_launch_us": conv_us, "launches": n_conv, "flops_per_launch": conv_flops(H, W) * B},

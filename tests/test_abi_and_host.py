@@ -91,3 +91,16 @@ def test_cpp_dropin_compiles_and_links():
            "-Wl,-rpath," + os.path.join(ROOT, "xfeatslam_amd"), "-Wl,-rpath,/opt/rocm/lib", "-o", out]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_convert_weights_tool(tmp_path):
+    import torch
+    w = WT.make_synthetic(99)
+    sd = {k: torch.from_numpy(v) for k, v in w.items()}
+    sd["fine_matcher.0.weight"] = torch.zeros(512, 128)            # extra tensors are ignored
+    sd["block1.0.layer.1.running_mean"] = torch.zeros(4)
+    torch.save(sd, tmp_path / "xfeat.pt")
+    r = subprocess.run(["python", os.path.join(ROOT, "tools", "convert_weights.py"), str(tmp_path / "xfeat.pt"), str(tmp_path / "o.xfhw")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert (tmp_path / "o.xfhw").read_bytes() == WT.pack_blob(w)

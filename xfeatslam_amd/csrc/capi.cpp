@@ -136,8 +136,8 @@ int xfh_destroy(xfh_ctx* c) {
     if (c->own_stream) hipStreamSynchronize(c->own_stream);
     auto F = [](void* p) { if (p) hipFree(p); };
     F(c->d_gray); F(c->X); F(c->pre_part); F(c->xstat);
-    for (int i = 0; i < XFH_NUM_LAYERS; ++i) { F(c->raw[i]); F(c->part[i]); F(c->stat[i]); F(c->w.mfma[i]); }
-    for (int i = 0; i < 4; ++i) F(c->w.direct[i]);
+    for (int i = 0; i < XFH_NUM_LAYERS; ++i) { F(c->raw[i]); F(c->part[i]); F(c->stat[i]); F(c->w.mfma[i]); F(c->w.mfma32[i]); }
+    for (int i = 0; i < 3; ++i) F(c->w.direct[i]);
     F(c->w.fus2); F(c->w.fus2_bias); F(c->w.skip_w); F(c->w.skip_b); F(c->w.heat2_w); F(c->w.heat2_b); F(c->w.kp3_w); F(c->w.kp3_b);
     F(c->skip_pool); F(c->xunfold); F(c->b2in); F(c->fuse_in); F(c->feats); F(c->m1n); F(c->H1); F(c->K1h);
     F(c->cand); F(c->cand_count); F(c->slot_src); F(c->sel_key); F(c->sel_n); F(c->d_records);
@@ -183,8 +183,8 @@ static int upload(xfh_ctx* c, float** dst, const std::vector<float>& v) {
 
 // OIHW -> [chunk = tap*NCB + cb][n (COUTP)][CB] with the k permutation of the MFMA kernels:
 // inside each group of 8 channels, channel e sits at position 4*(e&1) + (e>>1).
-static std::vector<float> pack_mfma(const float* w, int cout, int cin, int ks, int coutp) {
-    const int CB = cin > 64 ? 64 : cin, NCB = cin / CB;
+static std::vector<float> pack_mfma(const float* w, int cout, int cin, int ks, int coutp, int cbmax = 64) {
+    const int CB = cin > cbmax ? cbmax : cin, NCB = cin / CB;
     std::vector<float> o((size_t)ks * ks * NCB * coutp * CB, 0.f);
     for (int ky = 0; ky < ks; ++ky) for (int kx = 0; kx < ks; ++kx) for (int cb = 0; cb < NCB; ++cb)
         for (int n = 0; n < cout; ++n) for (int lc = 0; lc < CB; ++lc) {
@@ -205,7 +205,7 @@ int xfh_load_weights(xfh_ctx* c, const void* blob, size_t nbytes) {
         snprintf(nm, sizeof nm, "%s.layer.0.weight", L.name);
         if (!blob_find(blob, nbytes, nm, &e) || (int)e.dims[0] != L.cout || (int)e.dims[1] != L.cin || (int)e.dims[2] != L.ks) return XFH_ERR_BAD_WEIGHTS;
         int rc;
-        if (i < 4) {
+        if (i < 3) {
             std::vector<float> o((size_t)9 * L.cin * L.cout);
             for (int co = 0; co < L.cout; ++co) for (int ci = 0; ci < L.cin; ++ci) for (int ky = 0; ky < 3; ++ky) for (int kx = 0; kx < 3; ++kx)
                 o[(((size_t)ky * 3 + kx) * L.cin + ci) * L.cout + co] = e.p[(((size_t)co * L.cin + ci) * 3 + ky) * 3 + kx];
@@ -213,6 +213,8 @@ int xfh_load_weights(xfh_ctx* c, const void* blob, size_t nbytes) {
         } else {
             const int coutp = (L.cout + 31) / 32 * 32;
             rc = upload(c, &c->w.mfma[i], pack_mfma(e.p, L.cout, L.cin, L.ks, coutp));
+            if (rc == XFH_OK && L.cin == 64 && L.cout == 64 && L.ks == 3)
+                rc = upload(c, &c->w.mfma32[i], pack_mfma(e.p, L.cout, L.cin, L.ks, coutp, 32));
         }
         if (rc != XFH_OK) return rc;
     }

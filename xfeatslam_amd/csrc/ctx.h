@@ -6,8 +6,9 @@
 
 // packed device weights
 struct DevWeights {
-    float* direct[4] = {nullptr, nullptr, nullptr, nullptr};   // layers 0..3: [ky][kx][ci][co]
-    float* mfma[XFH_NUM_LAYERS] = {};                          // layers 4..22: [chunk][n][CB], k-permuted
+    float* direct[3] = {nullptr, nullptr, nullptr};            // layers 0..2: [ky][kx][ci][co]
+    float* mfma[XFH_NUM_LAYERS] = {};                          // layers 3..22: [chunk][n][CB], k-permuted
+    float* mfma32[XFH_NUM_LAYERS] = {};                        // 3x3 64->64 layers packed with 32-channel chunks
     float* fus2 = nullptr;                                     // block_fusion.2 packed like an MFMA layer
     float* fus2_bias = nullptr;                                // [64]
     float* skip_w = nullptr; float* skip_b = nullptr;          // [24] each

@@ -20,6 +20,7 @@
 // exactly what the f32 MFMA computes when K is walked in order with a single accumulator,
 // and what oracle/xfeat_oracle.c does; statistics are fp64.
 #include "ctx.h"
+#include <stdlib.h>
 
 struct ConvArgs {
     const float* in;        // raw input slab (or plain input)
@@ -174,7 +175,7 @@ void k_conv_direct(ConvArgs a) {
 // implicit-GEMM convolution on the f32 matrix cores.
 //   WM x WN waves per workgroup; each wave owns 32 output pixels (WH x WW) and NT tiles of 32
 //   output channels.  COUTP = WN*NT*32 >= COUT (padded weight rows are zero).
-template <int CIN, int COUT, int KS, int ST, int WM, int WN, int NT, int WW, int PRO, int EPI>
+template <int CIN, int COUT, int KS, int ST, int WM, int WN, int NT, int WW, int PRO, int EPI, int CBMAX = 64>
 __global__ __launch_bounds__(64 * WM * WN)
 void k_conv_mfma(ConvArgs a) {
     constexpr int NTHR = 64 * WM * WN;
@@ -183,9 +184,10 @@ void k_conv_mfma(ConvArgs a) {
     constexpr int PAD = KS / 2;
     constexpr int TIH = (TH - 1) * ST + KS, TIW = (TW - 1) * ST + KS;
     constexpr int CP = CIN + 4;                  // LDS pixel stride (floats)
-    constexpr int CB = CIN > 64 ? 64 : CIN;      // channels per weight chunk
+    constexpr int CB = CIN > CBMAX ? CBMAX : CIN;   // channels per weight chunk
     constexpr int NCB = CIN / CB;
     constexpr int NCHUNK = KS * KS * NCB;
+    constexpr int NWBUF = NCHUNK > 1 ? 2 : 1;
     constexpr int WS = CB + 4;                   // LDS weight row stride
     constexpr int WCH = COUTP * CB;              // floats per chunk in global memory
     constexpr int NWLD = (WCH / 4 + NTHR - 1) / NTHR;
@@ -196,7 +198,7 @@ void k_conv_mfma(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_in = smem;
     float* s_w = smem + IN_FLOATS;               // two buffers of W_FLOATS
-    float* s_stat = s_w + 2 * W_FLOATS;          // 2*CIN floats (PRO_BN)
+    float* s_stat = s_w + NWBUF * W_FLOATS;      // 2*CIN floats (PRO_BN)
 
     const int t = threadIdx.x, b = blockIdx.z;
     const int tile = blockIdx.x, tx0 = (tile % a.tiles_x) * TW, ty0 = (tile / a.tiles_x) * TH;
@@ -344,13 +346,14 @@ void k_conv_mfma(ConvArgs a) {
 
 // ------------------------------------------------------------------------------------
 // host side: layer -> template instance
-template <int CIN, int COUT, int KS, int ST, int WM, int WN, int NT, int WW, int PRO, int EPI>
+template <int CIN, int COUT, int KS, int ST, int WM, int WN, int NT, int WW, int PRO, int EPI, int CBMAX = 64>
 static hipError_t conv_mfma_launch(xfh_ctx* c, const ConvArgs& a, int B, int* npart_out, int layer) {
     constexpr int WH = 32 / WW, TH = WM * WH, TW = WW;
     constexpr int COUTP = WN * NT * 32;
     constexpr int TIH = (TH - 1) * ST + KS, TIW = (TW - 1) * ST + KS;
-    constexpr int CB = CIN > 64 ? 64 : CIN;
-    constexpr size_t LDS = sizeof(float) * ((size_t)TIH * TIW * (CIN + 4) + 2 * (size_t)COUTP * (CB + 4) + 2 * CIN);
+    constexpr int CB = CIN > CBMAX ? CBMAX : CIN;
+    constexpr int NWBUF = (KS * KS * (CIN / CB)) > 1 ? 2 : 1;
+    constexpr size_t LDS = sizeof(float) * ((size_t)TIH * TIW * (CIN + 4) + NWBUF * (size_t)COUTP * (CB + 4) + 2 * CIN);
     static_assert(LDS <= 160 * 1024, "LDS budget");
     static_assert(sizeof(double) * WM * COUTP * 2 <= LDS, "stat scratch");
     ConvArgs aa = a;
@@ -358,7 +361,7 @@ static hipError_t conv_mfma_launch(xfh_ctx* c, const ConvArgs& a, int B, int* np
     const int tiles_y = (a.Hout + TH - 1) / TH;
     const int ntile = aa.tiles_x * tiles_y;
     if (npart_out) *npart_out = ntile;
-    auto kern = k_conv_mfma<CIN, COUT, KS, ST, WM, WN, NT, WW, PRO, EPI>;
+    auto kern = k_conv_mfma<CIN, COUT, KS, ST, WM, WN, NT, WW, PRO, EPI, CBMAX>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
@@ -380,10 +383,18 @@ static hipError_t conv_direct_launch(xfh_ctx* c, const ConvArgs& a, int B, int* 
 }
 
 // number of statistic partials a layer produces per frame (needed to size buffers up front)
+// tile configuration of the 3x3 64->64 layers at 1/8 resolution (see launch_basic_layer)
+static int conv_cfg() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("XFH_CONV_CFG"); v = e ? atoi(e) : 1; }
+    return v;
+}
+
 int conv_layer_npart(int li, int Hout, int Wout) {
     auto cdiv = [](int a, int b) { return (a + b - 1) / b; };
-    if (li < 4) return cdiv(Wout, 16) * cdiv(Hout, 16);
+    if (li < 3) return cdiv(Wout, 16) * cdiv(Hout, 16);
     switch (li) {
+        case 7: case 16: case 17: return cdiv(Wout, 16) * cdiv(Hout, 8);     // 8x16 pixels in both configurations
         case 9: case 10: case 11: return cdiv(Wout, 8) * cdiv(Hout, 8);      // WM=2, WW=8
         case 12: case 13: case 14: case 15: return cdiv(Wout, 8) * cdiv(Hout, 4);   // WM=1, WW=8
         default: return cdiv(Wout, 16) * cdiv(Hout, 8);                       // WM=4, WW=16
@@ -399,7 +410,7 @@ hipError_t launch_basic_layer(xfh_ctx* c, int li, const float* in, size_t in_str
     c->lh[li] = Hout; c->lw[li] = Wout;
     ConvArgs a{};
     a.in = in; a.in_stat = in_stat; a.in_stride = in_stride; a.Hin = Hin; a.Win = Win;
-    a.w = (li < 4) ? c->w.direct[li] : c->w.mfma[li];
+    a.w = (li < 3) ? c->w.direct[li] : c->w.mfma[li];
     a.bias = nullptr;
     a.out = c->raw[li]; a.out_stride = c->raw_stride[li]; a.Hout = Hout; a.Wout = Wout;
     a.part = c->part[li]; a.part_stride = c->part_stride[li];
@@ -410,19 +421,31 @@ hipError_t launch_basic_layer(xfh_ctx* c, int li, const float* in, size_t in_str
         case 0: e = conv_direct_launch<1, 4, 1, PRO_IN>(c, a, B, &np, li); break;
         case 1: e = conv_direct_launch<4, 8, 2, PRO_BN>(c, a, B, &np, li); break;
         case 2: e = conv_direct_launch<8, 8, 1, PRO_BN>(c, a, B, &np, li); break;
-        case 3: e = conv_direct_launch<8, 24, 2, PRO_BN>(c, a, B, &np, li); break;
+        case 3: e = conv_mfma_launch<8, 24, 3, 2, 4, 1, 1, 16, PRO_BN, EPI_STATS>(c, a, B, &np, li); break;   // K = 72 on the matrix cores
         case 4: e = conv_mfma_launch<24, 24, 3, 1, 4, 1, 1, 16, PRO_PLAIN, EPI_STATS>(c, a, B, &np, li); break;  // input = b2in
         case 5: e = conv_mfma_launch<24, 24, 3, 1, 4, 1, 1, 16, PRO_BN, EPI_STATS>(c, a, B, &np, li); break;
         case 6: e = conv_mfma_launch<24, 64, 3, 2, 4, 1, 2, 16, PRO_BN, EPI_STATS>(c, a, B, &np, li); break;
-        case 7: e = conv_mfma_launch<64, 64, 3, 1, 4, 1, 2, 16, PRO_BN, EPI_STATS>(c, a, B, &np, li); break;
+        case 7: case 17: case 16: {
+            // the dominant 3x3 64->64 instance: 8x16 pixels x 64 channels per workgroup, 8 waves (4 x 2),
+            // 32-channel weight chunks (67 KB LDS -> 2 workgroups per CU); measured 70 us vs 77 us for the
+            // 4-wave / 64-channel-chunk form at B = 16 (profiles/r01_conv_cfg.log).  XFH_CONV_CFG=0 selects the latter.
+            const int cfg = conv_cfg();
+            if (cfg != 0) a.w = c->w.mfma32[li];
+            if (li == 16) {                                                                                     // input = fuse_in
+                if (cfg != 0) e = conv_mfma_launch<64, 64, 3, 1, 4, 2, 1, 16, PRO_PLAIN, EPI_STATS, 32>(c, a, B, &np, li);
+                else e = conv_mfma_launch<64, 64, 3, 1, 4, 1, 2, 16, PRO_PLAIN, EPI_STATS>(c, a, B, &np, li);
+            } else {
+                if (cfg != 0) e = conv_mfma_launch<64, 64, 3, 1, 4, 2, 1, 16, PRO_BN, EPI_STATS, 32>(c, a, B, &np, li);
+                else e = conv_mfma_launch<64, 64, 3, 1, 4, 1, 2, 16, PRO_BN, EPI_STATS>(c, a, B, &np, li);
+            }
+            break;
+        }
         case 8: e = conv_mfma_launch<64, 64, 1, 1, 4, 1, 2, 16, PRO_BN, EPI_STATS>(c, a, B, &np, li); break;
         case 9: e = conv_mfma_launch<64, 64, 3, 2, 2, 2, 1, 8, PRO_BN, EPI_STATS>(c, a, B, &np, li); break;
         case 10: case 11: e = conv_mfma_launch<64, 64, 3, 1, 2, 2, 1, 8, PRO_BN, EPI_STATS>(c, a, B, &np, li); break;
         case 12: e = conv_mfma_launch<64, 128, 3, 2, 1, 4, 1, 8, PRO_BN, EPI_STATS>(c, a, B, &np, li); break;
         case 13: case 14: e = conv_mfma_launch<128, 128, 3, 1, 1, 4, 1, 8, PRO_BN, EPI_STATS>(c, a, B, &np, li); break;
         case 15: e = conv_mfma_launch<128, 64, 1, 1, 1, 2, 1, 8, PRO_BN, EPI_STATS>(c, a, B, &np, li); break;
-        case 16: e = conv_mfma_launch<64, 64, 3, 1, 4, 1, 2, 16, PRO_PLAIN, EPI_STATS>(c, a, B, &np, li); break;  // input = fuse_in
-        case 17: e = conv_mfma_launch<64, 64, 3, 1, 4, 1, 2, 16, PRO_BN, EPI_STATS>(c, a, B, &np, li); break;
         case 18: case 20:                                                                                      // inputs: feats / unfold(xhat)
             e = conv_mfma_launch<64, 64, 1, 1, 4, 1, 2, 16, PRO_PLAIN, EPI_STATS>(c, a, B, &np, li); break;
         case 19: case 21: case 22:
