@@ -60,7 +60,13 @@ def main():
     N = max(world, 1)
     torch = dist = None
     use_dist = N > 1 or bool(os.environ.get("XFH_FORCE_DIST"))     # the env var exercises the RCCL path on one GPU
+    saved_stdout = None
     if use_dist:
+        # RCCL prints a version banner on stdout when the communicator is created: keep stdout clean
+        # for the single JSON line by pointing fd 1 at stderr until the result is printed
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
         # torch only for the process group / RCCL; it must be imported before the HIP library
         # so that both share one HIP runtime
         import torch
@@ -77,39 +83,58 @@ def main():
 
     B, H, W, K = args.batch, args.height, args.width, args.steps
     blob = WT.pack_blob(WT.make_synthetic(1234, KP_GAIN))
-    S = 1 if use_dist else max(1, args.streams)
+    S = max(1, args.streams)
     ctxs = [Context(nfeatures=NFEATURES, max_height=H, max_width=W, max_batch=B, device=local_rank if use_dist else 0) for _ in range(S)]
     for c_ in ctxs:
         c_.load_weights(blob)
     ctx = ctxs[0]
-    # frame i of the global batch goes to rank i mod N  (weak scaling: B frames per GPU)
+    # frame i of the global batch goes to rank i mod N  (weak scaling: S*B frames per GPU per step)
     base = synth.frames(min(B, 8), H, W, seed=42 + 100 * rank)
     frames = np.concatenate([base] * ((B + len(base) - 1) // len(base)))[:B]
     rec_bytes = ctx.rec_bytes
 
     if use_dist:
+        # records of the S sub-batches are contiguous so that ONE all-gather moves them; two
+        # generations (ping-pong) let the collective of step i overlap the extraction of step i+1
         d_in = torch.from_numpy(frames).cuda()
-        d_rec = torch.empty(B * rec_bytes, dtype=torch.uint8, device="cuda")
-        d_all = torch.empty(N * B * rec_bytes, dtype=torch.uint8, device="cuda")
-        in_ptr, rec_ptr = d_in.data_ptr(), d_rec.data_ptr()
-        capi.check(lib.xfh_set_stream(ctx.h, C.c_void_p(torch.cuda.current_stream().cuda_stream)), ctx.h)
+        d_rec2 = [torch.empty(S * B * rec_bytes, dtype=torch.uint8, device="cuda") for _ in range(2)]
+        d_all2 = [torch.empty(N * S * B * rec_bytes, dtype=torch.uint8, device="cuda") for _ in range(2)]
+        in_ptr = d_in.data_ptr()
+        streams = [torch.cuda.Stream() for _ in range(S)]
+        comm = torch.cuda.Stream()
+        gathered = [None, None]                                # event: generation g has been all-gathered
+        for c_, st_ in zip(ctxs, streams):
+            capi.check(lib.xfh_set_stream(c_.h, C.c_void_p(st_.cuda_stream)), c_.h)
+        d_rec = d_rec2[0]
+        rec_ptr = d_rec.data_ptr()
     else:
         d_in = capi.DeviceBuffer(frames.nbytes).upload(frames)
-        d_rec = capi.DeviceBuffer(B * rec_bytes)
-        in_ptr, rec_ptr = d_in.ptr, d_rec.ptr
-    extra_rec = [capi.DeviceBuffer(B * rec_bytes) for _ in range(S - 1)]
-    rec_ptrs = [rec_ptr] + [b_.ptr for b_ in extra_rec]
+        d_recb = capi.DeviceBuffer(S * B * rec_bytes)
+        in_ptr, rec_ptr = d_in.ptr, d_recb.ptr
+    step_no = [0]
 
     def step():
         # S sub-batches of B frames, each on its own ctx/stream: the latency-bound tail kernels of
         # one sub-batch (top-k, statistics, the 15x20 layers) overlap the convolutions of another
-        for c_, rp in zip(ctxs, rec_ptrs):
-            capi.check(lib.xfh_extract_batch_device(c_.h, in_ptr, B, H, W, 0, 0, rp), c_.h)
         if use_dist:
-            dist.all_gather_into_tensor(d_all, d_rec)
+            g = step_no[0] & 1
+            base_ptr = d_rec2[g].data_ptr()
+            for k, (c_, st_) in enumerate(zip(ctxs, streams)):
+                if gathered[g] is not None:
+                    st_.wait_event(gathered[g])            # generation g was gathered two steps ago
+                capi.check(lib.xfh_extract_batch_device(c_.h, in_ptr, B, H, W, 0, 0, base_ptr + k * B * rec_bytes), c_.h)
+                comm.wait_stream(st_)
+            with torch.cuda.stream(comm):
+                dist.all_gather_into_tensor(d_all2[g], d_rec2[g])
+                gathered[g] = comm.record_event()
+            step_no[0] += 1
+        else:
+            for k, c_ in enumerate(ctxs):
+                capi.check(lib.xfh_extract_batch_device(c_.h, in_ptr, B, H, W, 0, 0, rec_ptr + k * B * rec_bytes), c_.h)
 
     def sync():
         if use_dist:
+            torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
         for c_ in ctxs:
@@ -137,6 +162,8 @@ def main():
     # ---- matching leg: 4096 x 4096 MNN on the descriptors of frame 0 vs frame 1 (device resident) --------
     nf = NFEATURES
     d1p = rec_ptr + ctx.desc_off
+    if use_dist:
+        capi.check(lib.xfh_set_stream(ctx.h, None), ctx.h)          # the matching leg runs on the ctx's own stream
     d2p = rec_ptr + (rec_bytes if B > 1 else 0) + ctx.desc_off
     mout = capi.DeviceBuffer(12 * nf + 64)
 
@@ -180,7 +207,7 @@ def main():
         orc = O.Oracle(blob)
         nthr = min(O.get_threads(), os.cpu_count() or 1)
         O.set_threads(nthr)
-        raw = d_rec.cpu().numpy() if use_dist else d_rec.download(np.uint8, rec_bytes * B)
+        raw = d_rec[:rec_bytes * B].cpu().numpy() if use_dist else d_recb.download(np.uint8, rec_bytes * B)
         recs = ctx.parse_records(raw, B)
         orc.extract(frames[0], nf, (0, 0))                          # warm-up + parity reference
         t0 = time.perf_counter()
@@ -230,7 +257,10 @@ def main():
                                "launches": n_gemm, "flops_per_launch": 2.0 * nf * nf * 64}},
         "cpu_baseline": cpu, "parity": parity,
     }
-    print(json.dumps(out))
+    sys.stdout.flush()
+    if saved_stdout is not None:
+        os.dup2(saved_stdout, 1)
+    print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier(); dist.destroy_process_group()
 
