@@ -143,14 +143,20 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
-    layer_mask = sum(1 << l for l in DOMINANT_LAYERS)
-    ctx.timing_enable(capi.K["CONV_MFMA"], layer_mask)
     sync()
     t0 = time.perf_counter()
     for _ in range(K):
         step()
     sync()
     elapsed = time.perf_counter() - t0
+    # roofline of the dominant kernel: the same K steps once more on ONE stream with dispatch-attached
+    # events on that kernel (with several sub-batches in flight its launches share the CUs with other
+    # kernels, and rocprofv3 --kernel-trace serialises the streams, so only this form is comparable)
+    layer_mask = sum(1 << l for l in DOMINANT_LAYERS)
+    ctx.timing_enable(capi.K["CONV_MFMA"], layer_mask)
+    for _ in range(K):
+        capi.check(lib.xfh_extract_batch_device(ctx.h, in_ptr, B, H, W, 0, 0, rec_ptr), ctx.h)
+    ctx.synchronize()
     n_conv, ms_conv = ctx.timing_read()
     ctx.timing_enable(0)
     if use_dist:
@@ -246,7 +252,7 @@ def main():
                                + (", RCCL all-gather of records" if use_dist else ""),
                    "frames_per_gpu_per_step": B * S, "sub_batches_in_flight": S, "height": H, "width": W, "nfeatures": nf,
                    "weights": f"synthetic seed 1234, keypoint-logit gain {KP_GAIN}", "parallelism": f"frames x{N}"},
-        "roofline": {"kernel": "k_conv_mfma<64,64,3,1,4,2,1,16,1,0,32> (block3.1, block_fusion.1: 3x3 64->64 at 1/8 res)", "concurrent_streams": S,
+        "roofline": {"kernel": "k_conv_mfma<64,64,3,1,4,2,1,16,1,0,32> (block3.1, block_fusion.1: 3x3 64->64 at 1/8 res)", "measured": "single-stream pass of the same steps",
                      "bound": "mfma", "achieved": conv_tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": conv_tf / PEAK_F32_MFMA_TFLOPS, "traffic": (traffic or {}).get("conv_bytes_per_launch"),
                      "avg_launch_us": conv_us, "launches": n_conv, "flops_per_launch": conv_flops(H, W) * B},
