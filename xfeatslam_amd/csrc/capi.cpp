@@ -144,7 +144,7 @@ int xfh_destroy(xfh_ctx* c) {
     if (c->h_records) hipHostFree(c->h_records);
     if (c->h_gray) hipHostFree(c->h_gray);
     MatchWs& w = c->mws;
-    F(w.partR); F(w.best12); F(w.h_d1); F(w.o_idx1); F(w.o_tab); F(w.norm1);
+    F(w.bestR); F(w.h_d1); F(w.o_idx1); F(w.o_tab); F(w.norm1);
     if (c->timer.ev) { for (int i = 0; i < 2 * KTimer::MAXEV; ++i) if (c->timer.ev[i]) hipEventDestroy(c->timer.ev[i]); free(c->timer.ev); }
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;

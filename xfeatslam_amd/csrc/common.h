@@ -52,8 +52,7 @@ struct KTimer {
 
 // ---- matcher workspace ----------------------------------------------------------------
 struct MatchWs {
-    u64* partR = nullptr; u64* partC = nullptr; size_t cap_part = 0;   // elements each
-    int* best12 = nullptr; float* val12 = nullptr; int* best21 = nullptr; size_t cap_best = 0;
+    u64* bestR = nullptr; u64* bestC = nullptr; size_t cap_best = 0;   // packed arg-max keys per d1 row / d2 row
     float* h_d1 = nullptr; float* h_d2 = nullptr; size_t cap_in = 0;   // device staging of host inputs
     int* o_idx1 = nullptr; int* o_idx2 = nullptr; float* o_dist = nullptr; int* o_n = nullptr; size_t cap_out = 0;
     int32_t* o_tab = nullptr; size_t cap_tab = 0;

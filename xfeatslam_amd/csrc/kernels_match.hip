@@ -4,7 +4,6 @@
 //                   the row L2-normalisation fused into the tile load and the row / column
 //                   arg-max fused into the epilogue (reference: the commented-out
 //                   ORBmatcher::match, src/ORBmatcher.cc:358-368).
-//   k_mnn_reduce  : merges the per-tile arg-max partials.
 //   k_mnn_final   : mutual check, min_cossim gate, ordered compaction, distances (:371-403).
 //   k_dist_i32    : dense (int)(512 * ||a-b||^2), ORBmatcher::DescriptorDistance (:2246-2247).
 //
@@ -30,12 +29,12 @@ __device__ __forceinline__ u64 umax64(u64 a, u64 b) { return a > b ? a : b; }
 // reads k = 8g+2j+h for MFMA j out of one ds_read_b128.  16 lanes per row, 16 rows per block.
 __global__ __launch_bounds__(256)
 void k_rownorm(const float* __restrict__ d1, int n1, const float* __restrict__ d2, int n2,
-               float* __restrict__ o1, float* __restrict__ o2) {
+               float* __restrict__ o1, float* __restrict__ o2, u64* __restrict__ bestR, u64* __restrict__ bestC) {
     const int t = threadIdx.x, sub = t & 15;
     int row = blockIdx.x * 16 + (t >> 4);
     const float* d; float* o;
-    if (row < n1) { d = d1; o = o1; }
-    else { row -= n1; if (row >= n2) return; d = d2; o = o2; }      // 16-lane groups exit together
+    if (row < n1) { d = d1; o = o1; if (sub == 0) bestR[row] = 0ull; }       // arg-max keys start at "nothing"
+    else { row -= n1; if (row >= n2) return; d = d2; o = o2; if (sub == 0) bestC[row] = 0ull; }   // 16-lane groups exit together
     const f32x4 v = *(const f32x4*)(d + (size_t)row * 64 + sub * 4);
     double ss = (double)v.x * (double)v.x + (double)v.y * (double)v.y + (double)v.z * (double)v.z + (double)v.w * (double)v.w;
     ss += __shfl_xor(ss, 1); ss += __shfl_xor(ss, 2); ss += __shfl_xor(ss, 4); ss += __shfl_xor(ss, 8);
@@ -81,8 +80,9 @@ __device__ __forceinline__ void pack_rows(u64 (&rk)[32], const float (&rbv)[32],
 #define TPW 2
 __global__ __launch_bounds__(256, 2)
 void k_mnn_gemm(const float* __restrict__ d1, int n1, const float* __restrict__ d2, int n2,
-                u64* __restrict__ partR, u64* __restrict__ partC, int n1pad, int n2pad, int nbC) {
-    // d1/d2: normalised, k-permuted rows from k_rownorm
+                u64* __restrict__ bestR, u64* __restrict__ bestC, int nbC) {
+    // d1/d2: normalised, k-permuted rows from k_rownorm; bestR/bestC: packed arg-max keys, merged with
+    // 64-bit atomic max (order independent, so the result is deterministic)
     __shared__ __attribute__((aligned(16))) float smem[2 * MT * LDK + 2 * 4 * 64 * 2];
     float* sA = smem;
     float* sB = smem + MT * LDK;
@@ -194,7 +194,7 @@ void k_mnn_gemm(const float* __restrict__ d1, int n1, const float* __restrict__ 
         __syncthreads();                   // sB is free, column keys are visible
         if (wr == 0) {
             const u64 k = umax64(sCol[wave * 64 + lane], sCol[(wave + 2) * 64 + lane]);
-            partC[(size_t)by * n2pad + bx * MT + wc * 64 + lane] = k;
+            if (k) __hip_atomic_fetch_max(bestC + bx * MT + wc * 64 + lane, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (tile == 0 && has_b1) {
 #pragma unroll
@@ -220,68 +220,57 @@ void k_mnn_gemm(const float* __restrict__ d1, int n1, const float* __restrict__ 
     __syncthreads();
     if (wc == 0) {
         const u64 k = umax64(sRow[wave * 64 + lane], sRow[(wave + 1) * 64 + lane]);
-        partR[(size_t)bx2 * n1pad + by * MT + wr * 64 + lane] = k;
+        if (k) __hip_atomic_fetch_max(bestR + by * MT + wr * 64 + lane, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
-__global__ __launch_bounds__(256)
-void k_mnn_reduce(const u64* __restrict__ partR, const u64* __restrict__ partC, int nbR, int nbC,
-                  int n1, int n2, int n1pad, int n2pad,
-                  int* __restrict__ best12, float* __restrict__ val12, int* __restrict__ best21) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool isrow = t < n1pad;
-    const int idx = isrow ? t : t - n1pad;
-    const int n = isrow ? n1 : n2, nb = isrow ? nbC : nbR;
-    const size_t stride = isrow ? (size_t)n1pad : (size_t)n2pad;
-    const u64* p = (isrow ? partR : partC) + idx;
-    if (idx >= n) return;
-    u64 k = 0;
-    int b = 0;
-    for (; b + 8 <= nb; b += 8) {
-        u64 v[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = p[(size_t)(b + q) * stride];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) k = umax64(k, v[q]);
-    }
-    for (; b < nb; ++b) k = umax64(k, p[(size_t)b * stride]);
-    const int bi = (int)(0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull));
-    if (isrow) { best12[idx] = bi; val12[idx] = ord2f((unsigned)(k >> 32)); }
-    else best21[idx] = bi;
-}
-
-// one workgroup: mutual check + gate + ordered compaction (ascending idx1)
+// one workgroup: mutual check + gate + ordered compaction (ascending idx1).  Thread t owns rows
+// 4t..4t+3 of every 4096-row chunk, so one ballot scan per chunk orders the output.
 __global__ __launch_bounds__(1024)
-void k_mnn_final(const int* __restrict__ best12, const float* __restrict__ val12, const int* __restrict__ best21,
-                 int n1, float min_cossim, int* __restrict__ idx1, int* __restrict__ idx2,
-                 float* __restrict__ dist, int* __restrict__ n_matches) {
+void k_mnn_final(const u64* __restrict__ bestR, const u64* __restrict__ bestC, int n1, float min_cossim,
+                 int* __restrict__ idx1, int* __restrict__ idx2, float* __restrict__ dist, int* __restrict__ n_matches) {
     __shared__ int wsum[16];
     __shared__ int base;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     if (t == 0) base = 0;
     __syncthreads();
-    for (int i0 = 0; i0 < n1; i0 += 1024) {
-        const int i = i0 + t;
-        bool keep = false; int j = 0; float v = 0.f;
-        if (i < n1) {
-            j = best12[i]; v = val12[i];
-            keep = (best21[j] == i);
-            if (min_cossim > 0.f) keep = keep && (v > min_cossim);
+    for (int i0 = 0; i0 < n1; i0 += 4096) {
+        u64 kr[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int i = i0 + t * 4 + q; kr[q] = (i < n1) ? bestR[i] : 0ull; }
+        int j[4]; float v[4]; u64 kc[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            j[q] = (int)(0xFFFFFFFFu - (unsigned)(kr[q] & 0xFFFFFFFFull));
+            v[q] = ord2f((unsigned)(kr[q] >> 32));
+            kc[q] = kr[q] ? bestC[j[q]] : 0ull;
         }
-        const u64 m = __ballot(keep);
-        const int before = __popcll(m & ((1ull << lane) - 1ull));
-        if (lane == 0) wsum[wave] = __popcll(m);
+        bool keep[4]; int cnt = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = i0 + t * 4 + q;
+            keep[q] = kr[q] != 0ull && (int)(0xFFFFFFFFu - (unsigned)(kc[q] & 0xFFFFFFFFull)) == i;
+            if (min_cossim > 0.f) keep[q] = keep[q] && (v[q] > min_cossim);
+            cnt += keep[q] ? 1 : 0;
+        }
+        // exclusive scan of cnt over the 1024 threads
+        int incl = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+        if (lane == 63) wsum[wave] = incl;
         __syncthreads();
-        int off = base;
+        int off = base + incl - cnt;
         for (int w = 0; w < wave; ++w) off += wsum[w];
-        if (keep) {
-            const int o = off + before;
-            idx1[o] = i; idx2[o] = j;
-            const float cd = 1.0f - v;
-            dist[o] = sqrtf(2.0f * cd);
-        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (keep[q]) {
+                idx1[off] = i0 + t * 4 + q; idx2[off] = j[q];
+                const float cd = 1.0f - v[q];
+                dist[off] = sqrtf(2.0f * cd);
+                ++off;
+            }
         __syncthreads();
-        if (t == 0) { int s = 0; for (int w = 0; w < 16; ++w) s += wsum[w]; base += s; }
+        if (t == 0) { int sacc = 0; for (int w = 0; w < 16; ++w) sacc += wsum[w]; base += sacc; }
         __syncthreads();
     }
     if (t == 0) *n_matches = base;
@@ -346,24 +335,14 @@ hipError_t launch_mnn(xfh_ctx* c, const float* d1, int n1, const float* d2, int 
     hipError_t e;
     if (n1 <= 0 || n2 <= 0) return hipMemsetAsync(n_matches, 0, sizeof(int), c->stream);
     const int nbR = (n1 + MT - 1) / MT, nbC = (n2 + MT - 1) / MT, nbC2 = (nbC + TPW - 1) / TPW;
-    const int n1pad = nbR * MT, n2pad = nbC * MT;
     MatchWs& w = c->mws;
-    const size_t need_part = (size_t)nbC2 * n1pad + (size_t)nbR * n2pad;
-    if (w.cap_part < need_part) {
-        if (w.partR) hipFree(w.partR);
-        if ((e = hipMalloc((void**)&w.partR, need_part * sizeof(u64))) != hipSuccess) return e;
-        w.cap_part = need_part;
-    }
-    w.partC = w.partR + (size_t)nbC2 * n1pad;
-    const size_t need_best = (size_t)n1pad + n2pad;
+    const size_t need_best = (size_t)n1 + n2;
     if (w.cap_best < need_best) {
-        if (w.best12) hipFree(w.best12);
-        if ((e = hipMalloc((void**)&w.best12, need_best * (2 * sizeof(int) + sizeof(float)))) != hipSuccess) return e;
+        if (w.bestR) hipFree(w.bestR);
+        if ((e = hipMalloc((void**)&w.bestR, need_best * sizeof(u64))) != hipSuccess) return e;
         w.cap_best = need_best;
     }
-    w.val12 = (float*)(w.best12 + w.cap_best);
-    w.best21 = (int*)(w.val12 + w.cap_best);
-
+    w.bestC = w.bestR + n1;
     const size_t need_norm = ((size_t)n1 + n2) * 64;
     if (w.cap_norm < need_norm) {
         if (w.norm1) hipFree(w.norm1);
@@ -371,13 +350,10 @@ hipError_t launch_mnn(xfh_ctx* c, const float* d1, int n1, const float* d2, int 
         w.cap_norm = need_norm;
     }
     w.norm2 = w.norm1 + (size_t)n1 * 64;
-    hipLaunchKernelGGL(k_rownorm, dim3((n1 + n2 + 15) / 16 + 1), dim3(256), 0, c->stream, d1, n1, d2, n2, w.norm1, w.norm2);
+    hipLaunchKernelGGL(k_rownorm, dim3((n1 + n2 + 15) / 16 + 1), dim3(256), 0, c->stream, d1, n1, d2, n2, w.norm1, w.norm2, w.bestR, w.bestC);
     launch_k(c, XFH_K_MNN_GEMM, -1, k_mnn_gemm, dim3(nbC2, nbR), dim3(256), 0, (const float*)w.norm1, n1, (const float*)w.norm2, n2,
-             w.partR, w.partC, n1pad, n2pad, nbC);
-    const int nthr = n1pad + n2pad;
-    hipLaunchKernelGGL(k_mnn_reduce, dim3((nthr + 255) / 256), dim3(256), 0, c->stream, w.partR, w.partC, nbR, nbC2,
-                       n1, n2, n1pad, n2pad, w.best12, w.val12, w.best21);
-    hipLaunchKernelGGL(k_mnn_final, dim3(1), dim3(1024), 0, c->stream, w.best12, w.val12, w.best21, n1, min_cossim,
+             w.bestR, w.bestC, nbC);
+    hipLaunchKernelGGL(k_mnn_final, dim3(1), dim3(1024), 0, c->stream, (const u64*)w.bestR, (const u64*)w.bestC, n1, min_cossim,
                        idx1, idx2, dist, n_matches);
     return hipGetLastError();
 }
