@@ -117,7 +117,7 @@ int xfh_create(const xfh_config* cfg, xfh_ctx** out) {
     c->cand_cap = 1024;
     while (c->cand_cap < xs) c->cand_cap <<= 1;
     A(c->cand, sizeof(u64) * B * c->cand_cap);
-    A(c->cand_count, sizeof(int) * B);
+    A(c->cand_count, sizeof(int) * B * CAND_CNT_STRIDE);
     A(c->slot_src, sizeof(int) * B * cfg->nfeatures);
     A(c->sel_key, sizeof(u64) * B * cfg->nfeatures);
     A(c->sel_n, sizeof(int) * B);

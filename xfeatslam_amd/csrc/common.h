@@ -7,6 +7,7 @@
 
 #define XFH_NUM_LAYERS 23
 #define XFH_DESC_DIM 64
+#define CAND_CNT_STRIDE 64   // ints between per-frame candidate counters: one 256-B line each (atomics on one line serialise)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));

@@ -250,72 +250,89 @@ void k_heads_final(const float* __restrict__ rawH, const float* __restrict__ sta
     }
 }
 
-// ---- k_nms_score: 32x32 pixels per workgroup ---------------------------------------------------
+// ---- k_nms_score: 64x16 pixels per workgroup ---------------------------------------------------
+// phase 1: the tile (+2 halo, fetched as aligned float4 with -inf outside the image, as max_pool2d
+// pads) goes to LDS; every thread owns 4 consecutive pixels of one row and evaluates the 5x5 maximum
+// from registers (15 ds_read_b128, ~60 VALU) and only records the (few) candidates;
+// phase 2: the candidates are scored densely, one per lane (the score arithmetic -- divides,
+// nearbyint, four taps -- would otherwise run mostly masked for every wave).
+#define NMS_TW 64
+#define NMS_TH 16
+#define NMS_LD 72
 __global__ __launch_bounds__(256)
 void k_nms_score(const float* __restrict__ K1h, size_t k_stride, const float* __restrict__ H1, size_t h_stride,
                  int H, int W, float thr, u64* __restrict__ cand, size_t cand_cap, int* __restrict__ cand_count) {
-    __shared__ float s[36 * 37];
-    __shared__ float hm[36 * 33];
+    __shared__ __attribute__((aligned(16))) float s[(NMS_TH + 4) * NMS_LD];
     __shared__ u64 keys[1024];
+    __shared__ unsigned short cpx[1024];
     __shared__ int cnt, base;
     const int t = threadIdx.x, b = blockIdx.z;
-    const int tiles_x = (W + 31) / 32;
-    const int tx0 = (blockIdx.x % tiles_x) * 32, ty0 = (blockIdx.x / tiles_x) * 32;
+    const int tiles_x = (W + NMS_TW - 1) / NMS_TW;
+    const int tx0 = (blockIdx.x % tiles_x) * NMS_TW, ty0 = (blockIdx.x / tiles_x) * NMS_TH;
     const float* k = K1h + (size_t)b * k_stride;
     const float NEG = -__builtin_huge_valf();
     if (t == 0) cnt = 0;
-    for (int e = t; e < 36 * 36; e += 256) {
-        const int iy = e / 36, ix = e % 36;
-        const int gy = ty0 - 2 + iy, gx = tx0 - 2 + ix;
-        s[iy * 37 + ix] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? k[(size_t)gy * W + gx] : NEG;   // max_pool2d pads with -inf
+    for (int item = t; item < (NMS_TH + 4) * (NMS_LD / 4); item += 256) {
+        const int iy = item / (NMS_LD / 4), c4 = item % (NMS_LD / 4);
+        const int gy = ty0 - 2 + iy, gx = tx0 - 4 + 4 * c4;              // W % 4 == 0: a float4 is all in or all out
+        f32x4 v = {NEG, NEG, NEG, NEG};
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = *(const f32x4*)(k + (size_t)gy * W + gx);
+        *(f32x4*)(s + iy * NMS_LD + 4 * c4) = v;
     }
     __syncthreads();
-    for (int e = t; e < 36 * 32; e += 256) {
-        const int iy = e >> 5, ix = e & 31;
-        const float* r = s + iy * 37 + ix;
-        hm[iy * 33 + ix] = fmaxf(fmaxf(fmaxf(r[0], r[1]), fmaxf(r[2], r[3])), r[4]);
-    }
-    __syncthreads();
-    const int lx = t & 31, ly0 = (t >> 5) * 4;
+    {
+        const int tx = t & 15, ty = t >> 4;
+        float m[4] = {NEG, NEG, NEG, NEG}, ctr[4] = {NEG, NEG, NEG, NEG};
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int ly = ly0 + q;
-        const int gy = ty0 + ly, gx = tx0 + lx;
-        const float* c = hm + ly * 33 + lx;
-        const float m = fmaxf(fmaxf(fmaxf(c[0], c[33]), fmaxf(c[66], c[99])), c[132]);
-        const float v = s[(ly + 2) * 37 + lx + 2];
-        if (gy < H && gx < W && v == m && v > thr) {
-            // score = nearest(K1h) * bilinear(H1) at (x,y)   (XFextractor.cc:280)
-            const int Wh = W >> 3, Hh = H >> 3;
-            const float fx = nearbyintf(grid_coord(gx, W, W)), fy = nearbyintf(grid_coord(gy, H, H));
-            float nv = 0.f;
-            if (fx >= 0.f && fx <= (float)(W - 1) && fy >= 0.f && fy <= (float)(H - 1))
-                nv = k[(size_t)(int)fy * W + (int)fx];
-            const float ix = grid_coord(gx, W, Wh), iy = grid_coord(gy, H, Hh);
-            const float xw = floorf(ix), yn = floorf(iy);
-            const float w = ix - xw, e = 1.0f - w, n = iy - yn, so = 1.0f - n;
-            const float nw = e * so, ne = w * so, sw = e * n, se = w * n;
-            const int x0 = (int)xw, y0 = (int)yn, x1 = x0 + 1, y1 = y0 + 1;
-            const bool vx0 = x0 >= 0 && x0 < Wh, vx1 = x1 >= 0 && x1 < Wh, vy0 = y0 >= 0 && y0 < Hh, vy1 = y1 >= 0 && y1 < Hh;
-            const float* h1 = H1 + (size_t)b * h_stride;
-            const float a = (vx0 && vy0) ? h1[y0 * Wh + x0] : 0.f, bb = (vx1 && vy0) ? h1[y0 * Wh + x1] : 0.f;
-            const float d = (vx0 && vy1) ? h1[y1 * Wh + x0] : 0.f, g = (vx1 && vy1) ? h1[y1 * Wh + x1] : 0.f;
-            const float hb = ((a * nw + bb * ne) + d * sw) + g * se;
-            float score = nv * hb;
-            if (gx == 0 && gy == 0) score = -1.0f;                       // :281-282
-            const int pos = atomicAdd(&cnt, 1);
-            // ascending key order == descending score, then ascending linear index (stable argsort)
-            keys[pos] = ((u64)(~f2ord(score)) << 32) | (u64)(unsigned)(gy * W + gx);
+        for (int r = 0; r < 5; ++r) {
+            const float* row = s + (ty + r) * NMS_LD + 4 * tx;
+            const f32x4 f0 = *(const f32x4*)row, f1 = *(const f32x4*)(row + 4), f2 = *(const f32x4*)(row + 8);
+            const float f[12] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w, f2.x, f2.y, f2.z, f2.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float h = fmaxf(fmaxf(fmaxf(f[j + 2], f[j + 3]), fmaxf(f[j + 4], f[j + 5])), f[j + 6]);
+                m[j] = fmaxf(m[j], h);
+                if (r == 2) ctr[j] = f[j + 4];
+            }
         }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (ty0 + ty < H && tx0 + 4 * tx + j < W && ctr[j] == m[j] && ctr[j] > thr)
+                cpx[atomicAdd(&cnt, 1)] = (unsigned short)(ty * NMS_TW + 4 * tx + j);
     }
     __syncthreads();
-    if (t == 0) base = atomicAdd(&cand_count[b], cnt);
+    const int n = cnt;
+    const int Wh = W >> 3, Hh = H >> 3;
+    const float* h1 = H1 + (size_t)b * h_stride;
+    for (int e = t; e < n; e += 256) {
+        const int ly = cpx[e] / NMS_TW, lx2 = cpx[e] % NMS_TW;
+        const int gy = ty0 + ly, gx = tx0 + lx2;
+        // score = nearest(K1h) * bilinear(H1) at (x,y)   (XFextractor.cc:280)
+        const float fx = nearbyintf(grid_coord(gx, W, W)), fy = nearbyintf(grid_coord(gy, H, H));
+        float nv = 0.f;
+        if (fx >= 0.f && fx <= (float)(W - 1) && fy >= 0.f && fy <= (float)(H - 1))
+            nv = k[(size_t)(int)fy * W + (int)fx];
+        const float ix = grid_coord(gx, W, Wh), iy = grid_coord(gy, H, Hh);
+        const float xw = floorf(ix), yn = floorf(iy);
+        const float w = ix - xw, ee = 1.0f - w, nn = iy - yn, so = 1.0f - nn;
+        const float nw = ee * so, ne = w * so, sw = ee * nn, se = w * nn;
+        const int x0 = (int)xw, y0 = (int)yn, x1 = x0 + 1, y1 = y0 + 1;
+        const bool vx0 = x0 >= 0 && x0 < Wh, vx1 = x1 >= 0 && x1 < Wh, vy0 = y0 >= 0 && y0 < Hh, vy1 = y1 >= 0 && y1 < Hh;
+        const float a = (vx0 && vy0) ? h1[y0 * Wh + x0] : 0.f, bb = (vx1 && vy0) ? h1[y0 * Wh + x1] : 0.f;
+        const float d = (vx0 && vy1) ? h1[y1 * Wh + x0] : 0.f, g = (vx1 && vy1) ? h1[y1 * Wh + x1] : 0.f;
+        const float hb = ((a * nw + bb * ne) + d * sw) + g * se;
+        float score = nv * hb;
+        if (gx == 0 && gy == 0) score = -1.0f;                       // :281-282
+        // ascending key order == descending score, then ascending linear index (stable argsort)
+        keys[e] = ((u64)(~f2ord(score)) << 32) | (u64)(unsigned)(gy * W + gx);
+    }
+    if (t == 0) base = atomicAdd(&cand_count[b * CAND_CNT_STRIDE], n);
     __syncthreads();
-    for (int e = t; e < cnt; e += 256)
+    for (int e = t; e < n; e += 256)
         if ((size_t)(base + e) < cand_cap) cand[(size_t)b * cand_cap + base + e] = keys[e];
 }
 
-// ---- k_select: one workgroup of 1024 threads per frame -------------------------------------------
+// ---- k_select_generic: any nfeatures (fallback when nfeatures > 4096): full bitonic sort -----------
 #define SEL_LDS_KEYS 16384
 template <bool LDSMEM>
 __device__ __forceinline__ void bitonic_sort(u64* a, int n, int t) {
@@ -334,7 +351,7 @@ __device__ __forceinline__ void bitonic_sort(u64* a, int n, int t) {
 }
 
 __global__ __launch_bounds__(1024)
-void k_select(u64* __restrict__ cand, size_t cand_cap, const int* __restrict__ cand_count, int W, int nfeatures,
+void k_select_generic(u64* __restrict__ cand, size_t cand_cap, const int* __restrict__ cand_count, int W, int nfeatures,
               int lap0, int lap1, int* __restrict__ slot_src, u64* __restrict__ sel_key, int* __restrict__ sel_n,
               uint8_t* __restrict__ records, size_t rec_bytes) {
     extern __shared__ __attribute__((aligned(16))) u64 skeys[];
@@ -342,7 +359,7 @@ void k_select(u64* __restrict__ cand, size_t cand_cap, const int* __restrict__ c
     __shared__ int baseF, baseB, baseV;
     const int t = threadIdx.x, b = blockIdx.x, lane = t & 63, wave = t >> 6;
     u64* gk = cand + (size_t)b * cand_cap;
-    int C = cand_count[b];
+    int C = cand_count[b * CAND_CNT_STRIDE];
     if ((size_t)C > cand_cap) C = (int)cand_cap;
     int n = 1024;
     while (n < C) n <<= 1;
@@ -394,9 +411,196 @@ void k_select(u64* __restrict__ cand, size_t cand_cap, const int* __restrict__ c
     if (t == 0) {
         sel_n[b] = N;
         RecordHeader* hdr = (RecordHeader*)(records + (size_t)b * rec_bytes);
-        hdr->n_valid = baseF + baseB; hdr->mono_index = baseF; hdr->n_candidates = cand_count[b]; hdr->reserved = 0;
+        hdr->n_valid = baseF + baseB; hdr->mono_index = baseF; hdr->n_candidates = cand_count[b * CAND_CNT_STRIDE]; hdr->reserved = 0;
     }
     (void)wsumV; (void)baseV;
+}
+
+// ---- k_select: top-k for nfeatures <= 4096, one workgroup of 1024 threads per frame ---------------
+//   * C > 4096 candidates: an 8-bit MSB radix select (LDS histogram) first finds the key prefix below
+//     which exactly nfeatures keys lie (keys are unique: score bits + linear pixel index) and
+//     compacts those keys;
+//   * the <= 4096 keys are sorted with a bitonic network that keeps 4 keys per thread in registers:
+//     strides 1-2 are register compare-exchanges, strides up to 32 threads are wave shuffles, and only
+//     the 10 widest of the 78 passes go through LDS with a barrier.  (Sorting all candidates with 16
+//     keys per thread was measured slower, 140 us vs 50 us: the ds_bpermute volume dominates.)
+//   * validity (score > 0) and front/back slots come from one ballot scan (thread t owns ranks
+//     KPT*t .. KPT*t+KPT-1).
+#define SEL_FAST_MAX 4096
+__device__ __forceinline__ void cmpx(u64& a, u64& b, bool asc) {          // a has the lower index
+    const bool sw = (a > b) == asc;
+    const u64 x = sw ? b : a, y = sw ? a : b;
+    a = x; b = y;
+}
+template <int KPT, int J>
+__device__ __forceinline__ void reg_stage(u64 (&key)[KPT], int k, int t) {
+#pragma unroll
+    for (int q = 0; q < KPT; ++q)
+        if ((q & J) == 0) cmpx(key[q], key[q + J], ((KPT * t + q) & k) == 0);
+}
+// sorts KPT*1024 keys ascending; thread t ends with ranks KPT*t .. KPT*t+KPT-1
+template <int KPT>
+__device__ __forceinline__ void hybrid_bitonic(u64 (&key)[KPT], u64* sk, int t) {
+    constexpr int NTOT = KPT * 1024;
+    for (int k = 2; k <= NTOT; k <<= 1) {
+        for (int j = k >> 1; j >= 1; j >>= 1) {
+            if (j >= 64 * KPT) {
+                const int m = j / KPT;                        // partner thread distance (>= 64: other wave)
+#pragma unroll
+                for (int q = 0; q < KPT; ++q) sk[q * 1024 + t] = key[q];
+                __syncthreads();
+                const bool lower = (t & m) == 0;
+#pragma unroll
+                for (int q = 0; q < KPT; ++q) {
+                    const u64 o = sk[q * 1024 + (t ^ m)];
+                    const bool keep_min = (lower == (((KPT * t + q) & k) == 0));
+                    key[q] = keep_min ? (key[q] < o ? key[q] : o) : (key[q] > o ? key[q] : o);
+                }
+                __syncthreads();
+            } else if (j >= KPT) {
+                const int m = j / KPT;                        // partner lane distance (< 64: same wave)
+                const bool lower = (t & m) == 0;
+#pragma unroll
+                for (int q = 0; q < KPT; ++q) {
+                    const u64 o = __shfl_xor(key[q], m);
+                    const bool keep_min = (lower == (((KPT * t + q) & k) == 0));
+                    key[q] = keep_min ? (key[q] < o ? key[q] : o) : (key[q] > o ? key[q] : o);
+                }
+            } else {
+                switch (j) {
+                    case 1: reg_stage<KPT, 1>(key, k, t); break;
+                    case 2: reg_stage<KPT, 2>(key, k, t); break;
+                    case 4: if constexpr (KPT > 4) reg_stage<KPT, 4>(key, k, t); break;
+                    case 8: if constexpr (KPT > 8) reg_stage<KPT, 8>(key, k, t); break;
+                }
+            }
+        }
+    }
+}
+// validity, slots and bookkeeping for the sorted keys held KPT per thread
+template <int KPT>
+__device__ __forceinline__ void place_sorted(const u64 (&key)[KPT], int t, int b, int N, int W, int nfeatures, int lap0, int lap1,
+                                             int* __restrict__ slot_src, u64* __restrict__ sel_key, int* __restrict__ sel_n,
+                                             uint8_t* __restrict__ records, size_t rec_bytes, int n_cand, int* wsumF, int* wsumB) {
+    const int lane = t & 63, wave = t >> 6;
+    for (int e = t; e < nfeatures; e += 1024) slot_src[(size_t)b * nfeatures + e] = -1;
+    __syncthreads();
+    bool front[KPT], back[KPT];
+    int cF = 0, cB = 0;
+#pragma unroll
+    for (int q = 0; q < KPT; ++q) {
+        const int i = KPT * t + q;
+        front[q] = false; back[q] = false;
+        if (i < N) {
+            const float score = ord2f(~(unsigned)(key[q] >> 32));
+            const int x = (int)((unsigned)(key[q] & 0xFFFFFFFFull) % (unsigned)W);
+            const bool valid = score > 0.f;                               // XFextractor.cc:313
+            back[q] = valid && (x >= lap0 && x <= lap1);                  // :332
+            front[q] = valid && !back[q];
+            sel_key[(size_t)b * nfeatures + i] = key[q];
+        }
+        cF += front[q] ? 1 : 0; cB += back[q] ? 1 : 0;
+    }
+    int iF = cF, iB = cB;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int oF = __shfl_up(iF, d), oB = __shfl_up(iB, d);
+        if (lane >= d) { iF += oF; iB += oB; }
+    }
+    if (lane == 63) { wsumF[wave] = iF; wsumB[wave] = iB; }
+    __syncthreads();
+    int oF = iF - cF, oB = iB - cB, totF = 0, totB = 0;
+    for (int w = 0; w < 16; ++w) {
+        if (w < wave) { oF += wsumF[w]; oB += wsumB[w]; }
+        totF += wsumF[w]; totB += wsumB[w];
+    }
+#pragma unroll
+    for (int q = 0; q < KPT; ++q) {
+        if (front[q]) slot_src[(size_t)b * nfeatures + oF++] = KPT * t + q;
+        if (back[q]) slot_src[(size_t)b * nfeatures + (nfeatures - 1 - oB++)] = KPT * t + q;
+    }
+    if (t == 0) {
+        sel_n[b] = N;
+        RecordHeader* hdr = (RecordHeader*)(records + (size_t)b * rec_bytes);
+        hdr->n_valid = totF + totB; hdr->mono_index = totF; hdr->n_candidates = n_cand; hdr->reserved = 0;
+    }
+}
+
+__global__ __launch_bounds__(1024)
+void k_select(const u64* __restrict__ cand, size_t cand_cap, const int* __restrict__ cand_count, int W, int nfeatures,
+              int lap0, int lap1, int* __restrict__ slot_src, u64* __restrict__ sel_key, int* __restrict__ sel_n,
+              uint8_t* __restrict__ records, size_t rec_bytes) {
+    extern __shared__ __attribute__((aligned(16))) u64 sk[];        // 16384 keys
+    __shared__ int hist[256];
+    __shared__ int wsumF[16], wsumB[16];
+    __shared__ int s_digit, s_need, s_done, s_cnt;
+    const int t = threadIdx.x, b = blockIdx.x, lane = t & 63, wave = t >> 6;
+    const u64* gk = cand + (size_t)b * cand_cap;
+    const int n_cand = cand_count[b * CAND_CNT_STRIDE];
+    int C = n_cand;
+    if ((size_t)C > cand_cap) C = (int)cand_cap;
+    const int N = C < nfeatures ? C : nfeatures;
+
+    if (C <= 4 * 1024) {
+        u64 key[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) key[q] = (4 * t + q < C) ? gk[4 * t + q] : ~0ull;
+        hybrid_bitonic<4>(key, sk, t);
+        place_sorted<4>(key, t, b, N, W, nfeatures, lap0, lap1, slot_src, sel_key, sel_n, records, rec_bytes, n_cand, wsumF, wsumB);
+        return;
+    }
+    // ---- more than 4096 candidates: radix select down to N, then the 4-per-thread sort -----------
+    int shift = 64;
+    u64 prefix = 0;
+    {
+        int need = N;
+        for (int pass = 0; pass < 8; ++pass) {
+            const int sh = 56 - 8 * pass;
+            for (int e = t; e < 256; e += 1024) hist[e] = 0;
+            __syncthreads();
+            for (int e = t; e < C; e += 1024) {
+                const u64 k = gk[e];
+                if (pass == 0 || (k >> (sh + 8)) == prefix) atomicAdd(&hist[(int)((k >> sh) & 255)], 1);
+            }
+            __syncthreads();
+            if (wave == 0) {
+                const int h0 = hist[lane * 4], h1 = hist[lane * 4 + 1], h2 = hist[lane * 4 + 2], h3 = hist[lane * 4 + 3];
+                const int s4 = h0 + h1 + h2 + h3;
+                int incl = s4;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+                const int excl = incl - s4;
+                if (excl < need && need <= incl) {
+                    int cum = excl, dg = lane * 4, hv = h0;
+                    if (cum + h0 < need) { cum += h0; dg = lane * 4 + 1; hv = h1;
+                        if (cum + h1 < need) { cum += h1; dg = lane * 4 + 2; hv = h2;
+                            if (cum + h2 < need) { cum += h2; dg = lane * 4 + 3; hv = h3; } } }
+                    s_digit = dg; s_need = need - cum; s_done = (hv == need - cum) ? 1 : 0;
+                }
+            }
+            __syncthreads();
+            prefix = (prefix << 8) | (u64)s_digit;
+            need = s_need;
+            shift = sh;
+            const int done = s_done;
+            __syncthreads();
+            if (done) break;
+        }
+    }
+    if (t == 0) s_cnt = 0;
+    for (int e = t; e < SEL_FAST_MAX; e += 1024) sk[e] = ~0ull;
+    __syncthreads();
+    for (int e = t; e < C; e += 1024) {
+        const u64 k = gk[e];
+        if ((k >> shift) <= prefix) sk[atomicAdd(&s_cnt, 1)] = k;
+    }
+    __syncthreads();
+    u64 key[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) key[q] = sk[4 * t + q];
+    __syncthreads();
+    hybrid_bitonic<4>(key, sk, t);
+    place_sorted<4>(key, t, b, N, W, nfeatures, lap0, lap1, slot_src, sel_key, sel_n, records, rec_bytes, n_cand, wsumF, wsumB);
 }
 
 // ---- k_desc: one wave per output slot, lane = descriptor channel ---------------------------------
@@ -465,7 +669,7 @@ hipError_t run_extract(xfh_ctx* c, const uint8_t* d_gray, int B, int H0, int W0,
     const int nf = c->cfg.nfeatures;
     const size_t rec = xfh_record_bytes(nf);
 
-    CK(hipMemsetAsync(c->cand_count, 0, sizeof(int) * B, s));
+    CK(hipMemsetAsync(c->cand_count, 0, sizeof(int) * B * CAND_CNT_STRIDE, s));
     // image -> float, resize, InstanceNorm statistics
     const int npre = (H * W + 1023) / 1024;
     launch_k(c, XFH_K_PREPROC, -1, k_preproc, dim3(npre, 1, B), dim3(256), 0, d_gray, (size_t)H0 * W0, H0, W0, H, W, c->X, xs, c->pre_part, c->pre_npart);
@@ -519,13 +723,20 @@ hipError_t run_extract(xfh_ctx* c, const uint8_t* d_gray, int B, int H0, int W0,
                        c->w.kp3_w, c->w.kp3_b, h8, w8, c->H1, xs / 64, c->K1h, xs);
     CK(hipGetLastError());
     // NMS + score, top-k + placement, descriptors
-    launch_k(c, XFH_K_NMS, -1, k_nms_score, dim3(((W + 31) / 32) * ((H + 31) / 32), 1, B), dim3(256), 0, c->K1h, xs, c->H1, xs / 64,
+    launch_k(c, XFH_K_NMS, -1, k_nms_score, dim3(((W + NMS_TW - 1) / NMS_TW) * ((H + NMS_TH - 1) / NMS_TH), 1, B), dim3(256), 0, c->K1h, xs, c->H1, xs / 64,
                        H, W, c->cfg.nms_threshold, c->cand, c->cand_cap, c->cand_count);
     CK(hipGetLastError());
-    static bool attr = false;
-    if (!attr) { CK(hipFuncSetAttribute((const void*)k_select, hipFuncAttributeMaxDynamicSharedMemorySize, SEL_LDS_KEYS * 8)); attr = true; }
-    launch_k(c, XFH_K_SELECT, -1, k_select, dim3(B), dim3(1024), SEL_LDS_KEYS * 8, c->cand, c->cand_cap, c->cand_count, W, nf, lap0, lap1,
-                       c->slot_src, c->sel_key, c->sel_n, d_records, rec);
+    if (nf <= SEL_FAST_MAX) {
+        static bool attr_f = false;
+        if (!attr_f) { CK(hipFuncSetAttribute((const void*)k_select, hipFuncAttributeMaxDynamicSharedMemorySize, SEL_LDS_KEYS * 8)); attr_f = true; }
+        launch_k(c, XFH_K_SELECT, -1, k_select, dim3(B), dim3(1024), SEL_LDS_KEYS * 8, (const u64*)c->cand, c->cand_cap, (const int*)c->cand_count, W, nf,
+                 lap0, lap1, c->slot_src, c->sel_key, c->sel_n, d_records, rec);
+    } else {
+        static bool attr = false;
+        if (!attr) { CK(hipFuncSetAttribute((const void*)k_select_generic, hipFuncAttributeMaxDynamicSharedMemorySize, SEL_LDS_KEYS * 8)); attr = true; }
+        launch_k(c, XFH_K_SELECT, -1, k_select_generic, dim3(B), dim3(1024), SEL_LDS_KEYS * 8, c->cand, c->cand_cap, (const int*)c->cand_count, W, nf,
+                 lap0, lap1, c->slot_src, c->sel_key, c->sel_n, d_records, rec);
+    }
     CK(hipGetLastError());
     launch_k(c, XFH_K_DESC, -1, k_desc, dim3((nf + 3) / 4, 1, B), dim3(256), 0, c->m1n, c->raw_stride[17], c->slot_src, c->sel_key, H, W, nf,
                        d_records, rec, xfh_record_kps_offset(), xfh_record_desc_offset(nf));
