@@ -60,6 +60,20 @@ public:
         for (int k = 0; k < n; ++k) _matches.emplace_back(DMatch(i1[k], i2[k], d[k]));   // :401
     }
 
+    // Guided matching: the inner loop of SearchByProjection / SearchByBoW / SearchForTriangulation / Fuse
+    // (ORBmatcher.cc:75-119): best and second-best DescriptorDistance over per-query candidate lists
+    // (CSR: offsets[nq+1], indices[]) with the reference's initial value 256 for both.
+    void best2(const Mat& queries, const Mat& targets, const std::vector<int>& offsets, const std::vector<int>& indices,
+               std::vector<int>& bestIdx, std::vector<int>& bestDist, std::vector<int>& secondIdx, std::vector<int>& secondDist,
+               int initDist = 256) {
+        const int nq = queries.rows;
+        bestIdx.assign(nq, -1); bestDist.assign(nq, initDist); secondIdx.assign(nq, -1); secondDist.assign(nq, initDist);
+        if (nq == 0) return;
+        const int rc = xfh_best2_csr(ctx, queries.template ptr<float>(0), nq, targets.template ptr<float>(0), targets.rows,
+                                     offsets.data(), indices.data(), initDist, bestIdx.data(), bestDist.data(), secondIdx.data(), secondDist.data());
+        if (rc != XFH_OK) throw std::runtime_error(std::string("XFmatcher::best2: ") + xfh_strerror(rc));
+    }
+
 protected:
     float mfNNratio;
     bool mbCheckOrientation;

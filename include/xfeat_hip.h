@@ -127,6 +127,25 @@ int xfh_descriptor_distance(const float* a, const float* b);
 int xfh_distance_i32(xfh_ctx* ctx, const float* d1, int n1, const float* d2, int n2, int32_t* out);
 int xfh_distance_i32_device(xfh_ctx* ctx, const float* d_d1, int n1, const float* d_d2, int n2, int32_t* d_out);
 
+/* Guided ("windowed") matching, the inner loop of ORBmatcher::SearchByProjection / SearchByBoW /
+ * SearchForTriangulation / Fuse (ORBmatcher.cc:82-119, 1928-1953, 450-500, ...): for query q the
+ * candidates are indices[offsets[q] .. offsets[q+1]) into the target descriptors, visited in that
+ * order with
+ *     dist = DescriptorDistance(query_q, target_idx);
+ *     if (dist < best)        { second = best; best = dist; best_idx = idx; }
+ *     else if (dist < second) { second = dist; }
+ * starting from best = second = init_dist (the reference keeps ORB's 256) and
+ * best_idx = -1.  second_idx is the candidate that holds `second` at the end (the reference keeps
+ * its pyramid level, always 0 for XFeat).  The map-state filters of the reference (already-matched
+ * map points, stereo consistency) are applied by the caller when it builds the candidate lists.
+ * All pointers host memory (the _device variant: device memory, asynchronous). */
+int xfh_best2_csr(xfh_ctx* ctx, const float* queries, int nq, const float* targets, int nt,
+                  const int* offsets, const int* indices, int init_dist,
+                  int* best_idx, int* best_dist, int* second_idx, int* second_dist);
+int xfh_best2_csr_device(xfh_ctx* ctx, const float* d_queries, int nq, const float* d_targets, int nt,
+                         const int* d_offsets, const int* d_indices, int init_dist,
+                         int* d_best_idx, int* d_best_dist, int* d_second_idx, int* d_second_dist);
+
 /* ---- plumbing ----------------------------------------------------------------------- */
 int xfh_synchronize(xfh_ctx* ctx);
 /* run the ctx on an externally owned hipStream_t (e.g. torch's current stream); NULL
@@ -151,7 +170,7 @@ int xfh_memcpy_d2h(void* dst, const void* src, size_t nbytes);
 enum {
     XFH_K_NONE = 0, XFH_K_MNN_GEMM = 1, XFH_K_CONV_MFMA = 2, XFH_K_CONV_DIRECT = 3,
     XFH_K_NMS = 4, XFH_K_SELECT = 5, XFH_K_DESC = 6, XFH_K_HEADS = 7, XFH_K_DIST_I32 = 8,
-    XFH_K_PREPROC = 9, XFH_K_COUNT = 10
+    XFH_K_PREPROC = 9, XFH_K_BEST2 = 10, XFH_K_COUNT = 11
 };
 /* layer_mask selects conv layers for XFH_K_CONV_*: 0 = every layer, else bit i = BasicLayer i
  * (0..22 in XFeatModel order) and bit 23 = block_fusion.2 */

@@ -51,6 +51,7 @@ def lib():
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
         L.xfo_distance_i32.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         L.xfo_descriptor_distance.argtypes = [C.c_void_p, C.c_void_p]
+        L.xfo_best2_csr.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 4
         _lib = L
     return _lib
 
@@ -122,3 +123,11 @@ def distance_i32(d1: np.ndarray, d2: np.ndarray) -> np.ndarray:
 def descriptor_distance(a: np.ndarray, b: np.ndarray) -> int:
     a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32)
     return int(lib().xfo_descriptor_distance(a.ctypes.data, b.ctypes.data))
+
+
+def best2_csr(queries, targets, offsets, indices, init_dist: int = 256):
+    q = np.ascontiguousarray(queries, np.float32); tg = np.ascontiguousarray(targets, np.float32)
+    off = np.ascontiguousarray(offsets, np.int32); ind = np.ascontiguousarray(indices, np.int32)
+    out = [np.zeros(max(len(q), 1), np.int32) for _ in range(4)]
+    lib().xfo_best2_csr(q.ctypes.data, len(q), tg.ctypes.data, off.ctypes.data, ind.ctypes.data, int(init_dist), *[o.ctypes.data for o in out])
+    return tuple(o[:len(q)] for o in out)

@@ -573,6 +573,24 @@ int xfo_distance_i32(const float* d1, int n1, const float* d2, int n2, int32_t* 
     return 0;
 }
 
+/* inner loop of ORBmatcher::SearchByProjection (src/ORBmatcher.cc:75-119; same shape at :450-500,
+ * :1928-1953, ...): candidates visited in list order, strict '<' against best and second, both
+ * starting at init_dist (256 in the reference), best index starting at -1. */
+int xfo_best2_csr(const float* q, int nq, const float* tg, const int* offsets, const int* indices, int init_dist,
+                  int* best_idx, int* best_dist, int* second_idx, int* second_dist) {
+    for (int i = 0; i < nq; ++i) {
+        int bestDist = init_dist, bestDist2 = init_dist, bestIdx = -1, idx2 = -1;
+        for (int p = offsets[i]; p < offsets[i + 1]; ++p) {
+            const int idx = indices[p];
+            const int dist = xfo_descriptor_distance(q + (size_t)i * 64, tg + (size_t)idx * 64);
+            if (dist < bestDist) { bestDist2 = bestDist; idx2 = bestIdx; bestDist = dist; bestIdx = idx; }
+            else if (dist < bestDist2) { bestDist2 = dist; idx2 = idx; }
+        }
+        best_idx[i] = bestIdx; best_dist[i] = bestDist; second_idx[i] = idx2; second_dist[i] = bestDist2;
+    }
+    return 0;
+}
+
 int xfo_match_mnn(const float* d1, int n1, const float* d2, int n2, float min_cossim,
                   int* idx1, int* idx2, float* dist, int* n_matches) {
     /* src/ORBmatcher.cc:358-359 normalise rows */

@@ -83,6 +83,11 @@ int xfo_match_mnn(const float* d1, int n1, const float* d2, int n2, float min_co
 int xfo_distance_i32(const float* d1, int n1, const float* d2, int n2, int32_t* out);
 int xfo_descriptor_distance(const float* a, const float* b);
 
+/* best / second-best integer distance over per-query candidate lists: the inner loop of
+ * ORBmatcher::SearchByProjection and friends (src/ORBmatcher.cc:75-119) */
+int xfo_best2_csr(const float* q, int nq, const float* tg, const int* offsets, const int* indices, int init_dist,
+                  int* best_idx, int* best_dist, int* second_idx, int* second_dist);
+
 #ifdef __cplusplus
 }
 #endif

@@ -21,7 +21,10 @@ def _ctx(nf, H, W, B=1):
 
 @pytest.mark.parametrize("H,W,gain,nf,lap", [(96, 128, 1.0, 256, (0, 0)), (480, 640, 1.0, 4096, (0, 0)),
                                               (480, 640, 6.0, 4096, (0, 1000)), (480, 640, 6.0, 1000, (200, 400)),
-                                              (720, 1280, 1.0, 4096, (0, 1000)), (170, 230, 2.0, 300, (100, 150))])
+                                              (720, 1280, 1.0, 4096, (0, 1000)), (170, 230, 2.0, 300, (100, 150)),
+                                              (1080, 1920, 6.0, 4096, (0, 1000)),      # > 16k candidates: radix-select path
+                                              (480, 640, 6.0, 8000, (0, 0)),           # nfeatures > 4096: generic sort path
+                                              (64, 32, 6.0, 64, (0, 0))])              # smallest supported image
 def test_extract_matches_oracle(gpu_lib, oracle_mod, H, W, gain, nf, lap):
     blob = WT.pack_blob(WT.make_synthetic(1234, gain))
     img = synth.image(H, W, 42)

@@ -101,3 +101,25 @@ def test_mnn_device_resident_and_deterministic(mctx):
         assert np.array_equal(r[0], host[0]) and np.array_equal(r[1], host[1]) and np.array_equal(r[2], host[2], equal_nan=True)
     # misaligned device pointer is rejected, not read
     assert L.xfh_match_mnn_device(mctx.h, b1.ptr + 4, n - 1, b2.ptr, n, -1.0, out.ptr, out.ptr, out.ptr, out.ptr) == 1
+
+
+def test_best2_csr_matches_oracle(mctx, oracle_mod):
+    """guided matching primitive (SearchByProjection inner loop) -- integer work: bit exact"""
+    rng = np.random.RandomState(3)
+    for nq, nt, mx, noise, init in [(500, 4096, 80, 0.25, 256), (64, 100, 300, 0.2, 256), (200, 1000, 20, 0.5, 1 << 30), (1, 1, 1, 0.1, 256)]:
+        q, tg = synth.descriptor_sets(nq, nt, noise=noise)
+        if nt > 10:
+            tg[7] = tg[3]
+        counts = rng.randint(0, mx + 1, nq)
+        off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+        ind = rng.randint(0, nt, off[-1]).astype(np.int32)
+        a = oracle_mod.best2_csr(q, tg, off, ind, init)
+        b = mctx.best2_csr(q, tg, off, ind, init)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+    # invalid lists are rejected on the host, nothing is read out of bounds
+    L = capi.lib()
+    q, tg = synth.descriptor_sets(4, 8)
+    off = np.array([0, 2, 2, 3, 4], np.int32); ind = np.array([0, 9, 1, 2], np.int32)
+    o = [np.zeros(4, np.int32) for _ in range(4)]
+    assert L.xfh_best2_csr(mctx.h, q.ctypes.data, 4, tg.ctypes.data, 8, off.ctypes.data, ind.ctypes.data, 256, *[x.ctypes.data for x in o]) == 1

@@ -36,7 +36,7 @@ const char* xfh_strerror(int s) {
 
 const char* xfh_kernel_name(int id) {
     static const char* n[XFH_K_COUNT] = {"none", "k_mnn_gemm", "k_conv_mfma", "k_conv_direct", "k_nms_score", "k_select",
-                                         "k_desc", "k_heads_final", "k_dist_i32", "k_preproc"};
+                                         "k_desc", "k_heads_final", "k_dist_i32", "k_preproc", "k_best2_csr"};
     return (id >= 0 && id < XFH_K_COUNT) ? n[id] : "?";
 }
 
@@ -144,7 +144,7 @@ int xfh_destroy(xfh_ctx* c) {
     if (c->h_records) hipHostFree(c->h_records);
     if (c->h_gray) hipHostFree(c->h_gray);
     MatchWs& w = c->mws;
-    F(w.bestR); F(w.h_d1); F(w.o_idx1); F(w.o_tab); F(w.norm1);
+    F(w.bestR); F(w.b2_buf); F(w.h_d1); F(w.o_idx1); F(w.o_tab); F(w.norm1);
     if (c->timer.ev) { for (int i = 0; i < 2 * KTimer::MAXEV; ++i) if (c->timer.ev[i]) hipEventDestroy(c->timer.ev[i]); free(c->timer.ev); }
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
@@ -397,6 +397,48 @@ int xfh_distance_i32(xfh_ctx* c, const float* d1, int n1, const float* d2, int n
     HIPCK(c, hipMemcpyAsync(w.h_d2, d2, b2, hipMemcpyHostToDevice, c->stream));
     HIPCK(c, launch_dist_i32(c, w.h_d1, n1, w.h_d2, n2, w.o_tab));
     HIPCK(c, hipMemcpyAsync(out, w.o_tab, (size_t)n1 * n2 * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return XFH_OK;
+}
+
+int xfh_best2_csr_device(xfh_ctx* c, const float* q, int nq, const float* tg, int nt, const int* offsets, const int* indices, int init_dist,
+                         int* best_idx, int* best_dist, int* second_idx, int* second_dist) {
+    if (!c || nq < 0 || nt < 0) return XFH_ERR_INVALID_ARG;
+    if (nq == 0) return XFH_OK;
+    if (!q || !offsets || !best_idx || !best_dist || !second_idx || !second_dist) return XFH_ERR_INVALID_ARG;
+    if ((((uintptr_t)q) | ((uintptr_t)tg)) & 15) return XFH_ERR_INVALID_ARG;
+    HIPCK(c, hipSetDevice(c->cfg.device));
+    HIPCK(c, launch_best2(c, q, nq, tg, offsets, indices, init_dist, best_idx, best_dist, second_idx, second_dist));
+    return XFH_OK;
+}
+
+int xfh_best2_csr(xfh_ctx* c, const float* q, int nq, const float* tg, int nt, const int* offsets, const int* indices, int init_dist,
+                  int* best_idx, int* best_dist, int* second_idx, int* second_dist) {
+    if (!c || nq < 0 || nt < 0) return XFH_ERR_INVALID_ARG;
+    if (nq == 0) return XFH_OK;
+    if (!q || !offsets || !best_idx || !best_dist || !second_idx || !second_dist) return XFH_ERR_INVALID_ARG;
+    const int nnz = offsets[nq];
+    if (nnz < 0 || (nnz > 0 && (!indices || !tg))) return XFH_ERR_INVALID_ARG;
+    for (int i = 0; i < nq; ++i) if (offsets[i] > offsets[i + 1] || offsets[i] < 0) return XFH_ERR_INVALID_ARG;
+    for (int p = 0; p < nnz; ++p) if (indices[p] < 0 || indices[p] >= nt) return XFH_ERR_INVALID_ARG;
+    HIPCK(c, hipSetDevice(c->cfg.device));
+    MatchWs& w = c->mws;
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t bq = al((size_t)nq * 256), bt = al((size_t)nt * 256 + 16), bo = al((size_t)(nq + 1) * 4), bi = al((size_t)nnz * 4 + 16), br = al((size_t)nq * 4);
+    int rc = grow(c, &w.b2_buf, &w.cap_b2, bq + bt + bo + bi + 4 * br);
+    if (rc != XFH_OK) return rc;
+    char* p0 = (char*)w.b2_buf;
+    float* dq = (float*)p0; float* dt = (float*)(p0 + bq); int* doff = (int*)(p0 + bq + bt); int* dind = (int*)(p0 + bq + bt + bo);
+    int* o0 = (int*)(p0 + bq + bt + bo + bi); int* o1 = (int*)((char*)o0 + br); int* o2 = (int*)((char*)o1 + br); int* o3 = (int*)((char*)o2 + br);
+    HIPCK(c, hipMemcpyAsync(dq, q, (size_t)nq * 256, hipMemcpyHostToDevice, c->stream));
+    if (nt > 0) HIPCK(c, hipMemcpyAsync(dt, tg, (size_t)nt * 256, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(doff, offsets, (size_t)(nq + 1) * 4, hipMemcpyHostToDevice, c->stream));
+    if (nnz > 0) HIPCK(c, hipMemcpyAsync(dind, indices, (size_t)nnz * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, launch_best2(c, dq, nq, dt, doff, dind, init_dist, o0, o1, o2, o3));
+    HIPCK(c, hipMemcpyAsync(best_idx, o0, (size_t)nq * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipMemcpyAsync(best_dist, o1, (size_t)nq * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipMemcpyAsync(second_idx, o2, (size_t)nq * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipMemcpyAsync(second_dist, o3, (size_t)nq * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));
     return XFH_OK;
 }

@@ -58,6 +58,7 @@ struct MatchWs {
     int* o_idx1 = nullptr; int* o_idx2 = nullptr; float* o_dist = nullptr; int* o_n = nullptr; size_t cap_out = 0;
     int32_t* o_tab = nullptr; size_t cap_tab = 0;
     float* norm1 = nullptr; float* norm2 = nullptr; size_t cap_norm = 0;   // normalised, k-permuted rows
+    void* b2_buf = nullptr; size_t cap_b2 = 0;                             // staging for the host-pointer best2 call
 };
 
 // ---- launchers implemented in the .hip files ------------------------------------------
@@ -65,3 +66,5 @@ struct xfh_ctx;
 hipError_t launch_mnn(xfh_ctx* c, const float* d1, int n1, const float* d2, int n2, float min_cossim,
                       int* idx1, int* idx2, float* dist, int* n_matches);
 hipError_t launch_dist_i32(xfh_ctx* c, const float* d1, int n1, const float* d2, int n2, int32_t* out);
+hipError_t launch_best2(xfh_ctx* c, const float* q, int nq, const float* tg, const int* offsets, const int* indices, int init_dist,
+                        int* best_idx, int* best_dist, int* second_idx, int* second_dist);

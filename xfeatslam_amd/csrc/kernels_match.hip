@@ -321,6 +321,66 @@ void k_dist_i32(const float* __restrict__ d1, int n1, const float* __restrict__ 
         }
 }
 
+// ---- k_best2_csr: best / second-best integer distance over per-query candidate lists -----------
+// One wave per query (the query row comes through the scalar cache); lane l visits candidates
+// l, l+64, ... and keeps its two smallest (dist << 32 | position) keys, which reproduces the
+// reference's sequential rule exactly (strict '<' in list order = smallest (dist, position)); a
+// butterfly merges the 64 lane pairs.  Distances are the exact DescriptorDistance arithmetic.
+__device__ __forceinline__ void top2_merge(u64& b, u64& s, u64 ob, u64 os) {
+    const u64 lo = b < ob ? b : ob, hi = b < ob ? ob : b;
+    const u64 ms = s < os ? s : os;
+    b = lo; s = hi < ms ? hi : ms;
+}
+__global__ __launch_bounds__(256)
+void k_best2_csr(const float* __restrict__ q, int nq, const float* __restrict__ tg, const int* __restrict__ offsets,
+                 const int* __restrict__ indices, int init_dist, int* __restrict__ best_idx, int* __restrict__ best_dist,
+                 int* __restrict__ second_idx, int* __restrict__ second_dist) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int qi = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wave);
+    if (qi >= nq) return;
+    const float* qr = q + (size_t)qi * 64;
+    const int beg = offsets[qi], end = offsets[qi + 1];
+    const u64 NONE = ~0ull;
+    u64 b = NONE, s2 = NONE;
+    for (int p = beg + lane; p < end; p += 64) {
+        const int idx = indices[p];
+        const f32x4* tr = (const f32x4*)(tg + (size_t)idx * 64);
+        double acc = 0.0;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const f32x4 tv = tr[g];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const double df = (double)(qr[g * 4 + e] - tv[e]); acc = fma(df, df, acc); }
+        }
+        const float nd = (float)acc;
+        const int dist = (int)(nd * 512.0f);
+        const u64 key = ((u64)(unsigned)dist << 32) | (u64)(unsigned)(p - beg);
+        if (key < b) { s2 = b; b = key; } else if (key < s2) s2 = key;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const u64 ob = __shfl_xor(b, m), os = __shfl_xor(s2, m);
+        top2_merge(b, s2, ob, os);
+    }
+    if (lane == 0) {
+        // apply the reference's initial values: a candidate only counts if dist < init_dist
+        int bd = init_dist, bi = -1, sd = init_dist, si = -1;
+        if (b != NONE && (int)(b >> 32) < init_dist) {
+            bd = (int)(b >> 32); bi = indices[beg + (int)(b & 0xFFFFFFFFull)];
+            if (s2 != NONE && (int)(s2 >> 32) < init_dist) { sd = (int)(s2 >> 32); si = indices[beg + (int)(s2 & 0xFFFFFFFFull)]; }
+        }
+        best_idx[qi] = bi; best_dist[qi] = bd; second_idx[qi] = si; second_dist[qi] = sd;
+    }
+}
+
+hipError_t launch_best2(xfh_ctx* c, const float* q, int nq, const float* tg, const int* offsets, const int* indices, int init_dist,
+                        int* best_idx, int* best_dist, int* second_idx, int* second_dist) {
+    if (nq <= 0) return hipSuccess;
+    launch_k(c, XFH_K_BEST2, -1, k_best2_csr, dim3((nq + 3) / 4), dim3(256), 0, q, nq, tg, offsets, indices, init_dist,
+             best_idx, best_dist, second_idx, second_dist);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------
 static hipError_t ensure(void** p, size_t* cap, size_t need_bytes) {
     if (*cap >= need_bytes && *p) return hipSuccess;

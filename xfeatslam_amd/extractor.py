@@ -95,6 +95,16 @@ class Context:
         check(lib().xfh_distance_i32(self.h, d1.ctypes.data, len(d1), d2.ctypes.data, len(d2), out.ctypes.data), self.h)
         return out
 
+    def best2_csr(self, queries, targets, offsets, indices, init_dist: int = 256):
+        """guided matching primitive: best / second-best (int)(512*d^2) over per-query candidate lists"""
+        q = np.ascontiguousarray(queries, np.float32); tg = np.ascontiguousarray(targets, np.float32)
+        off = np.ascontiguousarray(offsets, np.int32); ind = np.ascontiguousarray(indices, np.int32)
+        nq = len(q)
+        out = [np.zeros(max(nq, 1), np.int32) for _ in range(4)]
+        check(lib().xfh_best2_csr(self.h, q.ctypes.data, nq, tg.ctypes.data, len(tg), off.ctypes.data, ind.ctypes.data, int(init_dist),
+                                  *[o.ctypes.data for o in out]), self.h)
+        return tuple(o[:nq] for o in out)
+
     # -- timing ---------------------------------------------------------------------------
     def timing_enable(self, kernel_id: int, layer_mask: int = 0):
         check(lib().xfh_timing_enable(self.h, kernel_id, layer_mask), self.h)
