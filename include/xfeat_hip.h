@@ -48,10 +48,13 @@ typedef struct {
     int32_t octave, class_id;
 } xfh_keypoint;
 
-/* BatchNorm behaviour.  BATCH_STATS reproduces the reference (the module is never put in
- * eval(), so every BasicLayer normalises with the statistics of the current frame --
- * SURVEY.md Q1).  Statistics are always per frame, also in batched calls. */
-enum { XFH_BN_BATCH_STATS = 0 };
+/* BatchNorm behaviour.  BATCH_STATS (default) reproduces the reference: the module is never put in
+ * eval(), so every BasicLayer normalises with the statistics of the current frame;
+ * statistics are always per frame, also in batched calls.  RUNNING_STATS is the upstream-XFeat
+ * eval() behaviour: the running_mean / running_var buffers of the weight file are used instead (the
+ * blob must carry them, otherwise xfh_load_weights returns XFH_ERR_BAD_WEIGHTS); the InstanceNorm of
+ * the input image is per frame in both modes. */
+enum { XFH_BN_BATCH_STATS = 0, XFH_BN_RUNNING_STATS = 1 };
 
 typedef struct {
     int32_t device;        /* HIP device ordinal                                              */

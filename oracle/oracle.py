@@ -42,6 +42,7 @@ def lib():
         L.xfo_create.restype = C.c_void_p
         L.xfo_create.argtypes = [C.c_void_p, C.c_size_t]
         L.xfo_destroy.argtypes = [C.c_void_p]
+        L.xfo_set_bn_mode.argtypes = [C.c_void_p, C.c_int]
         L.xfo_set_threads.argtypes = [C.c_int]
         L.xfo_get_threads.restype = C.c_int
         L.xfo_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -67,11 +68,13 @@ def get_threads() -> int:
 class Oracle:
     """CPU restatement of XFextractor::operator() (reference src/XFextractor.cc:250-356)."""
 
-    def __init__(self, blob: bytes):
+    def __init__(self, blob: bytes, bn_mode: int = 0):
         self._blob = blob
         self._h = lib().xfo_create(blob, len(blob))
         if not self._h:
             raise RuntimeError("oracle: bad weight blob")
+        if lib().xfo_set_bn_mode(self._h, bn_mode) != 0:
+            raise RuntimeError("oracle: blob has no BatchNorm running statistics")
 
     def __del__(self):
         if getattr(self, "_h", None):

@@ -29,55 +29,58 @@ def _t(w):
     return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in w.items()}
 
 
-def _basic(x, w, ks, stride, taps, name):
+def _basic(x, w, ks, stride, taps, name, bn=None):
     # BasicLayerImpl (XFeat.cc:7-28): Conv2d(bias=False) -> BatchNorm2d(affine=False) -> ReLU.
     # The module is never put in eval() => training=True, batch statistics.
     x = F.conv2d(x, w, None, stride=stride, padding=ks // 2, dilation=1)
     if taps is not None:
         taps[name] = x
-    x = F.batch_norm(x, None, None, None, None, True, 0.1, 1e-5)
+    if bn is None:
+        x = F.batch_norm(x, None, None, None, None, True, 0.1, 1e-5)
+    else:       # eval() semantics of upstream XFeat (not what the reference does): running statistics
+        x = F.batch_norm(x, bn[name + ".layer.1.running_mean"], bn[name + ".layer.1.running_var"], None, None, False, 0.1, 1e-5)
     return F.relu(x)
 
 
-def _seq(x, w, block, taps):
+def _seq(x, w, block, taps, bn=None):
     for i, (ks, st) in enumerate(_BLOCKS[block]):
-        x = _basic(x, w[f"{block}.{i}.layer.0.weight"], ks, st, taps, f"{block}.{i}")
+        x = _basic(x, w[f"{block}.{i}.layer.0.weight"], ks, st, taps, f"{block}.{i}", bn)
     return x
 
 
-def model_forward(x, w, taps=None):
+def model_forward(x, w, taps=None, bn=None):
     """XFeatModel::forward (XFeat.cc:135-173). x: [1,1,H,W] float."""
     with torch.no_grad():
         x = x.mean(1, True)                                                      # :148
         x = F.instance_norm(x, None, None, None, None, True, 0.1, 1e-5)          # :149
         if taps is not None:
             taps["xhat"] = x
-        x1 = _seq(x, w, "block1", taps)                                          # :152
+        x1 = _seq(x, w, "block1", taps, bn)                                          # :152
         skip = F.conv2d(F.avg_pool2d(x, 4, 4), w["skip1.1.weight"], w["skip1.1.bias"])   # :36-39
-        x2 = _seq(x1 + skip, w, "block2", taps)                                  # :153
-        x3 = _seq(x2, w, "block3", taps)                                         # :154
-        x4 = _seq(x3, w, "block4", taps)                                         # :155
-        x5 = _seq(x4, w, "block5", taps)                                         # :156
+        x2 = _seq(x1 + skip, w, "block2", taps, bn)                                  # :153
+        x3 = _seq(x2, w, "block3", taps, bn)                                         # :154
+        x4 = _seq(x3, w, "block4", taps, bn)                                         # :155
+        x5 = _seq(x4, w, "block5", taps, bn)                                         # :156
         size = [x3.size(2), x3.size(3)]
         x4 = F.interpolate(x4, size=size, mode="bilinear", align_corners=False)  # :159-161
         x5 = F.interpolate(x5, size=size, mode="bilinear", align_corners=False)  # :162-164
         f = x3 + x4 + x5
         if taps is not None:
             taps["fuse_in"] = f
-        f = _basic(f, w["block_fusion.0.layer.0.weight"], 3, 1, taps, "block_fusion.0")
-        f = _basic(f, w["block_fusion.1.layer.0.weight"], 3, 1, taps, "block_fusion.1")
+        f = _basic(f, w["block_fusion.0.layer.0.weight"], 3, 1, taps, "block_fusion.0", bn)
+        f = _basic(f, w["block_fusion.1.layer.0.weight"], 3, 1, taps, "block_fusion.1", bn)
         feats = F.conv2d(f, w["block_fusion.2.weight"], w["block_fusion.2.bias"])  # :166
-        h = _basic(feats, w["heatmap_head.0.layer.0.weight"], 1, 1, taps, "heatmap_head.0")
-        h = _basic(h, w["heatmap_head.1.layer.0.weight"], 1, 1, taps, "heatmap_head.1")
+        h = _basic(feats, w["heatmap_head.0.layer.0.weight"], 1, 1, taps, "heatmap_head.0", bn)
+        h = _basic(h, w["heatmap_head.1.layer.0.weight"], 1, 1, taps, "heatmap_head.1", bn)
         heatmap = torch.sigmoid(F.conv2d(h, w["heatmap_head.2.weight"], w["heatmap_head.2.bias"]))  # :169
         # unfold2d (:124-133)
         B, Cc, H, W = x.shape
         ws = 8
         u = x.unfold(2, ws, ws).unfold(3, ws, ws).reshape(B, Cc, H // ws, W // ws, ws * ws)
         u = u.permute(0, 1, 4, 2, 3).reshape(B, -1, H // ws, W // ws)
-        k = _basic(u, w["keypoint_head.0.layer.0.weight"], 1, 1, taps, "keypoint_head.0")
-        k = _basic(k, w["keypoint_head.1.layer.0.weight"], 1, 1, taps, "keypoint_head.1")
-        k = _basic(k, w["keypoint_head.2.layer.0.weight"], 1, 1, taps, "keypoint_head.2")
+        k = _basic(u, w["keypoint_head.0.layer.0.weight"], 1, 1, taps, "keypoint_head.0", bn)
+        k = _basic(k, w["keypoint_head.1.layer.0.weight"], 1, 1, taps, "keypoint_head.1", bn)
+        k = _basic(k, w["keypoint_head.2.layer.0.weight"], 1, 1, taps, "keypoint_head.2", bn)
         keypoints = F.conv2d(k, w["keypoint_head.3.weight"], w["keypoint_head.3.bias"])  # :170
     return feats, keypoints, heatmap
 
@@ -95,7 +98,7 @@ def _interp(x, pos, H, W, mode):
     return x.permute(0, 2, 3, 1).squeeze(-2)
 
 
-def extract(gray: np.ndarray, weights, nfeatures: int = 4096, lapping=(0, 0), taps=None):
+def extract(gray: np.ndarray, weights, nfeatures: int = 4096, lapping=(0, 0), taps=None, eval_mode: bool = False):
     """XFextractor::operator() (XFextractor.cc:250-356).  Returns
     (kps[nfeatures] structured, desc[nfeatures,64], n_valid, mono_index)."""
     from .oracle import KP_DTYPE
@@ -110,7 +113,7 @@ def extract(gray: np.ndarray, weights, nfeatures: int = 4096, lapping=(0, 0), ta
         x = F.interpolate(x, size=[_H, _W], mode="bilinear", align_corners=False)   # :198-200
         if taps is not None:
             taps["x"] = x
-        M1, K1, H1 = model_forward(x, w, taps)                                       # :268
+        M1, K1, H1 = model_forward(x, w, taps, w if eval_mode else None)             # :268
         M1 = F.normalize(M1, dim=1)                                                  # :273
         # getKptsHeatmap (:204-217)
         scores = F.softmax(K1 * 1.0, 1)[:, :64]

@@ -45,6 +45,8 @@ struct xfo_ctx {
     float* fus2_w; float fus2_b[64];    /* [ci][co] */
     float heat2_w[64]; float heat2_b;
     float* kp3_w; float kp3_b[65];      /* [ci][65] */
+    float* bn_stat[XFO_NUM_LAYERS];     /* optional running statistics as (mean[C], rstd[C]) */
+    int bn_mode;                        /* 0 = batch statistics (the reference), 1 = running statistics */
     /* intermediates of the last call */
     int H, W;                           /* after resize */
     float* t[128]; int64_t tn[128];
@@ -105,6 +107,19 @@ xfo_ctx* xfo_create(const void* blob, size_t nbytes) {
         const float* w = blob_find(blob, nbytes, nm, d);
         if (!w || (int)d[0] != LAYERS[i].cout || (int)d[1] != LAYERS[i].cin) { xfo_destroy(c); return NULL; }
         c->w[i] = repack(w, LAYERS[i].cout, LAYERS[i].cin, LAYERS[i].ks);
+        /* optional BatchNorm running statistics (eval() semantics of upstream XFeat) */
+        char n2[80]; uint32_t dm[4], dv[4];
+        snprintf(nm, sizeof nm, "%s.layer.1.running_mean", LAYERS[i].name);
+        snprintf(n2, sizeof n2, "%s.layer.1.running_var", LAYERS[i].name);
+        const float* rm = blob_find(blob, nbytes, nm, dm);
+        const float* rv = blob_find(blob, nbytes, n2, dv);
+        if (rm && rv && (int)dm[0] == LAYERS[i].cout && (int)dv[0] == LAYERS[i].cout) {
+            c->bn_stat[i] = (float*)malloc(sizeof(float) * 2 * LAYERS[i].cout);
+            for (int ch = 0; ch < LAYERS[i].cout; ++ch) {
+                c->bn_stat[i][ch] = rm[ch];
+                c->bn_stat[i][LAYERS[i].cout + ch] = (float)(1.0 / sqrt((double)rv[ch] + 1e-5));
+            }
+        }
     }
     const float* p;
     if (!(p = blob_find(blob, nbytes, "skip1.1.weight", d))) { xfo_destroy(c); return NULL; }
@@ -131,7 +146,7 @@ static void free_tensors(xfo_ctx* c) {
 }
 void xfo_destroy(xfo_ctx* c) {
     if (!c) return;
-    for (int i = 0; i < XFO_NUM_LAYERS; ++i) free(c->w[i]);
+    for (int i = 0; i < XFO_NUM_LAYERS; ++i) { free(c->w[i]); free(c->bn_stat[i]); }
     free(c->fus2_w); free(c->kp3_w);
     free_tensors(c);
     free(c);
@@ -141,6 +156,11 @@ static float* talloc(xfo_ctx* c, int id, int64_t n) {
     c->t[id] = (float*)calloc((size_t)(n > 0 ? n : 1), sizeof(float));
     c->tn[id] = n;
     return c->t[id];
+}
+int xfo_set_bn_mode(xfo_ctx* c, int mode) {
+    if (mode == 1) for (int i = 0; i < XFO_NUM_LAYERS; ++i) if (!c->bn_stat[i]) return -1;
+    c->bn_mode = mode;
+    return 0;
 }
 int xfo_get_tensor(xfo_ctx* c, int id, const float** ptr, int64_t* count) {
     if (id < 0 || id >= 128 || !c->t[id]) return -1;
@@ -315,7 +335,8 @@ static float* basic_layer(xfo_ctx* c, int li, const float* in, int Hi, int Wi, i
     float* raw = talloc(c, XFO_T_RAW0 + li, n * L->cout);
     conv_nhwc(in, Hi, Wi, L->cin, c->w[li], L->cout, L->ks, L->stride, raw, *Ho, *Wo);
     float* st = talloc(c, XFO_T_STAT0 + li, 2 * L->cout);
-    batch_stats(raw, n, L->cout, st);
+    if (c->bn_mode == 1 && c->bn_stat[li]) memcpy(st, c->bn_stat[li], sizeof(float) * 2 * L->cout);
+    else batch_stats(raw, n, L->cout, st);
     float* act = (float*)malloc(sizeof(float) * (size_t)n * L->cout);
     bn_relu(raw, n, L->cout, st, act);
     return act;

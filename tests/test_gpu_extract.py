@@ -164,3 +164,26 @@ def test_extract_to_match_device_resident(gpu_lib, oracle_mod, weights_dense):
     sel = np.isin(i1, valid)
     assert np.all(np.nan_to_num(dd[sel], nan=0.0) < 1e-3)
     ctx.close()
+
+
+def test_running_stats_mode(gpu_lib, oracle_mod):
+    """XFH_BN_RUNNING_STATS (upstream-XFeat eval() semantics) against the oracle in the same mode"""
+    from xfeatslam_amd.extractor import Context
+    w = WT.make_synthetic(1234, 6.0, with_bn=True)
+    blob = WT.pack_blob(w)
+    fr = synth.frames(2, 160, 224, seed=5)
+    ctx = Context(nfeatures=512, max_height=160, max_width=224, max_batch=2, bn_mode=1)
+    ctx.load_weights(blob)
+    recs = ctx.extract_batch(fr, (0, 100))
+    orc = oracle_mod.Oracle(blob, bn_mode=1)
+    for b in range(2):
+        ok, od, onv, omono = orc.extract(fr[b], 512, (0, 100))
+        hk, hd, hnv, hmono, _ = recs[b]
+        assert (hnv, hmono) == (onv, omono) and kp_set(hk) == kp_set(ok)
+        dd, ds, n = joined_desc_diff(hk, hd, ok, od)
+        assert n == onv and dd < DESC_TOL
+    # the two modes really differ, and a blob without running statistics is refused in this mode
+    ok0, _, _, _ = oracle_mod.Oracle(blob, bn_mode=0).extract(fr[0], 512, (0, 100))
+    assert kp_set(ok0) != kp_set(recs[0][0])
+    assert gpu_lib.xfh_load_weights(ctx.h, WT.pack_blob(WT.make_synthetic(1234, 6.0)), len(WT.pack_blob(WT.make_synthetic(1234, 6.0)))) == 5
+    ctx.close()

@@ -76,6 +76,7 @@ int xfh_create(const xfh_config* cfg, xfh_ctx** out) {
     *out = nullptr;
     if (cfg->max_height < 32 || cfg->max_width < 32 || cfg->nfeatures < 1 || cfg->nfeatures > 65536 || cfg->max_batch < 1)
         return XFH_ERR_INVALID_ARG;
+    if (cfg->bn_mode != XFH_BN_BATCH_STATS && cfg->bn_mode != XFH_BN_RUNNING_STATS) return XFH_ERR_INVALID_ARG;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return XFH_ERR_NO_DEVICE;
     if (cfg->device < 0 || cfg->device >= ndev) return XFH_ERR_NO_DEVICE;
@@ -217,6 +218,22 @@ int xfh_load_weights(xfh_ctx* c, const void* blob, size_t nbytes) {
                 rc = upload(c, &c->w.mfma32[i], pack_mfma(e.p, L.cout, L.cin, L.ks, coutp, 32));
         }
         if (rc != XFH_OK) return rc;
+        if (c->cfg.bn_mode == XFH_BN_RUNNING_STATS) {
+            // eval() semantics: (running_mean, 1/sqrt(running_var + eps)) replace the per-frame statistics;
+            // written once for every frame slot, k_bn_finalize is then never launched
+            BlobEntry em, ev; char n2[80];
+            snprintf(nm, sizeof nm, "%s.layer.1.running_mean", L.name);
+            snprintf(n2, sizeof n2, "%s.layer.1.running_var", L.name);
+            if (!blob_find(blob, nbytes, nm, &em) || !blob_find(blob, nbytes, n2, &ev) || (int)em.dims[0] != L.cout || (int)ev.dims[0] != L.cout)
+                return XFH_ERR_BAD_WEIGHTS;
+            std::vector<float> st((size_t)c->cfg.max_batch * 2 * L.cout);
+            for (int b = 0; b < c->cfg.max_batch; ++b)
+                for (int ch = 0; ch < L.cout; ++ch) {
+                    st[(size_t)b * 2 * L.cout + ch] = em.p[ch];
+                    st[(size_t)b * 2 * L.cout + L.cout + ch] = (float)(1.0 / sqrt((double)ev.p[ch] + 1e-5));
+                }
+            HIPCK(c, hipMemcpy(c->stat[i], st.data(), st.size() * sizeof(float), hipMemcpyHostToDevice));
+        }
     }
     int rc;
     if (!blob_find(blob, nbytes, "block_fusion.2.weight", &e) || e.dims[0] != 64 || e.dims[1] != 64) return XFH_ERR_BAD_WEIGHTS;

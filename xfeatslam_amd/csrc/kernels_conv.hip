@@ -455,6 +455,7 @@ hipError_t launch_basic_layer(xfh_ctx* c, int li, const float* in, size_t in_str
     (void)bn;
     if (e != hipSuccess) return e;
     c->npart[li] = np;
+    if (c->cfg.bn_mode == XFH_BN_RUNNING_STATS) return hipGetLastError();       // statistics come from the weight file
     hipLaunchKernelGGL(k_bn_finalize, dim3(B), dim3(256), 0, c->stream, (const double*)c->part[li], c->part_stride[li], np,
                        L.cout, (double)Hout * (double)Wout, c->stat[li]);
     return hipGetLastError();

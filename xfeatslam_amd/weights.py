@@ -61,6 +61,12 @@ TENSORS = [
 ]
 N_PARAMS = sum(int(np.prod(s)) for _, s in TENSORS)  # 657 910
 
+# Optional tensors: BatchNorm running statistics of the 23 BasicLayers.  They do not influence the
+# reference's output (it normalises with batch statistics); they are only needed for
+# the XFH_BN_RUNNING_STATS mode (upstream-XFeat eval() semantics).
+BN_LAYERS = [n[:-len(".layer.0.weight")] for n, _ in TENSORS if n.endswith(".layer.0.weight")]
+BN_TENSORS = [(f"{l}.layer.1.{k}", (dict(TENSORS)[f"{l}.layer.0.weight"][0],)) for l in BN_LAYERS for k in ("running_mean", "running_var")]
+
 _M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
 
 
@@ -83,7 +89,7 @@ def uniform01(seed: int, stream: int, n: int) -> np.ndarray:
     return bits.astype(np.float64) * (1.0 / 9007199254740992.0)
 
 
-def make_synthetic(seed: int = 1234, kp_logit_gain: float = 1.0) -> "OrderedDict[str, np.ndarray]":
+def make_synthetic(seed: int = 1234, kp_logit_gain: float = 1.0, with_bn: bool = False) -> "OrderedDict[str, np.ndarray]":
     """Deterministic stand-in for the absent `weights/xfeat.pt`.
 
     conv weights/biases ~ U(-1/sqrt(fan_in), +1/sqrt(fan_in)) (the libtorch Conv2d default
@@ -104,6 +110,11 @@ def make_synthetic(seed: int = 1234, kp_logit_gain: float = 1.0) -> "OrderedDict
         if name == "keypoint_head.3.weight":
             w = (w * np.float32(kp_logit_gain)).astype(np.float32)
         out[name] = w
+    if with_bn:
+        # plausible running statistics of a post-conv activation: mean ~ U(-0.5, 0.5), var ~ U(0.5, 1.5)
+        for j, (name, shape) in enumerate(BN_TENSORS):
+            u = uniform01(seed, 1000 + j, shape[0])
+            out[name] = ((u - 0.5) if name.endswith("mean") else (0.5 + u)).astype(np.float32)
     return out
 
 
@@ -111,7 +122,10 @@ def pack_blob(weights: "dict[str, np.ndarray]") -> bytes:
     entries = []
     data = []
     off = 0
-    for name, shape in TENSORS:
+    table = list(TENSORS)
+    if all(n in weights for n, _ in BN_TENSORS):
+        table += BN_TENSORS
+    for name, shape in table:
         a = np.ascontiguousarray(weights[name], dtype=np.float32)
         if tuple(a.shape) != tuple(shape):
             raise ValueError(f"{name}: shape {a.shape} != {shape}")
@@ -119,7 +133,7 @@ def pack_blob(weights: "dict[str, np.ndarray]") -> bytes:
         entries.append(struct.pack("<48sI4IQ", name.encode(), len(shape), *dims, off))
         data.append(a.tobytes())
         off += a.size
-    head = MAGIC + struct.pack("<II", len(TENSORS), 0)
+    head = MAGIC + struct.pack("<II", len(table), 0)
     return head + b"".join(entries) + b"".join(data)
 
 
@@ -154,4 +168,13 @@ def from_state_dict(sd) -> "OrderedDict[str, np.ndarray]":
             raise KeyError(name)
         a = np.asarray(src.detach().cpu().numpy() if hasattr(src, "detach") else src, dtype=np.float32)
         out[name] = a.reshape(shape)
+    for name, shape in BN_TENSORS:                      # optional: only if every one is present
+        for k in (name, "net." + name):
+            if k in sd:
+                src = sd[k]
+                out[name] = np.asarray(src.detach().cpu().numpy() if hasattr(src, "detach") else src, dtype=np.float32).reshape(shape)
+                break
+    if not all(n in out for n, _ in BN_TENSORS):
+        for n, _ in BN_TENSORS:
+            out.pop(n, None)
     return out
