@@ -50,6 +50,13 @@ struct Mat {
     std::vector<unsigned char> store;
     Mat() = default;
     Mat(int r, int c, int elem_bytes) { create(r, c, elem_bytes); }
+    Mat(const Mat& o) { *this = o; }
+    Mat& operator=(const Mat& o) {                       // deep copy; `data` must follow `store`
+        if (this == &o) return *this;
+        rows = o.rows; cols = o.cols; elem = o.elem; step = o.step; store = o.store;
+        data = o.data ? (o.store.empty() ? o.data : store.data()) : nullptr;
+        return *this;
+    }
     void create(int r, int c, int elem_bytes) {
         rows = r; cols = c; elem = elem_bytes; step = (size_t)c * elem_bytes;
         store.assign((size_t)r * step, 0); data = store.data();

@@ -39,3 +39,25 @@ def test_cpp_dropin_end_to_end(gpu_lib, oracle_mod, tmp_path):
     assert n == onv and dd < 1e-4
     a = oracle_mod.match_mnn(desc, desc)
     assert np.array_equal(a[0], m["q"]) and np.array_equal(a[1], m["t"])
+
+
+def test_frontend_replay_example(gpu_lib, tmp_path):
+    """examples/frontend_replay.cpp (shaped after rgbd_tum.cc): extract + match against the previous frame"""
+    exe = str(tmp_path / "frontend_replay")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "frontend_replay.cpp"),
+                           "-L" + os.path.join(ROOT, "xfeatslam_amd"), "-lxfeat_hip", "-Wl,-rpath," + os.path.join(ROOT, "xfeatslam_amd"),
+                           "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    (tmp_path / "w.xfhw").write_bytes(WT.pack_blob(WT.make_synthetic(1234, 6.0)))
+    # PGM sequence + TUM-style association list
+    os.makedirs(tmp_path / "rgb")
+    lines = []
+    for i in range(4):
+        img = synth.image(96, 128, 20 + i)
+        with open(tmp_path / "rgb" / f"{i}.pgm", "wb") as f:
+            f.write(b"P5\n# frame\n128 96\n255\n" + img.tobytes())
+        lines.append(f"{i}.0 rgb/{i}.pgm {i}.0 depth/{i}.png")
+    (tmp_path / "assoc.txt").write_text("\n".join(lines) + "\n")
+    for args in ([str(tmp_path / "assoc.txt"), str(tmp_path)], ["--synthetic", "5", "128", "160"]):
+        r = subprocess.run([exe, str(tmp_path / "w.xfhw")] + args, capture_output=True, text=True, env=dict(os.environ, XFH_NFEATURES="300"))
+        assert r.returncode == 0, r.stderr
+        assert "median front-end time" in r.stdout and "keypoints/frame" in r.stdout
