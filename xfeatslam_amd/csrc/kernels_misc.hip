@@ -43,9 +43,10 @@ __device__ __forceinline__ float grid_coord(int pos, int full, int size) {
 // grid (ceil(H*W/1024), 1, B), 256 threads, 4 consecutive pixels per thread.
 __global__ __launch_bounds__(256)
 void k_preproc(const uint8_t* __restrict__ gray, size_t gray_stride, int H0, int W0, int H, int W,
-               float* __restrict__ X, size_t x_stride, double* __restrict__ part, int npart) {
+               float* __restrict__ X, size_t x_stride, double* __restrict__ part, int npart, int* __restrict__ cand_count) {
     __shared__ double red[8];
     const int t = threadIdx.x, b = blockIdx.z;
+    if (blockIdx.x == 0 && t == 0) cand_count[b * CAND_CNT_STRIDE] = 0;     // consumed by k_nms_score much later in the stream
     const uint8_t* g = gray + (size_t)b * gray_stride;
     const int p0 = (blockIdx.x * 256 + t) * 4;
     double s = 0.0, ss = 0.0;
@@ -669,10 +670,9 @@ hipError_t run_extract(xfh_ctx* c, const uint8_t* d_gray, int B, int H0, int W0,
     const int nf = c->cfg.nfeatures;
     const size_t rec = xfh_record_bytes(nf);
 
-    CK(hipMemsetAsync(c->cand_count, 0, sizeof(int) * B * CAND_CNT_STRIDE, s));
     // image -> float, resize, InstanceNorm statistics
     const int npre = (H * W + 1023) / 1024;
-    launch_k(c, XFH_K_PREPROC, -1, k_preproc, dim3(npre, 1, B), dim3(256), 0, d_gray, (size_t)H0 * W0, H0, W0, H, W, c->X, xs, c->pre_part, c->pre_npart);
+    launch_k(c, XFH_K_PREPROC, -1, k_preproc, dim3(npre, 1, B), dim3(256), 0, d_gray, (size_t)H0 * W0, H0, W0, H, W, c->X, xs, c->pre_part, c->pre_npart, c->cand_count);
     CK(hipGetLastError());
     CK(launch_finalize_image(c, B, npre, (double)H * (double)W));
     hipLaunchKernelGGL(k_norm_aux, dim3((h4 * w4 + 255) / 256, 1, B), dim3(256), 0, s, c->X, xs, c->xstat, H, W,
