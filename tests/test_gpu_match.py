@@ -73,6 +73,31 @@ def test_mnn_edge_cases(mctx, oracle_mod):
     assert all(got.get(k) == inv[k] for k in ok)
 
 
+@pytest.mark.parametrize("n1,n2", [(700, 900), (4096, 4096), (130, 260)])
+def test_mnn_ties_across_candidate_groups(mctx, oracle_mod, n1, n2):
+    """The kernel keeps value maxima per group of 4 d2 rows / 16 d1 rows and names the member afterwards
+    (k_mnn_fix).  Duplicated descriptors give exact ties inside a group, across neighbouring groups,
+    across 128/256-row tiles and across workgroups; the first index must win on both axes."""
+    rs = np.random.RandomState(n1 + n2)
+    d1, d2 = synth.descriptor_sets(n1, n2, noise=0.25)
+    for src, dsts in [(3, (1, 2)), (5, (7, 9, 300)), (64, (65, 80, 127)), (17, (n2 - 1,)), (255, (256, 257, 511 % n2))]:
+        for d in dsts:
+            d2[d % n2] = d2[src % n2]
+    for src, dsts in [(2, (0,)), (20, (21, 35)), (15, (16, 31)), (100, (n1 - 1,)), (127, (128,))]:
+        for d in dsts:
+            d1[d % n1] = d1[src % n1]
+    k = min(n1, n2) // 3
+    d2[rs.randint(0, n2, k)] = d2[rs.randint(0, n2, k)]      # many random duplicates on top
+    d1[rs.randint(0, n1, k)] = d1[rs.randint(0, n1, k)]
+    a = oracle_mod.match_mnn(d1, d2); b = mctx.match_mnn(d1, d2)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert np.array_equal(a[2], b[2], equal_nan=True)
+    # all rows identical: every dot product ties, (0, 0) is the only mutual pair
+    e = np.tile(d1[:1], (300, 1))
+    i1, i2, _ = mctx.match_mnn(e, e[:200])
+    assert i1.tolist() == [0] and i2.tolist() == [0]
+
+
 def test_distance_i32_exact(mctx, oracle_mod):
     for n1, n2, z in [(512, 384, 0), (70, 33, 3), (1, 1, 0), (64, 65, 0)]:
         d1, d2 = synth.descriptor_sets(n1, n2, noise=0.3, zero_rows=z)

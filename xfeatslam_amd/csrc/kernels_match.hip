@@ -1,16 +1,20 @@
 // kernels_match.hip -- descriptor matching on gfx950.
 //
-//   k_mnn_gemm    : cosine-similarity GEMM (N1 x 64) . (64 x N2) on v_mfma_f32_32x32x2_f32 with
-//                   the row L2-normalisation fused into the tile load and the row / column
-//                   arg-max fused into the epilogue (reference: the commented-out
-//                   ORBmatcher::match, src/ORBmatcher.cc:358-368).
-//   k_mnn_final   : mutual check, min_cossim gate, ordered compaction, distances (:371-403).
+//   k_rownorm     : F::normalize of both descriptor sets (ORBmatcher.cc:358-359), stored k-permuted.
+//   k_mnn_gemm    : cosine-similarity GEMM (N1 x 64) . (64 x N2) on v_mfma_f32_32x32x2_f32 with the
+//                   first level of the row / column arg-max (:363-368) fused into the epilogue:
+//                   value maxima over small index groups, merged with 64-bit atomic max.
+//   k_mnn_fix     : second level: names the member of the winning group by recomputing its few dot
+//                   products bit-identically, and does the mutual check (:372) + min_cossim gate.
+//   k_mnn_final   : ordered compaction and distances (:371-403).
 //   k_dist_i32    : dense (int)(512 * ||a-b||^2), ORBmatcher::DescriptorDistance (:2246-2247).
+//   k_best2_csr   : best / second-best distance over candidate lists (the SearchBy* inner loop, :75-119).
 //
 // Numerics: normalised rows and the 64-term dot products are bit-identical to the oracle
 // (fp64 sum of squares -> fp32 sqrt/max/div; one fp32 fma chain in k order, which is what
-// the f32 MFMA computes), so the arg-max decisions including ties agree by construction.
-// Ties resolve to the lowest index through the packed key (ordered(value) << 32 | ~index).
+// the f32 MFMA computes), so the arg-max decisions including ties agree by construction:
+// ties resolve to the lowest index (packed key ordered(value) << 32 | ~group, then the first
+// member of the group that reaches the value).
 #include "ctx.h"
 #include <utility>
 #include <stdlib.h>
@@ -59,30 +63,37 @@ __device__ __forceinline__ void bfly_step(u64 (&k)[N], bool up, std::integer_seq
     ((k[Q] = umax64(up ? k[Q + S] : k[Q], __shfl_xor(up ? k[Q] : k[Q + S], S))), ...);
 }
 
-template <int... Q>
-__device__ __forceinline__ void pack_rows(u64 (&rk)[32], const float (&rbv)[32], const int (&rbc)[32], std::integer_sequence<int, Q...>) {
-    ((rk[Q] = (rbv[Q] > -__builtin_huge_valf()) ? pack_key(rbv[Q], (unsigned)rbc[Q]) : 0ull), ...);
-}
-
-// k_mnn_gemm: one workgroup = 128 rows of d1 against TPW = 2 consecutive 128-row blocks of d2.
-//   - the second d2 block is prefetched into registers while the first one is on the MFMAs, so
+// k_mnn_gemm: one workgroup = 128 rows of d1 against one block of TPW*128 = 256 rows of d2.
+//   - the second d2 tile is prefetched into registers while the first one is on the MFMAs, so
 //     only the first global load of a workgroup is exposed;
-//   - grid = (ceil(nbC/2), nbR): 512 workgroups at 4096 x 4096, all resident at 2 per CU;
-//   - per tile, every wave owns 64 x 64 outputs as 2 x 2 MFMA tiles (four independent chains);
-//   - column arg-max (over rows) is lane-local in the C/D layout; the row arg-max is carried
-//     lane-locally across both tiles (value + column per row slot) and reduced across lanes ONCE
-//     at the end with a packed-key butterfly.
-// Measured on gfx950 (tools/probes/mfma_probe.hip, profiles/r01_gemm_notes.md): the f32 MFMA and
-// the ordinary VALU instructions of a SIMD do not overlap -- every epilogue instruction costs
-// matrix time -- which is why the arg-max is kept at 3 VALU per value and direction.  Variants
-// with the epilogue interleaved between MFMAs, 8-wave and persistent 4-tile workgroups were
-// measured slower (DESIGN.md "Match kernel: what was tried").
+//   - grid = (ceil(n2/256), ceil(n1/128)): 512 workgroups at 4096 x 4096, all resident at 2 per CU;
+//   - per tile, every wave owns 64 x 64 outputs as 2 x 2 MFMA tiles (four independent chains).
+//
+// Two-level exact arg-max.  On gfx950 the f32 MFMA and the ordinary VALU instructions of a SIMD
+// do not overlap (tools/probes/mfma_probe.hip), so every epilogue instruction costs matrix time;
+// carrying an index next to every running maximum (compare + two selects per value and direction)
+// held the previous kernel at 50 % of the MFMA peak.  Here the epilogue only takes VALUE maxima
+// (v_max3_f32: half an instruction per value and direction) over small candidate groups that are
+// fixed by the lane / wave position:
+//     row i of d1   -> best value over the 4 consecutive d2 rows   4*gc .. 4*gc+3   (gc: column group)
+//     row j of d2   -> best value over the 16 consecutive d1 rows 16*gr .. 16*gr+15 (gr: row group)
+// and merges (value, group) keys with 64-bit atomic max (order independent => deterministic).  The
+// d1 / d2 rows are assigned to MFMA rows / columns through a permutation of the LDS tile rows such
+// that every lane's candidates are consecutive and the groups ascend with the index, so "largest
+// value, then lowest group, then first member equal to that value" is exactly "first index of the
+// maximum".  k_mnn_fix recomputes the few candidate dot products (same fp32 fma chain in k order as
+// the MFMA, hence the same bits) to name the member.
+//
+// Tile-row permutations (block-local indices):
+//     d1: MFMA row  wr*64 + rt*32 + (r&3) + 8*(r>>2) + 4h   <->  d1 row  wr*64 + h*32 + rt*16 + r
+//     d2: MFMA col  wc*64 + ct*32 + i  of tile `tile`       <->  d2 row  i*8 + wc*4 + tile*2 + ct
 #define TPW 2
+#define MNN_NC 4        // candidates per d1 row (see k_mnn_fix)
+#define TLD 68          // row stride (floats) of the per-wave transposition scratch
 __global__ __launch_bounds__(256, 2)
 void k_mnn_gemm(const float* __restrict__ d1, int n1, const float* __restrict__ d2, int n2,
-                u64* __restrict__ bestR, u64* __restrict__ bestC, int nbC) {
-    // d1/d2: normalised, k-permuted rows from k_rownorm; bestR/bestC: packed arg-max keys, merged with
-    // 64-bit atomic max (order independent, so the result is deterministic)
+                u64* __restrict__ bestR, u64* __restrict__ bestC) {
+    // d1/d2: normalised, k-permuted rows from k_rownorm; bestR/bestC: packed (value, group) keys
     __shared__ __attribute__((aligned(16))) float smem[2 * MT * LDK + 2 * 4 * 64 * 2];
     float* sA = smem;
     float* sB = smem + MT * LDK;
@@ -91,15 +102,24 @@ void k_mnn_gemm(const float* __restrict__ d1, int n1, const float* __restrict__ 
     const int t = threadIdx.x;
     const int bx2 = blockIdx.x, by = blockIdx.y;
     const int sub = t & 15, r0 = t >> 4;
-    const bool has_b1 = bx2 * 2 + 1 < nbC;
+    const int row_base = by * MT, col_base = bx2 * (TPW * MT);
+    // staging: thread (r0 = t>>4, sub = t&15) moves 16 bytes of tile row rho = p*16 + r0, p = 0..7.  With the
+    // permutations above the global row splits into a per-thread part and a compile-time part of p:
+    //   d1 row = row_base + [((r0>>2)&1)*32 + (r0&3) + 4*(r0>>3)] + [(p>>2)*64 + ((p>>1)&1)*16 + (p&1)*8]
+    //   d2 row = col_base + [r0*8] + [(p&1)*128 + (p>>2)*4 + ((p>>1)&1) + tile*2]
+    const bool full = (row_base + MT <= n1) && (col_base + TPW * MT <= n2);      // block-uniform
+    const int ra0 = row_base + ((r0 >> 2) & 1) * 32 + (r0 & 3) + 4 * (r0 >> 3), rb0 = col_base + r0 * 8;
+    const float* gA = d1 + (size_t)ra0 * 64 + sub * 4;
+    const float* gB = d2 + (size_t)rb0 * 64 + sub * 4;
+    const f32x4 Z4 = {0.f, 0.f, 0.f, 0.f};
     f32x4 vb[8];
     {
         f32x4 va[8];
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
-            const int ra = by * MT + p * 16 + r0, rb = bx2 * 2 * MT + p * 16 + r0;
-            va[p] = (ra < n1) ? *(const f32x4*)(d1 + (size_t)ra * 64 + sub * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-            vb[p] = (rb < n2) ? *(const f32x4*)(d2 + (size_t)rb * 64 + sub * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const int ca = (p >> 2) * 64 + ((p >> 1) & 1) * 16 + (p & 1) * 8, cb = (p & 1) * 128 + (p >> 2) * 4 + ((p >> 1) & 1);
+            va[p] = (full || ra0 + ca < n1) ? *(const f32x4*)(gA + ca * 64) : Z4;
+            vb[p] = (full || rb0 + cb < n2) ? *(const f32x4*)(gB + cb * 64) : Z4;
         }
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
@@ -108,40 +128,28 @@ void k_mnn_gemm(const float* __restrict__ d1, int n1, const float* __restrict__ 
         }
     }
     __syncthreads();
-    if (has_b1) {
 #pragma unroll
-        for (int p = 0; p < 8; ++p) {
-            const int rb = (bx2 * 2 + 1) * MT + p * 16 + r0;
-            vb[p] = (rb < n2) ? *(const f32x4*)(d2 + (size_t)rb * 64 + sub * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+    for (int p = 0; p < 8; ++p) {                 // tile 1 -> registers
+        const int cb = (p & 1) * 128 + (p >> 2) * 4 + ((p >> 1) & 1) + 2;
+        vb[p] = (full || rb0 + cb < n2) ? *(const f32x4*)(gB + cb * 64) : Z4;
     }
 
     const int wave = t >> 6, lane = t & 63, i = lane & 31, h = lane >> 5;
     const int wr = wave >> 1, wc = wave & 1;
     const float NEG = -__builtin_huge_valf();
-    const int grow0 = by * MT + wr * 64;
     const float* pa = sA + (wr * 64 + i) * LDK + 4 * h;
     const float* pb = sB + (wc * 64 + i) * LDK + 4 * h;
+    const int grow_lane = row_base + wr * 64 + h * 32;        // + rt*16 + r
+    const f32x16 Z16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
-    // running row best of this lane: slot q = rt*16 + r  <->  row rt*32 + (r&3) + 8*(r>>2) + 4h
+    // running row maximum of this lane: slot q = rt*16 + r  <->  d1 row grow_lane + q
     float rbv[32];
-    int rbc[32];
 #pragma unroll
-    for (int q = 0; q < 32; ++q) { rbv[q] = NEG; rbc[q] = 0; }
+    for (int q = 0; q < 32; ++q) rbv[q] = NEG;
 
 #pragma unroll
     for (int tile = 0; tile < 2; ++tile) {
-        if (tile == 1 && !has_b1) break;
-        const int bx = bx2 * 2 + tile;
-        const int gcol0 = bx * MT + wc * 64;
-        const bool full = (by * MT + MT <= n1) && (bx * MT + MT <= n2);     // block-uniform
         f32x16 acc[2][2];
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
             const f32x4 a0 = *(const f32x4*)(pa + g * 8);
@@ -150,84 +158,155 @@ void k_mnn_gemm(const float* __restrict__ d1, int n1, const float* __restrict__ 
             const f32x4 b1 = *(const f32x4*)(pb + 32 * LDK + g * 8);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[j], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b1[j], acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b0[j], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1[j], acc[1][1], 0, 0, 0);
+                // the first k step takes the literal zero as C: no accumulator clearing instructions
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[j], (g | j) ? acc[0][0] : Z16, 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b1[j], (g | j) ? acc[0][1] : Z16, 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b0[j], (g | j) ? acc[1][0] : Z16, 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1[j], (g | j) ? acc[1][1] : Z16, 0, 0, 0);
             }
         }
-        // ---- tile epilogue: C/D layout = column (lane&31), rows (r&3) + 8*(r>>2) + 4*(lane>>5)
+        // ---- tile epilogue: acc[rt][ct][r] = <d1 row grow_lane + rt*16 + r, d2 row gcol0 + ct>
+        const int gcol0 = col_base + i * 8 + wc * 4 + tile * 2;
         if (!full) {
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const bool vr = grow0 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h < n1;
+                    const bool vr = grow_lane + rt * 16 + r < n1;
 #pragma unroll
                     for (int ct = 0; ct < 2; ++ct)
-                        if (!(vr && gcol0 + ct * 32 + i < n2)) acc[rt][ct][r] = NEG;
+                        if (!(vr && gcol0 + ct < n2)) acc[rt][ct][r] = NEG;
                 }
         }
-        float cbv[2] = {NEG, NEG};
-        int cbr[2] = {0, 0};
-        const int c0 = gcol0 + i, c1 = gcol0 + 32 + i;
+        // rows: value maximum over this lane's (up to) 4 columns
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int lrow = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const float v0 = acc[rt][0][r], v1 = acc[rt][1][r];
-                // columns: ascending row order + strict '>' keeps the lowest row among equals
-                bool gt = v0 > cbv[0]; cbv[0] = gt ? v0 : cbv[0]; cbr[0] = gt ? lrow : cbr[0];
-                gt = v1 > cbv[1]; cbv[1] = gt ? v1 : cbv[1]; cbr[1] = gt ? lrow : cbr[1];
-                // rows: ascending column order (tile 0 before tile 1, c0 < c1) + strict '>'
                 const int q = rt * 16 + r;
-                gt = v0 > rbv[q]; rbv[q] = gt ? v0 : rbv[q]; rbc[q] = gt ? c0 : rbc[q];
-                gt = v1 > rbv[q]; rbv[q] = gt ? v1 : rbv[q]; rbc[q] = gt ? c1 : rbc[q];
+                rbv[q] = fmaxf(fmaxf(rbv[q], acc[rt][0][r]), acc[rt][1][r]);
             }
+        // columns: value maximum over the 16 rows of each (rt) group, key = (value, row group)
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
-            const u64 k = (cbv[ct] > NEG) ? pack_key(cbv[ct], (unsigned)(grow0 + cbr[ct])) : 0ull;
+            float m[2];
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                m[rt] = acc[rt][ct][0];
+#pragma unroll
+                for (int r = 1; r < 15; r += 2) m[rt] = fmaxf(fmaxf(m[rt], acc[rt][ct][r]), acc[rt][ct][r + 1]);
+                m[rt] = fmaxf(m[rt], acc[rt][ct][15]);
+            }
+            const bool second = m[1] > m[0];                   // tie -> the lower row group
+            const float mm = second ? m[1] : m[0];
+            const unsigned gr = (unsigned)(grow_lane >> 4) + (second ? 1u : 0u);
+            const u64 k = (mm > NEG) ? pack_key(mm, gr) : 0ull;
             const u64 kk = umax64(k, __shfl_xor(k, 32));
             if (lane < 32) sCol[wave * 64 + ct * 32 + lane] = kk;
         }
         __syncthreads();                   // sB is free, column keys are visible
         if (wr == 0) {
             const u64 k = umax64(sCol[wave * 64 + lane], sCol[(wave + 2) * 64 + lane]);
-            if (k) __hip_atomic_fetch_max(bestC + bx * MT + wc * 64 + lane, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int col = col_base + (lane & 31) * 8 + wc * 4 + tile * 2 + (lane >> 5);
+            if (k) __hip_atomic_fetch_max(bestC + col, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (tile == 0 && has_b1) {
+        if (tile == 0) {
 #pragma unroll
             for (int p = 0; p < 8; ++p) *(f32x4*)(sB + (p * 16 + r0) * LDK + sub * 4) = vb[p];
             __syncthreads();
         }
     }
 
-    // ---- rows: one packed-key reduce-scatter over the 32 lanes of each half --------------
-    u64 rk[32];
-    pack_rows(rk, rbv, rbc, std::make_integer_sequence<int, 32>{});
-    bfly_step<16>(rk, (lane & 16) != 0, std::make_integer_sequence<int, 16>{});
-    bfly_step<8>(rk, (lane & 8) != 0, std::make_integer_sequence<int, 8>{});
-    bfly_step<4>(rk, (lane & 4) != 0, std::make_integer_sequence<int, 4>{});
-    bfly_step<2>(rk, (lane & 2) != 0, std::make_integer_sequence<int, 2>{});
-    bfly_step<1>(rk, (lane & 1) != 0, std::make_integer_sequence<int, 1>{});
+    // ---- rows: transpose the 64 lanes x 32 slots through LDS (the tiles are dead; wave w owns
+    // floats [w*32*TLD, (w+1)*32*TLD)), then every lane scans the 32 lanes of its half for slot q = i
+    __syncthreads();                                   // all waves are done with sA / sB
+    float* T = smem + wave * (32 * TLD);
+#pragma unroll
+    for (int q = 0; q < 32; ++q) T[q * TLD + lane] = rbv[q];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    float best = NEG; int bi = 0;
     {
-        // lane (i,h) now holds slot q = i: row (q>>4)*32 + (q&3) + 8*((q&15)>>2) + 4h
-        const int q = i;
-        const int lr = (q >> 4) * 32 + (q & 3) + 8 * ((q & 15) >> 2) + 4 * h;
-        sRow[wave * 64 + lr] = rk[0];
+        const float* src = T + i * TLD + h * 32;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const f32x4 v = *(const f32x4*)(src + g * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const bool gt = v[e] > best; best = gt ? v[e] : best; bi = gt ? g * 4 + e : bi; }
+        }
     }
+    // lane (i, h) holds slot q = i of half h: d1 row row_base + wr*64 + h*32 + i = row_base + wr*64 + lane
+    sRow[wave * 64 + lane] = (best > NEG) ? pack_key(best, (unsigned)(bx2 * 64 + bi * 2 + wc)) : 0ull;
     __syncthreads();
     if (wc == 0) {
         const u64 k = umax64(sRow[wave * 64 + lane], sRow[(wave + 1) * 64 + lane]);
-        if (k) __hip_atomic_fetch_max(bestR + by * MT + wr * 64 + lane, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (k) __hip_atomic_fetch_max(bestR + row_base + wr * 64 + lane, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
-// one workgroup: mutual check + gate + ordered compaction (ascending idx1).  Thread t owns rows
-// 4t..4t+3 of every 4096-row chunk, so one ballot scan per chunk orders the output.
+// <a, b> over 64 elements as ONE fp32 fma chain in k order from 0 -- the arithmetic of the MFMA loop
+// above.  a, b: k-permuted rows (element e of group g at 8g + 4(e&1) + (e>>1)).
+__device__ __forceinline__ float dot64_chain(const float* __restrict__ a, const float* __restrict__ b) {
+    float acc = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        const f32x4 a0 = *(const f32x4*)(a + g * 8), a1 = *(const f32x4*)(a + g * 8 + 4);
+        const f32x4 b0 = *(const f32x4*)(b + g * 8), b1 = *(const f32x4*)(b + g * 8 + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { acc = fmaf(a0[j], b0[j], acc); acc = fmaf(a1[j], b1[j], acc); }
+    }
+    return acc;
+}
+
+// k_mnn_fix: second level of the arg-max and the mutual check.  Sixteen lanes per d1 row.
+//   bestR[row] = (M, gc): the row maximum M sits in d2 rows NC*gc .. NC*gc+NC-1 -> lanes 0..NC-1
+//   recompute those dot products, the first one equal to M is m12[row] (ORBmatcher.cc:367).
+//   bestC[col] = (Mc, gr): m21[col] is the first d1 row of 16*gr .. 16*gr+15 whose dot product equals
+//   Mc (:368).  row is a mutual match (:372) iff Mc == M, row lies in that group and no earlier row of
+//   the group reaches Mc -- lane l recomputes <d1 row 16*gr + l, col> for the rows before `row` only.
+__global__ __launch_bounds__(256)
+void k_mnn_fix(const float* __restrict__ d1, int n1, const float* __restrict__ d2, int n2, int NC,
+               const u64* __restrict__ bestR, const u64* __restrict__ bestC, float min_cossim,
+               int* __restrict__ mcol, float* __restrict__ mval) {
+    const int t = threadIdx.x, c = t & 15;
+    const int row = blockIdx.x * 16 + (t >> 4);
+    const u64 kr = (row < n1) ? bestR[row] : 0ull;
+    const float M = ord2f((unsigned)(kr >> 32));
+    const int gc = (int)(0xFFFFFFFFu - (unsigned)(kr & 0xFFFFFFFFull));
+    const int col = gc * NC + c;
+    const bool have = kr != 0ull && c < NC && col < n2;
+    const float dv = have ? dot64_chain(d1 + (size_t)row * 64, d2 + (size_t)col * 64) : 0.f;
+    unsigned eq = (have && dv == M) ? (1u << c) : 0u;
+    eq |= __shfl_xor(eq, 1); eq |= __shfl_xor(eq, 2); eq |= __shfl_xor(eq, 4); eq |= __shfl_xor(eq, 8);
+    int cs;
+    if (eq) cs = __builtin_ctz(eq);
+    else {      // cannot happen while the recomputation is bit-identical; stay deterministic anyway
+        u64 k = have ? pack_key(dv, (unsigned)c) : 0ull;
+        k = umax64(k, __shfl_xor(k, 1)); k = umax64(k, __shfl_xor(k, 2)); k = umax64(k, __shfl_xor(k, 4)); k = umax64(k, __shfl_xor(k, 8));
+        cs = (int)(0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull)) & 15;
+    }
+    const int cstar = gc * NC + cs;
+    bool mutual = false;
+    if (kr != 0ull) {                                   // uniform over the 16 lanes of a row
+        const u64 kc = bestC[cstar];
+        const float Mc = ord2f((unsigned)(kc >> 32));
+        const int gr = (int)(0xFFFFFFFFu - (unsigned)(kc & 0xFFFFFFFFull));
+        if (kc != 0ull && Mc == M && (row >> 4) == gr) {
+            const int r = gr * 16 + c;
+            unsigned earlier = (r < row && dot64_chain(d1 + (size_t)r * 64, d2 + (size_t)cstar * 64) == Mc) ? 1u : 0u;
+            earlier |= __shfl_xor(earlier, 1); earlier |= __shfl_xor(earlier, 2); earlier |= __shfl_xor(earlier, 4); earlier |= __shfl_xor(earlier, 8);
+            mutual = earlier == 0u;
+        }
+    }
+    if (min_cossim > 0.f) mutual = mutual && (M > min_cossim);
+    if (c == 0 && row < n1) { mcol[row] = mutual ? cstar : -1; mval[row] = M; }
+}
+
+// one workgroup: ordered compaction (ascending idx1) of the mutual pairs and their distances
+// (:371-403).  Thread t owns rows 4t..4t+3 of every 4096-row chunk, so one scan per chunk orders
+// the output.
 __global__ __launch_bounds__(1024)
-void k_mnn_final(const u64* __restrict__ bestR, const u64* __restrict__ bestC, int n1, float min_cossim,
+void k_mnn_final(const int* __restrict__ mcol, const float* __restrict__ mval, int n1,
                  int* __restrict__ idx1, int* __restrict__ idx2, float* __restrict__ dist, int* __restrict__ n_matches) {
     __shared__ int wsum[16];
     __shared__ int base;
@@ -235,23 +314,13 @@ void k_mnn_final(const u64* __restrict__ bestR, const u64* __restrict__ bestC, i
     if (t == 0) base = 0;
     __syncthreads();
     for (int i0 = 0; i0 < n1; i0 += 4096) {
-        u64 kr[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { const int i = i0 + t * 4 + q; kr[q] = (i < n1) ? bestR[i] : 0ull; }
-        int j[4]; float v[4]; u64 kc[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            j[q] = (int)(0xFFFFFFFFu - (unsigned)(kr[q] & 0xFFFFFFFFull));
-            v[q] = ord2f((unsigned)(kr[q] >> 32));
-            kc[q] = kr[q] ? bestC[j[q]] : 0ull;
-        }
-        bool keep[4]; int cnt = 0;
+        int j[4]; float v[4]; int cnt = 0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int i = i0 + t * 4 + q;
-            keep[q] = kr[q] != 0ull && (int)(0xFFFFFFFFu - (unsigned)(kc[q] & 0xFFFFFFFFull)) == i;
-            if (min_cossim > 0.f) keep[q] = keep[q] && (v[q] > min_cossim);
-            cnt += keep[q] ? 1 : 0;
+            j[q] = (i < n1) ? mcol[i] : -1;
+            v[q] = (i < n1) ? mval[i] : 0.f;
+            cnt += j[q] >= 0 ? 1 : 0;
         }
         // exclusive scan of cnt over the 1024 threads
         int incl = cnt;
@@ -263,7 +332,7 @@ void k_mnn_final(const u64* __restrict__ bestR, const u64* __restrict__ bestC, i
         for (int w = 0; w < wave; ++w) off += wsum[w];
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            if (keep[q]) {
+            if (j[q] >= 0) {
                 idx1[off] = i0 + t * 4 + q; idx2[off] = j[q];
                 const float cd = 1.0f - v[q];
                 dist[off] = sqrtf(2.0f * cd);
@@ -394,15 +463,16 @@ hipError_t launch_mnn(xfh_ctx* c, const float* d1, int n1, const float* d2, int 
                       int* idx1, int* idx2, float* dist, int* n_matches) {
     hipError_t e;
     if (n1 <= 0 || n2 <= 0) return hipMemsetAsync(n_matches, 0, sizeof(int), c->stream);
-    const int nbR = (n1 + MT - 1) / MT, nbC = (n2 + MT - 1) / MT, nbC2 = (nbC + TPW - 1) / TPW;
     MatchWs& w = c->mws;
-    const size_t need_best = (size_t)n1 + n2;
+    const size_t need_best = 2 * (size_t)n1 + n2;          // bestR[n1], bestC[n2], then mcol[n1] (int) + mval[n1] (float)
     if (w.cap_best < need_best) {
         if (w.bestR) hipFree(w.bestR);
         if ((e = hipMalloc((void**)&w.bestR, need_best * sizeof(u64))) != hipSuccess) return e;
         w.cap_best = need_best;
     }
     w.bestC = w.bestR + n1;
+    int* mcol = (int*)(w.bestC + n2);
+    float* mval = (float*)(mcol + n1);
     const size_t need_norm = ((size_t)n1 + n2) * 64;
     if (w.cap_norm < need_norm) {
         if (w.norm1) hipFree(w.norm1);
@@ -411,9 +481,12 @@ hipError_t launch_mnn(xfh_ctx* c, const float* d1, int n1, const float* d2, int 
     }
     w.norm2 = w.norm1 + (size_t)n1 * 64;
     hipLaunchKernelGGL(k_rownorm, dim3((n1 + n2 + 15) / 16 + 1), dim3(256), 0, c->stream, d1, n1, d2, n2, w.norm1, w.norm2, w.bestR, w.bestC);
-    launch_k(c, XFH_K_MNN_GEMM, -1, k_mnn_gemm, dim3(nbC2, nbR), dim3(256), 0, (const float*)w.norm1, n1, (const float*)w.norm2, n2,
-             w.bestR, w.bestC, nbC);
-    hipLaunchKernelGGL(k_mnn_final, dim3(1), dim3(1024), 0, c->stream, (const u64*)w.bestR, (const u64*)w.bestC, n1, min_cossim,
+    const int NC = MNN_NC;
+    launch_k(c, XFH_K_MNN_GEMM, -1, k_mnn_gemm, dim3((n2 + TPW * MT - 1) / (TPW * MT), (n1 + MT - 1) / MT), dim3(256), 0,
+             (const float*)w.norm1, n1, (const float*)w.norm2, n2, w.bestR, w.bestC);
+    hipLaunchKernelGGL(k_mnn_fix, dim3((n1 + 15) / 16), dim3(256), 0, c->stream, (const float*)w.norm1, n1, (const float*)w.norm2, n2, NC,
+                       (const u64*)w.bestR, (const u64*)w.bestC, min_cossim, mcol, mval);
+    hipLaunchKernelGGL(k_mnn_final, dim3(1), dim3(1024), 0, c->stream, (const int*)mcol, (const float*)mval, n1,
                        idx1, idx2, dist, n_matches);
     return hipGetLastError();
 }
