@@ -137,7 +137,7 @@ int xfh_destroy(xfh_ctx* c) {
     if (c->own_stream) hipStreamSynchronize(c->own_stream);
     auto F = [](void* p) { if (p) hipFree(p); };
     F(c->d_gray); F(c->X); F(c->pre_part); F(c->xstat);
-    for (int i = 0; i < XFH_NUM_LAYERS; ++i) { F(c->raw[i]); F(c->part[i]); F(c->stat[i]); F(c->w.mfma[i]); F(c->w.mfma32[i]); }
+    for (int i = 0; i < XFH_NUM_LAYERS; ++i) { F(c->raw[i]); F(c->part[i]); F(c->stat[i]); F(c->w.mfma[i]); F(c->w.alt[i]); }
     for (int i = 0; i < 3; ++i) F(c->w.direct[i]);
     F(c->w.fus2); F(c->w.fus2_bias); F(c->w.skip_w); F(c->w.skip_b); F(c->w.heat2_w); F(c->w.heat2_b); F(c->w.kp3_w); F(c->w.kp3_b);
     F(c->skip_pool); F(c->xunfold); F(c->b2in); F(c->fuse_in); F(c->feats); F(c->m1n); F(c->H1); F(c->K1h);
@@ -182,17 +182,19 @@ static int upload(xfh_ctx* c, float** dst, const std::vector<float>& v) {
     return XFH_OK;
 }
 
-// OIHW -> [chunk = tap*NCB + cb][n (COUTP)][CB] with the k permutation of the MFMA kernels:
-// inside each group of 8 channels, channel e sits at position 4*(e&1) + (e>>1).
-static std::vector<float> pack_mfma(const float* w, int cout, int cin, int ks, int coutp, int cbmax = 64) {
-    const int CB = cin > cbmax ? cbmax : cin, NCB = cin / CB;
+// OIHW -> [chunk][n (COUTP)][KC] with the k permutation of the MFMA kernels: inside each group of 8
+// channels, channel e sits at position 4*(e&1) + (e>>1).  A chunk holds CB = min(cin, cbmax) channels of
+// tpc consecutive taps (tpc > 1 only when CB == cin): chunk = (tap / tpc) * NCB + cb, KC = tpc * CB,
+// position inside the chunk row = (tap % tpc) * CB + pos.
+static std::vector<float> pack_mfma(const float* w, int cout, int cin, int ks, int coutp, int cbmax = 64, int tpc = 1) {
+    const int CB = cin > cbmax ? cbmax : cin, NCB = cin / CB, KC = tpc * CB;
     std::vector<float> o((size_t)ks * ks * NCB * coutp * CB, 0.f);
     for (int ky = 0; ky < ks; ++ky) for (int kx = 0; kx < ks; ++kx) for (int cb = 0; cb < NCB; ++cb)
         for (int n = 0; n < cout; ++n) for (int lc = 0; lc < CB; ++lc) {
             const int g = lc / 8, e = lc % 8, pos = g * 8 + 4 * (e & 1) + (e >> 1);
-            const int ci = cb * CB + lc;
-            const size_t chunk = (size_t)(ky * ks + kx) * NCB + cb;
-            o[(chunk * coutp + n) * CB + pos] = w[(((size_t)n * cin + ci) * ks + ky) * ks + kx];
+            const int ci = cb * CB + lc, tap = ky * ks + kx;
+            const size_t chunk = (size_t)(tap / tpc) * NCB + cb;
+            o[(chunk * coutp + n) * KC + (tap % tpc) * CB + pos] = w[(((size_t)n * cin + ci) * ks + ky) * ks + kx];
         }
     return o;
 }
@@ -214,8 +216,10 @@ int xfh_load_weights(xfh_ctx* c, const void* blob, size_t nbytes) {
         } else {
             const int coutp = (L.cout + 31) / 32 * 32;
             rc = upload(c, &c->w.mfma[i], pack_mfma(e.p, L.cout, L.cin, L.ks, coutp));
-            if (rc == XFH_OK && L.cin == 64 && L.cout == 64 && L.ks == 3)
-                rc = upload(c, &c->w.mfma32[i], pack_mfma(e.p, L.cout, L.cin, L.ks, coutp, 32));
+            if (rc == XFH_OK && L.ks == 3 && L.cin >= 64 && L.stride == 1 && i != 10 && i != 11)       // 7, 16, 17 and 13, 14: 32-channel chunks
+                rc = upload(c, &c->w.alt[i], pack_mfma(e.p, L.cout, L.cin, L.ks, coutp, 32));
+            if (rc == XFH_OK && i == 3)                                                                // block1.3: all nine taps in one chunk
+                rc = upload(c, &c->w.alt[i], pack_mfma(e.p, L.cout, L.cin, L.ks, coutp, 64, 9));
         }
         if (rc != XFH_OK) return rc;
         if (c->cfg.bn_mode == XFH_BN_RUNNING_STATS) {

@@ -175,7 +175,7 @@ void k_conv_direct(ConvArgs a) {
 // implicit-GEMM convolution on the f32 matrix cores.
 //   WM x WN waves per workgroup; each wave owns 32 output pixels (WH x WW) and NT tiles of 32
 //   output channels.  COUTP = WN*NT*32 >= COUT (padded weight rows are zero).
-template <int CIN, int COUT, int KS, int ST, int WM, int WN, int NT, int WW, int PRO, int EPI, int CBMAX = 64>
+template <int CIN, int COUT, int KS, int ST, int WM, int WN, int NT, int WW, int PRO, int EPI, int CBMAX = 64, int TPC = 1>
 __global__ __launch_bounds__(64 * WM * WN)
 void k_conv_mfma(ConvArgs a) {
     constexpr int NTHR = 64 * WM * WN;
@@ -184,12 +184,15 @@ void k_conv_mfma(ConvArgs a) {
     constexpr int PAD = KS / 2;
     constexpr int TIH = (TH - 1) * ST + KS, TIW = (TW - 1) * ST + KS;
     constexpr int CP = CIN + 4;                  // LDS pixel stride (floats)
-    constexpr int CB = CIN > CBMAX ? CBMAX : CIN;   // channels per weight chunk
+    constexpr int CB = CIN > CBMAX ? CBMAX : CIN;   // channels per weight chunk and tap
     constexpr int NCB = CIN / CB;
-    constexpr int NCHUNK = KS * KS * NCB;
+    static_assert(TPC == 1 || NCB == 1, "several taps per chunk only with all channels in the chunk");
+    static_assert((KS * KS) % TPC == 0, "taps per chunk");
+    constexpr int NCHUNK = KS * KS * NCB / TPC;
     constexpr int NWBUF = NCHUNK > 1 ? 2 : 1;
-    constexpr int WS = CB + 4;                   // LDS weight row stride
-    constexpr int WCH = COUTP * CB;              // floats per chunk in global memory
+    constexpr int KC = TPC * CB;                 // K elements per chunk: TPC taps x CB channels
+    constexpr int WS = KC + 4;                   // LDS weight row stride (WS/4 odd: conflict-free b128 reads)
+    constexpr int WCH = COUTP * KC;              // floats per chunk in global memory
     constexpr int NWLD = (WCH / 4 + NTHR - 1) / NTHR;
     constexpr int G = CIN / 8;
     constexpr int IN_FLOATS = TIH * TIW * CP;
@@ -244,7 +247,7 @@ void k_conv_mfma(ConvArgs a) {
     for (int q = 0; q < NWLD; ++q) {
         const int f = t + q * NTHR;
         if (f < WCH / 4) {
-            const int n = f / (CB / 4), c4 = f % (CB / 4);
+            const int n = f / (KC / 4), c4 = f % (KC / 4);
             *(f32x4*)(s_w + n * WS + c4 * 4) = wreg[q];
         }
     }
@@ -262,8 +265,6 @@ void k_conv_mfma(ConvArgs a) {
         for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
 
     for (int ch = 0; ch < NCHUNK; ++ch) {
-        const int tap = ch / NCB, cb = ch % NCB;
-        const int ky = tap / KS, kx = tap % KS;
         if (ch + 1 < NCHUNK) {
             const float* wsrc = a.w + (size_t)(ch + 1) * WCH;
 #pragma unroll
@@ -272,17 +273,22 @@ void k_conv_mfma(ConvArgs a) {
                 if (f < WCH / 4) wreg[q] = *(const f32x4*)(wsrc + (size_t)f * 4);
             }
         }
-        const float* pa = s_in + ((ly + ky) * TIW + lx + kx) * CP + cb * CB + 4 * h;
-        const float* pw = s_w + (ch & 1) * W_FLOATS + (wn * NT * 32 + i) * WS + 4 * h;
 #pragma unroll
-        for (int kk = 0; kk < CB / 8; ++kk) {
-            const f32x4 av = *(const f32x4*)(pa + kk * 8);
+        for (int tt = 0; tt < TPC; ++tt) {
+            const int tap = TPC == 1 ? ch / NCB : ch * TPC + tt, cb = TPC == 1 ? ch % NCB : 0;
+            const int ky = tap / KS, kx = tap % KS;
+            const float* pa = s_in + ((ly + ky) * TIW + lx + kx) * CP + cb * CB + 4 * h;
+            const float* pw = s_w + (ch & 1) * W_FLOATS + (wn * NT * 32 + i) * WS + tt * CB + 4 * h;
 #pragma unroll
-            for (int n = 0; n < NT; ++n) {
-                const f32x4 bv = *(const f32x4*)(pw + n * 32 * WS + kk * 8);
+            for (int kk = 0; kk < CB / 8; ++kk) {
+                const f32x4 av = *(const f32x4*)(pa + kk * 8);
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc[n], 0, 0, 0);
+                for (int n = 0; n < NT; ++n) {
+                    const f32x4 bv = *(const f32x4*)(pw + n * 32 * WS + kk * 8);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc[n], 0, 0, 0);
+                }
             }
         }
         if (ch + 1 < NCHUNK) {
@@ -291,7 +297,7 @@ void k_conv_mfma(ConvArgs a) {
             for (int q = 0; q < NWLD; ++q) {
                 const int f = t + q * NTHR;
                 if (f < WCH / 4) {
-                    const int n = f / (CB / 4), c4 = f % (CB / 4);
+                    const int n = f / (KC / 4), c4 = f % (KC / 4);
                     *(f32x4*)(wd + n * WS + c4 * 4) = wreg[q];
                 }
             }
@@ -346,14 +352,14 @@ void k_conv_mfma(ConvArgs a) {
 
 // ------------------------------------------------------------------------------------
 // host side: layer -> template instance
-template <int CIN, int COUT, int KS, int ST, int WM, int WN, int NT, int WW, int PRO, int EPI, int CBMAX = 64>
+template <int CIN, int COUT, int KS, int ST, int WM, int WN, int NT, int WW, int PRO, int EPI, int CBMAX = 64, int TPC = 1>
 static hipError_t conv_mfma_launch(xfh_ctx* c, const ConvArgs& a, int B, int* npart_out, int layer) {
     constexpr int WH = 32 / WW, TH = WM * WH, TW = WW;
     constexpr int COUTP = WN * NT * 32;
     constexpr int TIH = (TH - 1) * ST + KS, TIW = (TW - 1) * ST + KS;
     constexpr int CB = CIN > CBMAX ? CBMAX : CIN;
-    constexpr int NWBUF = (KS * KS * (CIN / CB)) > 1 ? 2 : 1;
-    constexpr size_t LDS = sizeof(float) * ((size_t)TIH * TIW * (CIN + 4) + NWBUF * (size_t)COUTP * (CB + 4) + 2 * CIN);
+    constexpr int NWBUF = (KS * KS * (CIN / CB) / TPC) > 1 ? 2 : 1;
+    constexpr size_t LDS = sizeof(float) * ((size_t)TIH * TIW * (CIN + 4) + NWBUF * (size_t)COUTP * (TPC * CB + 4) + 2 * CIN);
     static_assert(LDS <= 160 * 1024, "LDS budget");
     static_assert(sizeof(double) * WM * COUTP * 2 <= LDS, "stat scratch");
     ConvArgs aa = a;
@@ -361,7 +367,7 @@ static hipError_t conv_mfma_launch(xfh_ctx* c, const ConvArgs& a, int B, int* np
     const int tiles_y = (a.Hout + TH - 1) / TH;
     const int ntile = aa.tiles_x * tiles_y;
     if (npart_out) *npart_out = ntile;
-    auto kern = k_conv_mfma<CIN, COUT, KS, ST, WM, WN, NT, WW, PRO, EPI, CBMAX>;
+    auto kern = k_conv_mfma<CIN, COUT, KS, ST, WM, WN, NT, WW, PRO, EPI, CBMAX, TPC>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
@@ -421,7 +427,11 @@ hipError_t launch_basic_layer(xfh_ctx* c, int li, const float* in, size_t in_str
         case 0: e = conv_direct_launch<1, 4, 1, PRO_IN>(c, a, B, &np, li); break;
         case 1: e = conv_direct_launch<4, 8, 2, PRO_BN>(c, a, B, &np, li); break;
         case 2: e = conv_direct_launch<8, 8, 1, PRO_BN>(c, a, B, &np, li); break;
-        case 3: e = conv_mfma_launch<8, 24, 3, 2, 4, 1, 1, 16, PRO_BN, EPI_STATS>(c, a, B, &np, li); break;   // K = 72 on the matrix cores
+        case 3:     // all nine taps of the weights in one LDS chunk (no barrier inside the K = 72 loop): 49.5 -> 46.2 us at B = 32;
+                    // the same form measured slower for the 24 -> 24 layers (95 vs 91 us).  XFH_CONV_CFG=0: one tap per chunk
+            if (conv_cfg()) { a.w = c->w.alt[li]; e = conv_mfma_launch<8, 24, 3, 2, 4, 1, 1, 16, PRO_BN, EPI_STATS, 64, 9>(c, a, B, &np, li); }
+            else e = conv_mfma_launch<8, 24, 3, 2, 4, 1, 1, 16, PRO_BN, EPI_STATS>(c, a, B, &np, li);
+            break;
         case 4: e = conv_mfma_launch<24, 24, 3, 1, 4, 1, 1, 16, PRO_PLAIN, EPI_STATS>(c, a, B, &np, li); break;  // input = b2in
         case 5: e = conv_mfma_launch<24, 24, 3, 1, 4, 1, 1, 16, PRO_BN, EPI_STATS>(c, a, B, &np, li); break;
         case 6: e = conv_mfma_launch<24, 64, 3, 2, 4, 1, 2, 16, PRO_BN, EPI_STATS>(c, a, B, &np, li); break;
@@ -430,7 +440,7 @@ hipError_t launch_basic_layer(xfh_ctx* c, int li, const float* in, size_t in_str
             // 32-channel weight chunks (67 KB LDS -> 2 workgroups per CU); measured 70 us vs 77 us for the
             // 4-wave / 64-channel-chunk form at B = 16 (profiles/r01_conv_cfg.log).  XFH_CONV_CFG=0 selects the latter.
             const int cfg = conv_cfg();
-            if (cfg != 0) a.w = c->w.mfma32[li];
+            if (cfg != 0) a.w = c->w.alt[li];
             if (li == 16) {                                                                                     // input = fuse_in
                 if (cfg != 0) e = conv_mfma_launch<64, 64, 3, 1, 4, 2, 1, 16, PRO_PLAIN, EPI_STATS, 32>(c, a, B, &np, li);
                 else e = conv_mfma_launch<64, 64, 3, 1, 4, 1, 2, 16, PRO_PLAIN, EPI_STATS>(c, a, B, &np, li);
@@ -444,7 +454,10 @@ hipError_t launch_basic_layer(xfh_ctx* c, int li, const float* in, size_t in_str
         case 9: e = conv_mfma_launch<64, 64, 3, 2, 2, 2, 1, 8, PRO_BN, EPI_STATS>(c, a, B, &np, li); break;
         case 10: case 11: e = conv_mfma_launch<64, 64, 3, 1, 2, 2, 1, 8, PRO_BN, EPI_STATS>(c, a, B, &np, li); break;
         case 12: e = conv_mfma_launch<64, 128, 3, 2, 1, 4, 1, 8, PRO_BN, EPI_STATS>(c, a, B, &np, li); break;
-        case 13: case 14: e = conv_mfma_launch<128, 128, 3, 1, 1, 4, 1, 8, PRO_BN, EPI_STATS>(c, a, B, &np, li); break;
+        case 13: case 14:       // 32-channel weight chunks: 69 KB LDS -> 2 workgroups per CU, 58 -> 50 us at B = 32; XFH_CONV_CFG=0: 64-channel chunks
+            if (conv_cfg()) { a.w = c->w.alt[li]; e = conv_mfma_launch<128, 128, 3, 1, 1, 4, 1, 8, PRO_BN, EPI_STATS, 32>(c, a, B, &np, li); }
+            else e = conv_mfma_launch<128, 128, 3, 1, 1, 4, 1, 8, PRO_BN, EPI_STATS>(c, a, B, &np, li);
+            break;
         case 15: e = conv_mfma_launch<128, 64, 1, 1, 1, 2, 1, 8, PRO_BN, EPI_STATS>(c, a, B, &np, li); break;
         case 18: case 20:                                                                                      // inputs: feats / unfold(xhat)
             e = conv_mfma_launch<64, 64, 1, 1, 4, 1, 2, 16, PRO_PLAIN, EPI_STATS>(c, a, B, &np, li); break;
