@@ -47,10 +47,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=64, help="frames per sub-batch (per GPU per step: batch x streams)")
+    ap.add_argument("--batch", type=int, default=256, help="frames per sub-batch (per GPU per step: batch x streams)")
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--width", type=int, default=640)
-    ap.add_argument("--streams", type=int, default=3, help="independent sub-batches in flight (one ctx + HIP stream each)")
+    ap.add_argument("--streams", type=int, default=1, help="independent sub-batches in flight (one ctx + HIP stream each)")
     ap.add_argument("--match-iters", type=int, default=100)
     ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the bounded CPU-baseline sample (0 = skip)")
     args = ap.parse_args()
@@ -144,19 +144,25 @@ def main():
         step()
     sync()
     sync()
+    # roofline of the dominant kernel: dispatch-attached HIP events (hipExtLaunchKernelGGL) on every launch of
+    # that kernel.  With one sub-batch in flight (the default) they are taken INSIDE the timed region, on the
+    # stream the kernel runs on; rocprofv3 --kernel-trace of the same command reports the same average.
+    layer_mask = sum(1 << l for l in DOMINANT_LAYERS)
+    in_region = S == 1 and K * len(DOMINANT_LAYERS) <= 4096
+    if in_region:
+        ctx.timing_enable(capi.K["CONV_MFMA"], layer_mask)
     t0 = time.perf_counter()
     for _ in range(K):
         step()
     sync()
     elapsed = time.perf_counter() - t0
-    # roofline of the dominant kernel: the same K steps once more on ONE stream with dispatch-attached
-    # events on that kernel (with several sub-batches in flight its launches share the CUs with other
-    # kernels, and rocprofv3 --kernel-trace serialises the streams, so only this form is comparable)
-    layer_mask = sum(1 << l for l in DOMINANT_LAYERS)
-    ctx.timing_enable(capi.K["CONV_MFMA"], layer_mask)
-    for _ in range(K):
-        capi.check(lib.xfh_extract_batch_device(ctx.h, in_ptr, B, H, W, 0, 0, rec_ptr), ctx.h)
-    ctx.synchronize()
+    if not in_region:
+        # several sub-batches in flight share the CUs, so a launch's duration is not the kernel's own speed:
+        # time the kernel in the same K steps once more on ONE stream
+        ctx.timing_enable(capi.K["CONV_MFMA"], layer_mask)
+        for _ in range(K):
+            capi.check(lib.xfh_extract_batch_device(ctx.h, in_ptr, B, H, W, 0, 0, rec_ptr), ctx.h)
+        ctx.synchronize()
     n_conv, ms_conv = ctx.timing_read()
     ctx.timing_enable(0)
     if use_dist:
@@ -242,6 +248,10 @@ def main():
                          f"4096x4096 MNN once: {nf * nf / cpu_match_dt:.3e} pairs/s",
                "match_pairs_per_s": nf * nf / cpu_match_dt}
 
+    # PMC HBM bytes of the dominant kernel, scaled from the batch of the counter pass to this run's batch
+    conv_traffic = None
+    if traffic and traffic.get("conv_bytes_per_launch"):
+        conv_traffic = traffic["conv_bytes_per_launch"] * (B / traffic["conv_batch"] if traffic.get("conv_batch") else 1.0)
     out = {
         "metric": "XFeat frames/s (VGA, 4096 kpts) + 4096x4096 desc-match pairs/s",
         "value": frames_per_s, "unit": "frames/s", "n_gpus": N, "steps": K, "warmup": args.warmup,
@@ -252,9 +262,9 @@ def main():
                                + (", RCCL all-gather of records" if use_dist else ""),
                    "frames_per_gpu_per_step": B * S, "sub_batches_in_flight": S, "height": H, "width": W, "nfeatures": nf,
                    "weights": f"synthetic seed 1234, keypoint-logit gain {KP_GAIN}", "parallelism": f"frames x{N}"},
-        "roofline": {"kernel": "k_conv_mfma<64,64,3,1,4,2,1,16,1,0,32> (block3.1, block_fusion.1: 3x3 64->64 at 1/8 res)", "measured": "single-stream pass of the same steps",
+        "roofline": {"kernel": "k_conv_mfma<64,64,3,1,4,2,1,16,1,0,32,1> (block3.1, block_fusion.1: 3x3 64->64 at 1/8 res)", "measured": "HIP events attached to every dispatch of the kernel inside the timed region" if in_region else "single-stream pass of the same steps",
                      "bound": "mfma", "achieved": conv_tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                     "frac": conv_tf / PEAK_F32_MFMA_TFLOPS, "traffic": (traffic or {}).get("conv_bytes_per_launch"),
+                     "frac": conv_tf / PEAK_F32_MFMA_TFLOPS, "traffic": conv_traffic,
                      "avg_launch_us": conv_us, "launches": n_conv, "flops_per_launch": conv_flops(H, W) * B},
         "match": {"pairs_per_s": nf * nf / match_dt, "us_per_call": match_dt * 1e6, "n1": nf, "n2": nf, "n_matches": n_matches,
                   "roofline": {"kernel": "k_mnn_gemm", "bound": "mfma", "achieved": gemm_tf, "peak": PEAK_F32_MFMA_TFLOPS,

@@ -8,8 +8,8 @@ export TMPDIR=/tmp
 ( timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -40 ) > $O/pytest_gpu.log
 ( timeout 120 python -c "import __graft_entry__ as g; g.smoke()" ) > $O/smoke.log 2>&1
 ( timeout 300 python bench.py ) > $O/bench_default.json 2> $O/bench_default.err
-for B in ${BENCH_BATCHES:-1 8 16 32}; do for S in 1 3; do
-  ( timeout 300 python bench.py --batch $B --streams $S --steps 30 --cpu-frames 0 ) > $O/bench_B${B}_S$S.json 2> $O/bench_B${B}_S$S.err
+for B in ${BENCH_BATCHES:-1 8 16 32 64 128 256}; do for S in 1 3; do
+  ( timeout 300 python bench.py --batch $B --streams $S --steps 20 --cpu-frames 0 --match-iters 10 ) > $O/bench_B${B}_S$S.json 2> $O/bench_B${B}_S$S.err
 done; done
 ( XFH_FORCE_DIST=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29555 bench.py --gpus 1 --steps 20 --cpu-frames 0 ) > $O/bench_dist1.json 2> $O/bench_dist1.err
 rm -rf $O/prof $O/pmc_fetch $O/pmc_write
