@@ -165,6 +165,16 @@ def main():
         ctx.synchronize()
     n_conv, ms_conv = ctx.timing_read()
     ctx.timing_enable(0)
+    # configs[1] read literally: ONE frame per call (what a SLAM thread sees), device resident, back to back
+    for _ in range(10):
+        capi.check(lib.xfh_extract_batch_device(ctx.h, in_ptr, 1, H, W, 0, 0, rec_ptr), ctx.h)
+    ctx.synchronize()
+    t1 = time.perf_counter()
+    n_single = 200
+    for _ in range(n_single):
+        capi.check(lib.xfh_extract_batch_device(ctx.h, in_ptr, 1, H, W, 0, 0, rec_ptr), ctx.h)
+    ctx.synchronize()
+    single_dt = (time.perf_counter() - t1) / n_single
     if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -266,6 +276,8 @@ def main():
                      "bound": "mfma", "achieved": conv_tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": conv_tf / PEAK_F32_MFMA_TFLOPS, "traffic": conv_traffic,
                      "avg_launch_us": conv_us, "launches": n_conv, "flops_per_launch": conv_flops(H, W) * B},
+        "single_frame": {"ms_per_frame": single_dt * 1e3, "frames_per_s": 1.0 / single_dt,
+                         "note": "one 480x640 frame per xfh_extract_batch_device call, back to back on one stream (latency path of configs[1])"},
         "match": {"pairs_per_s": nf * nf / match_dt, "us_per_call": match_dt * 1e6, "n1": nf, "n2": nf, "n_matches": n_matches,
                   "roofline": {"kernel": "k_mnn_gemm", "bound": "mfma", "achieved": gemm_tf, "peak": PEAK_F32_MFMA_TFLOPS,
                                "unit": "TFLOP/s", "frac": gemm_tf / PEAK_F32_MFMA_TFLOPS,

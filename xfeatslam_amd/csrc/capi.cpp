@@ -36,7 +36,7 @@ const char* xfh_strerror(int s) {
 
 const char* xfh_kernel_name(int id) {
     static const char* n[XFH_K_COUNT] = {"none", "k_mnn_gemm", "k_conv_mfma", "k_conv_direct", "k_nms_score", "k_select",
-                                         "k_desc", "k_heads_final", "k_dist_i32", "k_preproc", "k_best2_csr"};
+                                         "k_desc", "k_heads_kp", "k_dist_i32", "k_preproc", "k_best2_csr"};
     return (id >= 0 && id < XFH_K_COUNT) ? n[id] : "?";
 }
 
@@ -91,6 +91,9 @@ int xfh_create(const xfh_config* cfg, xfh_ctx** out) {
     if (hipSetDevice(cfg->device) != hipSuccess) return fail(XFH_ERR_HIP);
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) return fail(XFH_ERR_HIP);
     c->stream = c->own_stream;
+    if (hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) != hipSuccess) return fail(XFH_ERR_HIP);
+    if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) return fail(XFH_ERR_HIP);
+    if (hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) return fail(XFH_ERR_HIP);
     const size_t xs = (size_t)c->Hmax * c->Wmax;
     A(c->d_gray, (size_t)B * cfg->max_height * cfg->max_width);
     A(c->X, sizeof(float) * B * xs);
@@ -135,6 +138,7 @@ int xfh_create(const xfh_config* cfg, xfh_ctx** out) {
 int xfh_destroy(xfh_ctx* c) {
     if (!c) return XFH_OK;
     if (c->own_stream) hipStreamSynchronize(c->own_stream);
+    if (c->aux_stream) hipStreamSynchronize(c->aux_stream);
     auto F = [](void* p) { if (p) hipFree(p); };
     F(c->d_gray); F(c->X); F(c->pre_part); F(c->xstat);
     for (int i = 0; i < XFH_NUM_LAYERS; ++i) { F(c->raw[i]); F(c->part[i]); F(c->stat[i]); F(c->w.mfma[i]); F(c->w.alt[i]); }
@@ -147,6 +151,9 @@ int xfh_destroy(xfh_ctx* c) {
     MatchWs& w = c->mws;
     F(w.bestR); F(w.b2_buf); F(w.h_d1); F(w.o_idx1); F(w.o_tab); F(w.norm1);
     if (c->timer.ev) { for (int i = 0; i < 2 * KTimer::MAXEV; ++i) if (c->timer.ev[i]) hipEventDestroy(c->timer.ev[i]); free(c->timer.ev); }
+    if (c->ev_fork) hipEventDestroy(c->ev_fork);
+    if (c->ev_join) hipEventDestroy(c->ev_join);
+    if (c->aux_stream) hipStreamDestroy(c->aux_stream);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
     return XFH_OK;

@@ -38,6 +38,48 @@ __host__ __device__ inline float ord2f(unsigned u) {
     return __builtin_bit_cast(float, u);
 }
 
+// ---- statistics finalisation ------------------------------------------------------------
+// Fold the npart (sum, sum of squares) fp64 partials of every channel in a FIXED order into
+// (mean, rstd).  Called by k_bn_finalize (one workgroup per frame) and, for small batches, by
+// every workgroup of the CONSUMING convolution (which saves the dependent finalize launch); the
+// order does not depend on the number of threads, so all callers produce the same bits.
+// red: >= 512 doubles of LDS; stat: 2*C floats (LDS or global); C <= 256.  Ends with a barrier.
+__device__ __forceinline__ void bn_fold(const double* __restrict__ p, int npart, int C, double count, float* stat, double* red, int t, int nthr) {
+    const int SL = 256 / C;
+    for (int idx = t; idx < SL * C; idx += nthr) {
+        const int c = idx % C, j = idx / C;
+        double s = 0.0, ss = 0.0;
+        int q = j;
+        for (; q + 7 * SL < npart; q += 8 * SL) {       // 16 independent loads in flight, summed in index order
+            double v[8], w[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                v[u] = p[((size_t)(q + u * SL) * C + c) * 2 + 0];
+                w[u] = p[((size_t)(q + u * SL) * C + c) * 2 + 1];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { s += v[u]; ss += w[u]; }
+        }
+        for (; q < npart; q += SL) {
+            s += p[((size_t)q * C + c) * 2 + 0];
+            ss += p[((size_t)q * C + c) * 2 + 1];
+        }
+        red[idx * 2 + 0] = s;
+        red[idx * 2 + 1] = ss;
+    }
+    __syncthreads();
+    for (int c = t; c < C; c += nthr) {
+        double S = 0.0, SS = 0.0;
+        for (int q = 0; q < SL; ++q) { S += red[(q * C + c) * 2 + 0]; SS += red[(q * C + c) * 2 + 1]; }
+        const double mean = S / count;
+        double var = SS / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        stat[c] = (float)mean;
+        stat[C + c] = (float)(1.0 / sqrt(var + 1e-5));
+    }
+    __syncthreads();
+}
+
 // per-frame output record header (include/xfeat_hip.h, xfh_record_bytes)
 struct RecordHeader { int32_t n_valid, mono_index, n_candidates, reserved; };
 

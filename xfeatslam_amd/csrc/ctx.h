@@ -22,6 +22,8 @@ struct xfh_ctx {
     int Hmax = 0, Wmax = 0;         // resized maxima (multiples of 32)
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;   // own_stream or an external one
+    hipStream_t aux_stream = nullptr;                  // keypoint branch of run_extract (forked / joined with the two events)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::string hip_err;
 
     DevWeights w;

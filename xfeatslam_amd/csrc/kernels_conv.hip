@@ -35,6 +35,9 @@ struct ConvArgs {
     double* part;           // [B][npart][COUT][2]
     size_t part_stride;     // doubles per frame
     int tiles_x;
+    // consumer-side statistics fold (small batches, k_conv_mfma PRO_BN): when in_part != nullptr every workgroup folds the
+    // producer's partials itself (bn_fold) instead of reading in_stat, and tile 0 publishes them to in_stat_out
+    const double* in_part; size_t in_part_stride; int in_npart; double in_count; float* in_stat_out;
 };
 
 enum { PRO_PLAIN = 0, PRO_BN = 1, PRO_IN = 2 };
@@ -46,29 +49,8 @@ __global__ __launch_bounds__(256)
 void k_bn_finalize(const double* __restrict__ part, size_t part_stride, int npart, int C, double count,
                    float* __restrict__ stat /* [B][2*C] */) {
     __shared__ double red[256 * 2];
-    const int b = blockIdx.x, t = threadIdx.x;
-    const int SL = 256 / C;
-    const int c = t % C, j = t / C;
-    const double* p = part + (size_t)b * part_stride;
-    double s = 0.0, ss = 0.0;
-    if (j < SL) {
-        for (int q = j; q < npart; q += SL) {
-            s += p[((size_t)q * C + c) * 2 + 0];
-            ss += p[((size_t)q * C + c) * 2 + 1];
-        }
-        red[(j * C + c) * 2 + 0] = s;
-        red[(j * C + c) * 2 + 1] = ss;
-    }
-    __syncthreads();
-    if (t < C) {
-        double S = 0.0, SS = 0.0;
-        for (int q = 0; q < SL; ++q) { S += red[(q * C + t) * 2 + 0]; SS += red[(q * C + t) * 2 + 1]; }
-        const double mean = S / count;
-        double var = SS / count - mean * mean;
-        if (var < 0.0) var = 0.0;
-        stat[(size_t)b * 2 * C + t] = (float)mean;
-        stat[(size_t)b * 2 * C + C + t] = (float)(1.0 / sqrt(var + 1e-5));
-    }
+    const int b = blockIdx.x;
+    bn_fold(part + (size_t)b * part_stride, npart, C, count, stat + (size_t)b * 2 * C, red, threadIdx.x, 256);
 }
 
 // ------------------------------------------------------------------------------------
@@ -215,9 +197,14 @@ void k_conv_mfma(ConvArgs a) {
         if (f < WCH / 4) wreg[q] = *(const f32x4*)(a.w + (size_t)f * 4);
     }
     if constexpr (PRO == PRO_BN) {
-        const float* st = a.in_stat + (size_t)b * 2 * CIN;
-        for (int q = t; q < 2 * CIN; q += NTHR) s_stat[q] = st[q];
-        __syncthreads();
+        if (a.in_part) {            // consumer-side fold of the producer's statistics (small batches); s_in is still free
+            bn_fold(a.in_part + (size_t)b * a.in_part_stride, a.in_npart, CIN, a.in_count, s_stat, (double*)s_in, t, NTHR);
+            if (tile == 0) for (int q = t; q < 2 * CIN; q += NTHR) a.in_stat_out[(size_t)b * 2 * CIN + q] = s_stat[q];
+        } else {
+            const float* st = a.in_stat + (size_t)b * 2 * CIN;
+            for (int q = t; q < 2 * CIN; q += NTHR) s_stat[q] = st[q];
+            __syncthreads();
+        }
     }
     // ---- stage the activated input tile (zero padding outside the image) ----------------
     for (int item = t; item < TIH * TIW * G; item += NTHR) {
@@ -362,6 +349,7 @@ static hipError_t conv_mfma_launch(xfh_ctx* c, const ConvArgs& a, int B, int* np
     constexpr size_t LDS = sizeof(float) * ((size_t)TIH * TIW * (CIN + 4) + NWBUF * (size_t)COUTP * (TPC * CB + 4) + 2 * CIN);
     static_assert(LDS <= 160 * 1024, "LDS budget");
     static_assert(sizeof(double) * WM * COUTP * 2 <= LDS, "stat scratch");
+    static_assert(sizeof(double) * 512 <= sizeof(float) * (size_t)TIH * TIW * (CIN + 4), "bn_fold scratch in the input tile");
     ConvArgs aa = a;
     aa.tiles_x = (a.Wout + TW - 1) / TW;
     const int tiles_y = (a.Hout + TH - 1) / TH;
@@ -396,6 +384,19 @@ static int conv_cfg() {
     return v;
 }
 
+// Small batches: a dependent launch costs ~5 us on this GPU whatever it does, so the statistics of a layer
+// whose consumer is a convolution are folded by every workgroup of that consumer (same bn_fold, same bits;
+// ~2 us of latency instead of a launch) and published by its tile 0.  Large batches keep k_bn_finalize:
+// there the per-workgroup re-read of the partials would cost more than the launch.  XFH_CONSUMER_FOLD=0/1 forces it.
+bool consumer_fold(int B) {
+    static int v = -2;
+    if (v == -2) { const char* e = getenv("XFH_CONSUMER_FOLD"); v = e ? atoi(e) : -1; }
+    return v < 0 ? B <= 8 : v != 0;
+}
+// layers whose (only or first) consumer is a PRO_BN k_conv_mfma: all but block1.0/1.1 (-> k_conv_direct, which reads the
+// statistics through the scalar cache), block1.3 (-> k_b2in), block5.3 (-> k_fuse_in), heatmap_head.1 / keypoint_head.2 (-> heads)
+static bool folds_in_consumer(int li) { return li >= 2 && li != 3 && li != 15 && li != 19 && li != 22; }
+
 int conv_layer_npart(int li, int Hout, int Wout) {
     auto cdiv = [](int a, int b) { return (a + b - 1) / b; };
     if (li < 3) return cdiv(Wout, 16) * cdiv(Hout, 16);
@@ -420,6 +421,14 @@ hipError_t launch_basic_layer(xfh_ctx* c, int li, const float* in, size_t in_str
     a.bias = nullptr;
     a.out = c->raw[li]; a.out_stride = c->raw_stride[li]; a.Hout = Hout; a.Wout = Wout;
     a.part = c->part[li]; a.part_stride = c->part_stride[li];
+    const bool running = c->cfg.bn_mode == XFH_BN_RUNNING_STATS;
+    if (pro == PRO_BN && !running && consumer_fold(B)) {
+        for (int j = 0; j < XFH_NUM_LAYERS; ++j)
+            if (in_stat == c->stat[j] && folds_in_consumer(j)) {
+                a.in_part = c->part[j]; a.in_part_stride = c->part_stride[j]; a.in_npart = c->npart[j];
+                a.in_count = (double)c->lh[j] * (double)c->lw[j]; a.in_stat_out = c->stat[j];
+            }
+    }
     int np = 0;
     hipError_t e = hipSuccess;
     const bool bn = (pro == PRO_BN);
@@ -468,7 +477,8 @@ hipError_t launch_basic_layer(xfh_ctx* c, int li, const float* in, size_t in_str
     (void)bn;
     if (e != hipSuccess) return e;
     c->npart[li] = np;
-    if (c->cfg.bn_mode == XFH_BN_RUNNING_STATS) return hipGetLastError();       // statistics come from the weight file
+    if (running) return hipGetLastError();                                       // statistics come from the weight file
+    if (consumer_fold(B) && folds_in_consumer(li)) return hipGetLastError();     // the consuming convolution folds the partials itself
     hipLaunchKernelGGL(k_bn_finalize, dim3(B), dim3(256), 0, c->stream, (const double*)c->part[li], c->part_stride[li], np,
                        L.cout, (double)Hout * (double)Wout, c->stat[li]);
     return hipGetLastError();
@@ -481,6 +491,10 @@ hipError_t launch_fusion_out(xfh_ctx* c, int Hh, int Wh, int B) {
     a.w = c->w.fus2; a.bias = c->w.fus2_bias;
     a.out = c->feats; a.out_stride = c->raw_stride[17]; a.Hout = Hh; a.Wout = Wh;
     a.part = nullptr; a.part_stride = 0;
+    if (c->cfg.bn_mode != XFH_BN_RUNNING_STATS && consumer_fold(B)) {
+        a.in_part = c->part[17]; a.in_part_stride = c->part_stride[17]; a.in_npart = c->npart[17];
+        a.in_count = (double)Hh * (double)Wh; a.in_stat_out = c->stat[17];
+    }
     return conv_mfma_launch<64, 64, 1, 1, 4, 1, 2, 16, PRO_BN, EPI_BIAS>(c, a, B, nullptr, 23);
 }
 

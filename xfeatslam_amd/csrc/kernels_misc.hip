@@ -5,13 +5,14 @@
 //   k_b2in         x1 + skip1(x)                       (XFeat.cc:153)
 //   k_fuse_in      x3 + up(x4) + up(x5)                (XFeat.cc:159-166)
 //   k_feats_norm   F::normalize(M1, dim=1)             (XFextractor.cc:273)
-//   k_heads_final  heatmap_head.2 + sigmoid, keypoint_head.3 + softmax + depth-to-space
+//   k_heads_heat   heatmap_head.2 + sigmoid; k_heads_kp: keypoint_head.3 + softmax + depth-to-space
 //                  (XFeat.cc:81-82,89; XFextractor.cc:204-217)
 //   k_nms_score    5x5 NMS, threshold, nearest*bilinear score (XFextractor.cc:219-248, 280-282)
 //   k_select       top-k by (score desc, index asc), validity, lapping placement (:285-295, 310-343)
 //   k_desc         bilinear descriptor sampling + L2 normalise + record packing (:298-301, 323-343)
 // Compiled with -ffp-contract=off: every fused multiply-add below is written as fmaf().
 #include "ctx.h"
+#include <stdlib.h>
 
 // ---- small helpers -----------------------------------------------------------------------
 __device__ __forceinline__ double wave_sum(double v) {
@@ -182,71 +183,76 @@ void k_feats_norm(const float* __restrict__ feats, size_t stride, int npix, floa
     out[(size_t)b * stride + (size_t)pix * 64 + lane] = v / nrm;
 }
 
-// ---- k_heads_final: 128 pixels per workgroup, one pixel per lane -----------------------------
+// ---- k_heads_heat / k_heads_kp: 128 pixels per workgroup, one pixel per lane -----------------------------
 #define HF_PX 128
 #define HF_LD 129
+// heatmap head: 64 -> 1, sigmoid (XFeat.cc:81-82)
 __global__ __launch_bounds__(HF_PX)
-void k_heads_final(const float* __restrict__ rawH, const float* __restrict__ statH,     // heatmap_head.1
-                   const float* __restrict__ rawK, const float* __restrict__ statK,     // keypoint_head.2
-                   size_t raw_stride, const float* __restrict__ wh, const float* __restrict__ bh,
-                   const float* __restrict__ wk /* [64][68] */, const float* __restrict__ bk /* [65] */,
-                   int Hh, int Wh, float* __restrict__ H1, size_t h1_stride, float* __restrict__ K1h, size_t k1h_stride) {
+void k_heads_heat(const float* __restrict__ rawH, const float* __restrict__ statH,     // heatmap_head.1
+                  size_t raw_stride, const float* __restrict__ wh, const float* __restrict__ bh,
+                  int npix, float* __restrict__ H1, size_t h1_stride) {
+    __shared__ float sA[64 * HF_LD];
+    const int t = threadIdx.x, b = blockIdx.z;
+    const int p0 = blockIdx.x * HF_PX;
+    const int pix = p0 + t;
+    const float* st = statH + (size_t)b * 128;
+    for (int item = t; item < HF_PX * 16; item += HF_PX) {
+        const int lp = item >> 4, g = item & 15;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (p0 + lp < npix) v = ld_act4(rawH + (size_t)b * raw_stride, st, 64, (size_t)(p0 + lp), g);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sA[(g * 4 + j) * HF_LD + lp] = v[j];
+    }
+    __syncthreads();
+    float acc = 0.f;
+    for (int k = 0; k < 64; ++k) acc = fmaf(sA[k * HF_LD + t], wh[k], acc);
+    acc += bh[0];
+    if (pix < npix) H1[(size_t)b * h1_stride + pix] = 1.0f / (1.0f + expf(-acc));
+}
+
+// keypoint head: 64 -> 65, softmax, drop dustbin, depth-to-space (XFeat.cc:89, XFextractor.cc:204-217).
+// Runs on the ctx's second stream together with keypoint_head.0-2: the whole branch only depends on the
+// normalised image, not on the backbone.
+__global__ __launch_bounds__(HF_PX)
+void k_heads_kp(const float* __restrict__ rawK, const float* __restrict__ statK,      // keypoint_head.2
+                size_t raw_stride, const float* __restrict__ wk /* [64][68] */, const float* __restrict__ bk /* [65] */,
+                int Hh, int Wh, float* __restrict__ K1h, size_t k1h_stride) {
     __shared__ float sA[64 * HF_LD];
     const int t = threadIdx.x, b = blockIdx.z;
     const int npix = Hh * Wh, p0 = blockIdx.x * HF_PX;
     const int pix = p0 + t;
-    // ---- heatmap head: 64 -> 1, sigmoid (XFeat.cc:81-82)
-    {
-        const float* st = statH + (size_t)b * 128;
-        for (int item = t; item < HF_PX * 16; item += HF_PX) {
-            const int lp = item >> 4, g = item & 15;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (p0 + lp < npix) v = ld_act4(rawH + (size_t)b * raw_stride, st, 64, (size_t)(p0 + lp), g);
+    const float* st = statK + (size_t)b * 128;
+    for (int item = t; item < HF_PX * 16; item += HF_PX) {
+        const int lp = item >> 4, g = item & 15;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (p0 + lp < npix) v = ld_act4(rawK + (size_t)b * raw_stride, st, 64, (size_t)(p0 + lp), g);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) sA[(g * 4 + j) * HF_LD + lp] = v[j];
-        }
-        __syncthreads();
-        float acc = 0.f;
-        for (int k = 0; k < 64; ++k) acc = fmaf(sA[k * HF_LD + t], wh[k], acc);
-        acc += bh[0];
-        if (pix < npix) H1[(size_t)b * h1_stride + pix] = 1.0f / (1.0f + expf(-acc));
-        __syncthreads();
+        for (int j = 0; j < 4; ++j) sA[(g * 4 + j) * HF_LD + lp] = v[j];
     }
-    // ---- keypoint head: 64 -> 65, softmax, drop dustbin, depth-to-space (XFeat.cc:89, XFextractor.cc:204-217)
-    {
-        const float* st = statK + (size_t)b * 128;
-        for (int item = t; item < HF_PX * 16; item += HF_PX) {
-            const int lp = item >> 4, g = item & 15;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (p0 + lp < npix) v = ld_act4(rawK + (size_t)b * raw_stride, st, 64, (size_t)(p0 + lp), g);
+    __syncthreads();
+    float acc[65];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) sA[(g * 4 + j) * HF_LD + lp] = v[j];
-        }
-        __syncthreads();
-        float acc[65];
-#pragma unroll
-        for (int n = 0; n < 65; ++n) acc[n] = 0.f;
+    for (int n = 0; n < 65; ++n) acc[n] = 0.f;
 #pragma unroll 2
-        for (int k = 0; k < 64; ++k) {
-            const float a = sA[k * HF_LD + t];
-            const float* wr = wk + k * 68;                 // wave-uniform row: scalar loads
+    for (int k = 0; k < 64; ++k) {
+        const float a = sA[k * HF_LD + t];
+        const float* wr = wk + k * 68;                 // wave-uniform row: scalar loads
 #pragma unroll
-            for (int n = 0; n < 65; ++n) acc[n] = fmaf(a, wr[n], acc[n]);
-        }
-        float mx = -__builtin_huge_valf();
+        for (int n = 0; n < 65; ++n) acc[n] = fmaf(a, wr[n], acc[n]);
+    }
+    float mx = -__builtin_huge_valf();
 #pragma unroll
-        for (int n = 0; n < 65; ++n) { acc[n] += bk[n]; mx = fmaxf(mx, acc[n]); }
-        float sum = 0.f;
+    for (int n = 0; n < 65; ++n) { acc[n] += bk[n]; mx = fmaxf(mx, acc[n]); }
+    float sum = 0.f;
 #pragma unroll
-        for (int n = 0; n < 65; ++n) { acc[n] = expf(acc[n] - mx); sum += acc[n]; }
-        if (pix < npix) {
-            const int y = pix / Wh, x = pix % Wh;
-            float* o = K1h + (size_t)b * k1h_stride + (size_t)(8 * y) * (8 * Wh) + 8 * x;
+    for (int n = 0; n < 65; ++n) { acc[n] = expf(acc[n] - mx); sum += acc[n]; }
+    if (pix < npix) {
+        const int y = pix / Wh, x = pix % Wh;
+        float* o = K1h + (size_t)b * k1h_stride + (size_t)(8 * y) * (8 * Wh) + 8 * x;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                *(f32x4*)(o + (size_t)i * 8 * Wh) = f32x4{acc[i * 8] / sum, acc[i * 8 + 1] / sum, acc[i * 8 + 2] / sum, acc[i * 8 + 3] / sum};
-                *(f32x4*)(o + (size_t)i * 8 * Wh + 4) = f32x4{acc[i * 8 + 4] / sum, acc[i * 8 + 5] / sum, acc[i * 8 + 6] / sum, acc[i * 8 + 7] / sum};
-            }
+        for (int i = 0; i < 8; ++i) {
+            *(f32x4*)(o + (size_t)i * 8 * Wh) = f32x4{acc[i * 8] / sum, acc[i * 8 + 1] / sum, acc[i * 8 + 2] / sum, acc[i * 8 + 3] / sum};
+            *(f32x4*)(o + (size_t)i * 8 * Wh + 4) = f32x4{acc[i * 8 + 4] / sum, acc[i * 8 + 5] / sum, acc[i * 8 + 6] / sum, acc[i * 8 + 7] / sum};
         }
     }
 }
@@ -678,6 +684,30 @@ hipError_t run_extract(xfh_ctx* c, const uint8_t* d_gray, int B, int H0, int W0,
     hipLaunchKernelGGL(k_norm_aux, dim3((h4 * w4 + 255) / 256, 1, B), dim3(256), 0, s, c->X, xs, c->xstat, H, W,
                        c->xunfold, xs, c->skip_pool, xs / 16);
     CK(hipGetLastError());
+    bool use_aux = true;
+    // keypoint branch (keypoint_head.0-3 on unfold2d(x), softmax, depth-to-space) on the second stream: it only needs
+    // the normalised image, so it runs beside the backbone (memory-bound 1x1 layers next to MFMA-bound 3x3 layers)
+    {
+        static int two = -1;
+        if (two < 0) { const char* e = getenv("XFH_AUX_STREAM"); two = e ? atoi(e) : 1; }
+        use_aux = two != 0;
+        if (use_aux) {
+            CK(hipEventRecord(c->ev_fork, s));
+            CK(hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
+            c->stream = c->aux_stream;
+        }
+        hipError_t e = launch_basic_layer(c, 20, c->xunfold, xs, nullptr, PRO_PLAIN, h8, w8, B);
+        if (e == hipSuccess) e = launch_basic_layer(c, 21, c->raw[20], c->raw_stride[20], c->stat[20], PRO_BN, h8, w8, B);
+        if (e == hipSuccess) e = launch_basic_layer(c, 22, c->raw[21], c->raw_stride[21], c->stat[21], PRO_BN, h8, w8, B);
+        if (e == hipSuccess) {
+            launch_k(c, XFH_K_HEADS, -1, k_heads_kp, dim3((h8 * w8 + HF_PX - 1) / HF_PX, 1, B), dim3(HF_PX), 0,
+                     (const float*)c->raw[22], (const float*)c->stat[22], c->raw_stride[22], (const float*)c->w.kp3_w, (const float*)c->w.kp3_b, h8, w8, c->K1h, xs);
+            e = hipGetLastError();
+        }
+        c->stream = s;
+        CK(e);
+        if (use_aux) CK(hipEventRecord(c->ev_join, c->aux_stream));
+    }
     // block1
     CK(launch_basic_layer(c, 0, c->X, xs, c->xstat, PRO_IN, H, W, B));
     CK(launch_basic_layer(c, 1, c->raw[0], c->raw_stride[0], c->stat[0], PRO_BN, c->lh[0], c->lw[0], B));
@@ -714,14 +744,10 @@ hipError_t run_extract(xfh_ctx* c, const uint8_t* d_gray, int B, int H0, int W0,
     // heatmap head
     CK(launch_basic_layer(c, 18, c->feats, c->raw_stride[17], nullptr, PRO_PLAIN, h8, w8, B));
     CK(launch_basic_layer(c, 19, c->raw[18], c->raw_stride[18], c->stat[18], PRO_BN, h8, w8, B));
-    // keypoint head
-    CK(launch_basic_layer(c, 20, c->xunfold, xs, nullptr, PRO_PLAIN, h8, w8, B));
-    CK(launch_basic_layer(c, 21, c->raw[20], c->raw_stride[20], c->stat[20], PRO_BN, h8, w8, B));
-    CK(launch_basic_layer(c, 22, c->raw[21], c->raw_stride[21], c->stat[21], PRO_BN, h8, w8, B));
-    launch_k(c, XFH_K_HEADS, -1, k_heads_final, dim3((h8 * w8 + HF_PX - 1) / HF_PX, 1, B), dim3(HF_PX), 0,
-                       c->raw[19], c->stat[19], c->raw[22], c->stat[22], c->raw_stride[19], c->w.heat2_w, c->w.heat2_b,
-                       c->w.kp3_w, c->w.kp3_b, h8, w8, c->H1, xs / 64, c->K1h, xs);
+    hipLaunchKernelGGL(k_heads_heat, dim3((h8 * w8 + HF_PX - 1) / HF_PX, 1, B), dim3(HF_PX), 0, s,
+                       (const float*)c->raw[19], (const float*)c->stat[19], c->raw_stride[19], (const float*)c->w.heat2_w, (const float*)c->w.heat2_b, h8 * w8, c->H1, xs / 64);
     CK(hipGetLastError());
+    if (use_aux) CK(hipStreamWaitEvent(s, c->ev_join, 0));          // K1h of the keypoint branch
     // NMS + score, top-k + placement, descriptors
     launch_k(c, XFH_K_NMS, -1, k_nms_score, dim3(((W + NMS_TW - 1) / NMS_TW) * ((H + NMS_TH - 1) / NMS_TH), 1, B), dim3(256), 0, c->K1h, xs, c->H1, xs / 64,
                        H, W, c->cfg.nms_threshold, c->cand, c->cand_cap, c->cand_count);
