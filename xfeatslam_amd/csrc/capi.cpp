@@ -141,7 +141,7 @@ int xfh_destroy(xfh_ctx* c) {
     if (c->aux_stream) hipStreamSynchronize(c->aux_stream);
     auto F = [](void* p) { if (p) hipFree(p); };
     F(c->d_gray); F(c->X); F(c->pre_part); F(c->xstat);
-    for (int i = 0; i < XFH_NUM_LAYERS; ++i) { F(c->raw[i]); F(c->part[i]); F(c->stat[i]); F(c->w.mfma[i]); F(c->w.alt[i]); }
+    for (int i = 0; i < XFH_NUM_LAYERS; ++i) { F(c->raw[i]); F(c->part[i]); F(c->stat[i]); F(c->w.mfma[i]); F(c->w.alt[i]); F(c->w.alt2[i]); }
     for (int i = 0; i < 3; ++i) F(c->w.direct[i]);
     F(c->w.fus2); F(c->w.fus2_bias); F(c->w.skip_w); F(c->w.skip_b); F(c->w.heat2_w); F(c->w.heat2_b); F(c->w.kp3_w); F(c->w.kp3_b);
     F(c->skip_pool); F(c->xunfold); F(c->b2in); F(c->fuse_in); F(c->feats); F(c->m1n); F(c->H1); F(c->K1h);
@@ -225,6 +225,8 @@ int xfh_load_weights(xfh_ctx* c, const void* blob, size_t nbytes) {
             rc = upload(c, &c->w.mfma[i], pack_mfma(e.p, L.cout, L.cin, L.ks, coutp));
             if (rc == XFH_OK && L.ks == 3 && L.cin >= 64 && L.stride == 1 && i != 10 && i != 11)       // 7, 16, 17 and 13, 14: 32-channel chunks
                 rc = upload(c, &c->w.alt[i], pack_mfma(e.p, L.cout, L.cin, L.ks, coutp, 32));
+            if (rc == XFH_OK && L.ks == 3 && L.cin == 64 && L.cout == 64 && L.stride == 1)                 // 7, 10, 11, 16, 17: three taps per chunk
+                rc = upload(c, &c->w.alt2[i], pack_mfma(e.p, L.cout, L.cin, L.ks, coutp, 64, 3));
             if (rc == XFH_OK && i == 3)                                                                // block1.3: all nine taps in one chunk
                 rc = upload(c, &c->w.alt[i], pack_mfma(e.p, L.cout, L.cin, L.ks, coutp, 64, 9));
         }

@@ -8,6 +8,7 @@
 struct DevWeights {
     float* direct[3] = {nullptr, nullptr, nullptr};            // layers 0..2: [ky][kx][ci][co]
     float* mfma[XFH_NUM_LAYERS] = {};                          // layers 3..22: [chunk][n][CB], k-permuted
+    float* alt2[XFH_NUM_LAYERS] = {};                          // third packing: three taps per chunk (small-batch configurations)
     float* alt[XFH_NUM_LAYERS] = {};                           // second packing of some layers (32-channel chunks / all taps in one chunk), see launch_basic_layer
     float* fus2 = nullptr;                                     // block_fusion.2 packed like an MFMA layer
     float* fus2_bias = nullptr;                                // [64]

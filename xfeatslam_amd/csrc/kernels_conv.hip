@@ -378,6 +378,13 @@ static hipError_t conv_direct_launch(xfh_ctx* c, const ConvArgs& a, int B, int* 
 
 // number of statistic partials a layer produces per frame (needed to size buffers up front)
 // tile configuration of the 3x3 64->64 layers at 1/8 resolution (see launch_basic_layer)
+// single-frame tile configurations (latency path; measured 0.492 -> 0.477 ms at B = 1, slower from B = 2 on).
+// XFH_SMALL_BATCH=0/1 forces it
+static bool small_batch(int B) {
+    static int v = -2;
+    if (v == -2) { const char* e = getenv("XFH_SMALL_BATCH"); v = e ? atoi(e) : -1; }
+    return v < 0 ? B == 1 : v != 0;
+}
 static int conv_cfg() {
     static int v = -1;
     if (v < 0) { const char* e = getenv("XFH_CONV_CFG"); v = e ? atoi(e) : 1; }
@@ -401,7 +408,7 @@ int conv_layer_npart(int li, int Hout, int Wout) {
     auto cdiv = [](int a, int b) { return (a + b - 1) / b; };
     if (li < 3) return cdiv(Wout, 16) * cdiv(Hout, 16);
     switch (li) {
-        case 7: case 16: case 17: return cdiv(Wout, 16) * cdiv(Hout, 8);     // 8x16 pixels in both configurations
+        case 7: case 16: case 17: return cdiv(Wout, 16) * cdiv(Hout, 2);     // 8x16 pixels; 2x16 in the small-batch configuration (the larger count sizes the buffers)
         case 9: case 10: case 11: return cdiv(Wout, 8) * cdiv(Hout, 8);      // WM=2, WW=8
         case 12: case 13: case 14: case 15: return cdiv(Wout, 8) * cdiv(Hout, 4);   // WM=1, WW=8
         default: return cdiv(Wout, 16) * cdiv(Hout, 8);                       // WM=4, WW=16
@@ -448,7 +455,15 @@ hipError_t launch_basic_layer(xfh_ctx* c, int li, const float* in, size_t in_str
             // the dominant 3x3 64->64 instance: 8x16 pixels x 64 channels per workgroup, 8 waves (4 x 2),
             // 32-channel weight chunks (67 KB LDS -> 2 workgroups per CU); measured 70 us vs 77 us for the
             // 4-wave / 64-channel-chunk form at B = 16 (profiles/r01_conv_cfg.log).  XFH_CONV_CFG=0 selects the latter.
+            // Single frame (40 workgroups cannot fill 256 CUs, and with one wave per SIMD the K loop waits on each of the
+            // 18 weight chunks): 2x16 pixels per workgroup, 2 waves, three taps per chunk (6 chunks).
             const int cfg = conv_cfg();
+            if (small_batch(B)) {
+                a.w = c->w.alt2[li];
+                if (li == 16) e = conv_mfma_launch<64, 64, 3, 1, 1, 2, 1, 16, PRO_PLAIN, EPI_STATS, 64, 3>(c, a, B, &np, li);
+                else e = conv_mfma_launch<64, 64, 3, 1, 1, 2, 1, 16, PRO_BN, EPI_STATS, 64, 3>(c, a, B, &np, li);
+                break;
+            }
             if (cfg != 0) a.w = c->w.alt[li];
             if (li == 16) {                                                                                     // input = fuse_in
                 if (cfg != 0) e = conv_mfma_launch<64, 64, 3, 1, 4, 2, 1, 16, PRO_PLAIN, EPI_STATS, 32>(c, a, B, &np, li);
@@ -461,10 +476,13 @@ hipError_t launch_basic_layer(xfh_ctx* c, int li, const float* in, size_t in_str
         }
         case 8: e = conv_mfma_launch<64, 64, 1, 1, 4, 1, 2, 16, PRO_BN, EPI_STATS>(c, a, B, &np, li); break;
         case 9: e = conv_mfma_launch<64, 64, 3, 2, 2, 2, 1, 8, PRO_BN, EPI_STATS>(c, a, B, &np, li); break;
-        case 10: case 11: e = conv_mfma_launch<64, 64, 3, 1, 2, 2, 1, 8, PRO_BN, EPI_STATS>(c, a, B, &np, li); break;
+        case 10: case 11:
+            if (small_batch(B)) { a.w = c->w.alt2[li]; e = conv_mfma_launch<64, 64, 3, 1, 2, 2, 1, 8, PRO_BN, EPI_STATS, 64, 3>(c, a, B, &np, li); }   // three taps per chunk
+            else e = conv_mfma_launch<64, 64, 3, 1, 2, 2, 1, 8, PRO_BN, EPI_STATS>(c, a, B, &np, li);
+            break;
         case 12: e = conv_mfma_launch<64, 128, 3, 2, 1, 4, 1, 8, PRO_BN, EPI_STATS>(c, a, B, &np, li); break;
         case 13: case 14:       // 32-channel weight chunks: 69 KB LDS -> 2 workgroups per CU, 58 -> 50 us at B = 32; XFH_CONV_CFG=0: 64-channel chunks
-            if (conv_cfg()) { a.w = c->w.alt[li]; e = conv_mfma_launch<128, 128, 3, 1, 1, 4, 1, 8, PRO_BN, EPI_STATS, 32>(c, a, B, &np, li); }
+            if (conv_cfg() && !small_batch(B)) { a.w = c->w.alt[li]; e = conv_mfma_launch<128, 128, 3, 1, 1, 4, 1, 8, PRO_BN, EPI_STATS, 32>(c, a, B, &np, li); }
             else e = conv_mfma_launch<128, 128, 3, 1, 1, 4, 1, 8, PRO_BN, EPI_STATS>(c, a, B, &np, li);
             break;
         case 15: e = conv_mfma_launch<128, 64, 1, 1, 1, 2, 1, 8, PRO_BN, EPI_STATS>(c, a, B, &np, li); break;
