@@ -82,16 +82,19 @@ def test_stage_tensors_match_oracle(gpu_lib, oracle_mod, weights_std):
     ctx.close()
 
 
-def test_batch_is_per_frame(gpu_lib, oracle_mod, weights_dense):
+@pytest.mark.parametrize("nb", [5, 12])
+def test_batch_is_per_frame(gpu_lib, oracle_mod, weights_dense, nb):
     """frames in one batch are normalised with their OWN statistics (the reference is always B=1):
-    a batched call equals single-frame calls bit for bit, and is deterministic run to run"""
+    a batched call equals single-frame calls bit for bit, and is deterministic run to run.  The three
+    batch regimes use different kernels / tilings (B = 1: single-frame tiles; B <= 8: statistics folded
+    by the consuming convolution; B > 8: k_bn_finalize) and must agree bit for bit."""
     _, blob = weights_dense
-    fr = synth.frames(5, 96, 160, seed=11)
+    fr = synth.frames(nb, 96, 160, seed=11)
     fr[3] = 200                                              # a constant frame in the middle of the batch
-    ctx = _ctx(200, 96, 160, B=5); ctx.load_weights(blob)
+    ctx = _ctx(200, 96, 160, B=nb); ctx.load_weights(blob)
     batch = ctx.extract_batch(fr, (0, 50))
     again = ctx.extract_batch(fr, (0, 50))
-    for b in range(5):
+    for b in range(nb):
         single, = ctx.extract_batch(fr[b:b + 1], (0, 50))
         for x, y, z in zip(batch[b], single, again[b]):
             assert np.array_equal(x, y) and np.array_equal(x, z)
