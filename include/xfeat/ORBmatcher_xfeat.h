@@ -6,6 +6,8 @@
  *   void match(cv::Mat d1, cv::Mat d2, std::vector<cv::DMatch>& out)    -- declared :77, the
  *        definition is commented out in the reference (ORBmatcher.cc:340-405); this supplies it.
  *   TH_LOW / TH_HIGH                                                    -- ORBmatcher.cc:34-35
+ *   best2 / distinctive: the batched inner loops of SearchBy* (ORBmatcher.cc:75-119) and of
+ *        MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:329-403)
  *
  * Drop the two member definitions into src/ORBmatcher.cc or use this
  * class directly.  Without OpenCV the cvlite mirrors of XFextractor.h are used.
@@ -72,6 +74,19 @@ public:
         const int rc = xfh_best2_csr(ctx, queries.template ptr<float>(0), nq, targets.template ptr<float>(0), targets.rows,
                                      offsets.data(), indices.data(), initDist, bestIdx.data(), bestDist.data(), secondIdx.data(), secondDist.data());
         if (rc != XFH_OK) throw std::runtime_error(std::string("XFmatcher::best2: ") + xfh_strerror(rc));
+    }
+
+    // MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:329-403), batched over map points: group g observes the
+    // rows indices[offsets[g] .. offsets[g+1]) of `table`; bestPos[g] = position in the group of the descriptor with
+    // the least median DescriptorDistance to the others (-1 for an empty group), bestMedian[g] = that median.
+    void distinctive(const Mat& table, const std::vector<int>& offsets, const std::vector<int>& indices,
+                     std::vector<int>& bestPos, std::vector<int>& bestMedian) {
+        const int ng = offsets.empty() ? 0 : (int)offsets.size() - 1;
+        bestPos.assign(ng, -1); bestMedian.assign(ng, 0x7fffffff);
+        if (ng == 0) return;
+        const int rc = xfh_distinctive_csr(ctx, table.template ptr<float>(0), table.rows, offsets.data(), indices.data(), ng,
+                                           bestPos.data(), bestMedian.data());
+        if (rc != XFH_OK) throw std::runtime_error(std::string("XFmatcher::distinctive: ") + xfh_strerror(rc));
     }
 
 protected:

@@ -149,6 +149,18 @@ int xfh_best2_csr_device(xfh_ctx* ctx, const float* d_queries, int nq, const flo
                          const int* d_offsets, const int* d_indices, int init_dist,
                          int* d_best_idx, int* d_best_dist, int* d_second_idx, int* d_second_dist);
 
+/* MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:329-403), batched over map points: group g observes the
+ * descriptor rows indices[offsets[g] .. offsets[g+1]) of `table` (n_rows x 64).  Pairwise DescriptorDistance inside
+ * the group (diagonal 0), per row the median sorted[(N-1)/2], and the FIRST row with the least median wins:
+ * best_pos[g] = its position inside the group, best_median[g] = that median; an empty group gives -1 / INT_MAX
+ * (the reference returns without touching mDescriptor).  Groups may hold at most XFH_MAX_GROUP rows.
+ * All pointers host memory (the _device variant: device memory, asynchronous, max_group = largest group size). */
+#define XFH_MAX_GROUP 256
+int xfh_distinctive_csr(xfh_ctx* ctx, const float* table, int n_rows, const int* offsets, const int* indices, int n_groups,
+                        int* best_pos, int* best_median);
+int xfh_distinctive_csr_device(xfh_ctx* ctx, const float* d_table, int n_rows, const int* d_offsets, const int* d_indices,
+                               int n_groups, int max_group, int* d_best_pos, int* d_best_median);
+
 /* ---- plumbing ----------------------------------------------------------------------- */
 int xfh_synchronize(xfh_ctx* ctx);
 /* run the ctx on an externally owned hipStream_t (e.g. torch's current stream); NULL
@@ -173,7 +185,7 @@ int xfh_memcpy_d2h(void* dst, const void* src, size_t nbytes);
 enum {
     XFH_K_NONE = 0, XFH_K_MNN_GEMM = 1, XFH_K_CONV_MFMA = 2, XFH_K_CONV_DIRECT = 3,
     XFH_K_NMS = 4, XFH_K_SELECT = 5, XFH_K_DESC = 6, XFH_K_HEADS = 7, XFH_K_DIST_I32 = 8,
-    XFH_K_PREPROC = 9, XFH_K_BEST2 = 10, XFH_K_COUNT = 11
+    XFH_K_PREPROC = 9, XFH_K_BEST2 = 10, XFH_K_DISTINCTIVE = 11, XFH_K_COUNT = 12
 };
 /* layer_mask selects conv layers for XFH_K_CONV_*: 0 = every layer, else bit i = BasicLayer i
  * (0..22 in XFeatModel order) and bit 23 = block_fusion.2 */

@@ -53,6 +53,7 @@ def lib():
         L.xfo_distance_i32.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         L.xfo_descriptor_distance.argtypes = [C.c_void_p, C.c_void_p]
         L.xfo_best2_csr.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 4
+        L.xfo_distinctive_csr.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -134,3 +135,13 @@ def best2_csr(queries, targets, offsets, indices, init_dist: int = 256):
     out = [np.zeros(max(len(q), 1), np.int32) for _ in range(4)]
     lib().xfo_best2_csr(q.ctypes.data, len(q), tg.ctypes.data, off.ctypes.data, ind.ctypes.data, int(init_dist), *[o.ctypes.data for o in out])
     return tuple(o[:len(q)] for o in out)
+
+
+def distinctive_csr(table, offsets, indices):
+    """MapPoint::ComputeDistinctiveDescriptors over CSR groups -> (best position in group, its median distance)"""
+    tb = np.ascontiguousarray(table, np.float32)
+    off = np.ascontiguousarray(offsets, np.int32); ind = np.ascontiguousarray(indices, np.int32)
+    ng = len(off) - 1
+    pos = np.zeros(max(ng, 1), np.int32); med = np.zeros(max(ng, 1), np.int32)
+    lib().xfo_distinctive_csr(tb.ctypes.data, off.ctypes.data, ind.ctypes.data, ng, pos.ctypes.data, med.ctypes.data)
+    return pos[:ng], med[:ng]

@@ -612,6 +612,38 @@ int xfo_best2_csr(const float* q, int nq, const float* tg, const int* offsets, c
     return 0;
 }
 
+/* MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:329-403), one call per group: group g observes the
+ * descriptor rows indices[offsets[g] .. offsets[g+1]) of `table`.  :372-385 pairwise DescriptorDistance (diagonal 0),
+ * :388-401 per row: sort, median = sorted[0.5*(N-1)] (truncated), strict '<' keeps the first row with the least
+ * median.  Empty group: the reference returns without touching mDescriptor (:383-384) -> -1 / INT_MAX here. */
+static int cmp_int(const void* a, const void* b) { const int x = *(const int*)a, y = *(const int*)b; return (x > y) - (x < y); }
+int xfo_distinctive_csr(const float* table, const int* offsets, const int* indices, int n_groups, int* best_pos, int* best_median) {
+    for (int g = 0; g < n_groups; ++g) {
+        const int beg = offsets[g], N = offsets[g + 1] - beg;
+        best_pos[g] = -1; best_median[g] = 0x7fffffff;
+        if (N <= 0) continue;
+        int* D = (int*)malloc(sizeof(int) * (size_t)N * N);
+        int* v = (int*)malloc(sizeof(int) * (size_t)N);
+        for (int i = 0; i < N; ++i) {
+            D[(size_t)i * N + i] = 0;
+            for (int j = i + 1; j < N; ++j) {
+                const int d = xfo_descriptor_distance(table + (size_t)indices[beg + i] * 64, table + (size_t)indices[beg + j] * 64);
+                D[(size_t)i * N + j] = d; D[(size_t)j * N + i] = d;
+            }
+        }
+        int BestMedian = 0x7fffffff, BestIdx = 0;
+        for (int i = 0; i < N; ++i) {
+            memcpy(v, D + (size_t)i * N, sizeof(int) * (size_t)N);
+            qsort(v, (size_t)N, sizeof(int), cmp_int);
+            const int median = v[(size_t)(0.5 * (N - 1))];
+            if (median < BestMedian) { BestMedian = median; BestIdx = i; }
+        }
+        best_pos[g] = BestIdx; best_median[g] = BestMedian;
+        free(D); free(v);
+    }
+    return 0;
+}
+
 int xfo_match_mnn(const float* d1, int n1, const float* d2, int n2, float min_cossim,
                   int* idx1, int* idx2, float* dist, int* n_matches) {
     /* src/ORBmatcher.cc:358-359 normalise rows */

@@ -91,6 +91,10 @@ int xfo_descriptor_distance(const float* a, const float* b);
 int xfo_best2_csr(const float* q, int nq, const float* tg, const int* offsets, const int* indices, int init_dist,
                   int* best_idx, int* best_dist, int* second_idx, int* second_dist);
 
+/* MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:329-403) over CSR groups of descriptor rows:
+ * position inside the group of the descriptor with the least median distance to the others, and that median */
+int xfo_distinctive_csr(const float* table, const int* offsets, const int* indices, int n_groups, int* best_pos, int* best_median);
+
 #ifdef __cplusplus
 }
 #endif

@@ -42,6 +42,11 @@ int main(int argc, char** argv) {
         if (!desc.empty()) {
             const int d = XFmatcher::DescriptorDistance(desc, desc);
             if (d != 0) return 5;
+            // the batched map-point primitives compile and answer through the wrapper: one group {0, 0, 1} -> the
+            // duplicated row 0 has median distance 0 and comes first
+            std::vector<int> off = {0, 3}, ind = {0, 0, 1}, pos, med;
+            matcher.distinctive(desc, off, ind, pos, med);
+            if (pos.size() != 1 || pos[0] != 0 || med[0] != 0) return 6;
         }
     } catch (const std::exception& e) {
         fprintf(stderr, "exception: %s\n", e.what());

@@ -148,3 +148,24 @@ def test_best2_csr_matches_oracle(mctx, oracle_mod):
     off = np.array([0, 2, 2, 3, 4], np.int32); ind = np.array([0, 9, 1, 2], np.int32)
     o = [np.zeros(4, np.int32) for _ in range(4)]
     assert L.xfh_best2_csr(mctx.h, q.ctypes.data, 4, tg.ctypes.data, 8, off.ctypes.data, ind.ctypes.data, 256, *[x.ctypes.data for x in o]) == 1
+
+
+def test_distinctive_csr_matches_oracle(mctx, oracle_mod):
+    """MapPoint::ComputeDistinctiveDescriptors batched over map points -- integer work: bit exact"""
+    rng = np.random.RandomState(8)
+    tb, _ = synth.descriptor_sets(2000, 1, noise=0.3)
+    tb[11] = tb[4]; tb[12] = tb[4]; tb[100:110] = 0            # duplicates and zero-padded rows
+    counts = np.concatenate([[0, 1, 2, 3, 63, 64, 65, 128, 200, 256], rng.randint(0, 40, 500)]).astype(np.int32)
+    off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    ind = rng.randint(0, 2000, off[-1]).astype(np.int32)
+    ind[off[3]:off[3] + 3] = [4, 11, 12]
+    a = oracle_mod.distinctive_csr(tb, off, ind)
+    b = mctx.distinctive_csr(tb, off, ind)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert b[0][0] == -1 and b[1][0] == 0x7fffffff and b[0][1] == 0 and b[1][1] == 0
+    # groups above XFH_MAX_GROUP and out-of-range rows are rejected on the host
+    L = capi.lib()
+    off2 = np.array([0, 257], np.int32); ind2 = np.zeros(257, np.int32); o = [np.zeros(1, np.int32) for _ in range(2)]
+    assert L.xfh_distinctive_csr(mctx.h, tb.ctypes.data, 2000, off2.ctypes.data, ind2.ctypes.data, 1, o[0].ctypes.data, o[1].ctypes.data) == 1
+    off3 = np.array([0, 2], np.int32); ind3 = np.array([0, 2000], np.int32)
+    assert L.xfh_distinctive_csr(mctx.h, tb.ctypes.data, 2000, off3.ctypes.data, ind3.ctypes.data, 1, o[0].ctypes.data, o[1].ctypes.data) == 1

@@ -25,7 +25,7 @@ STATUS = {0: "OK", 1: "INVALID_ARG", 2: "EMPTY_IMAGE", 3: "BAD_SIZE", 4: "NO_WEI
 ERR_EMPTY_IMAGE = 2
 ERR_NO_DEVICE = 7
 
-K = dict(NONE=0, MNN_GEMM=1, CONV_MFMA=2, CONV_DIRECT=3, NMS=4, SELECT=5, DESC=6, HEADS=7, DIST_I32=8, PREPROC=9, BEST2=10)
+K = dict(NONE=0, MNN_GEMM=1, CONV_MFMA=2, CONV_DIRECT=3, NMS=4, SELECT=5, DESC=6, HEADS=7, DIST_I32=8, PREPROC=9, BEST2=10, DISTINCTIVE=11)
 T = dict(X=0, XSTAT=1, SKIP_POOL=2, XUNFOLD=3, B2IN=4, FUSE_IN=5, FEATS=6, M1N=7, H1=8, K1H=9, RAW0=16, STAT0=48, SEL=80)
 
 
@@ -58,6 +58,8 @@ SYMBOLS = [
     ("xfh_distance_i32_device", _i, [_vp, _vp, _i, _vp, _i, _vp]),
     ("xfh_best2_csr", _i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     ("xfh_best2_csr_device", _i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    ("xfh_distinctive_csr", _i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp]),
+    ("xfh_distinctive_csr_device", _i, [_vp, _vp, _i, _vp, _vp, _i, _i, _vp, _vp]),
     ("xfh_synchronize", _i, [_vp]),
     ("xfh_set_stream", _i, [_vp, _vp]),
     ("xfh_strerror", C.c_char_p, [_i]),

@@ -36,7 +36,7 @@ const char* xfh_strerror(int s) {
 
 const char* xfh_kernel_name(int id) {
     static const char* n[XFH_K_COUNT] = {"none", "k_mnn_gemm", "k_conv_mfma", "k_conv_direct", "k_nms_score", "k_select",
-                                         "k_desc", "k_heads_kp", "k_dist_i32", "k_preproc", "k_best2_csr"};
+                                         "k_desc", "k_heads_kp", "k_dist_i32", "k_preproc", "k_best2_csr", "k_distinctive_csr"};
     return (id >= 0 && id < XFH_K_COUNT) ? n[id] : "?";
 }
 
@@ -469,6 +469,50 @@ int xfh_best2_csr(xfh_ctx* c, const float* q, int nq, const float* tg, int nt, c
     HIPCK(c, hipMemcpyAsync(best_dist, o1, (size_t)nq * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipMemcpyAsync(second_idx, o2, (size_t)nq * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipMemcpyAsync(second_dist, o3, (size_t)nq * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return XFH_OK;
+}
+
+int xfh_distinctive_csr_device(xfh_ctx* c, const float* table, int n_rows, const int* offsets, const int* indices, int n_groups,
+                               int max_group, int* best_pos, int* best_median) {
+    if (!c || n_rows < 0 || n_groups < 0 || max_group < 0 || max_group > XFH_MAX_GROUP) return XFH_ERR_INVALID_ARG;
+    if (n_groups == 0) return XFH_OK;
+    if (!offsets || !best_pos || !best_median || (max_group > 0 && (!table || !indices))) return XFH_ERR_INVALID_ARG;
+    if (((uintptr_t)table) & 15) return XFH_ERR_INVALID_ARG;
+    HIPCK(c, hipSetDevice(c->cfg.device));
+    HIPCK(c, launch_distinctive(c, table, offsets, indices, n_groups, max_group, best_pos, best_median));
+    return XFH_OK;
+}
+
+int xfh_distinctive_csr(xfh_ctx* c, const float* table, int n_rows, const int* offsets, const int* indices, int n_groups,
+                        int* best_pos, int* best_median) {
+    if (!c || n_rows < 0 || n_groups < 0) return XFH_ERR_INVALID_ARG;
+    if (n_groups == 0) return XFH_OK;
+    if (!offsets || !best_pos || !best_median) return XFH_ERR_INVALID_ARG;
+    const int nnz = offsets[n_groups];
+    if (nnz < 0 || (nnz > 0 && (!indices || !table))) return XFH_ERR_INVALID_ARG;
+    int max_group = 0;
+    for (int g = 0; g < n_groups; ++g) {
+        if (offsets[g] > offsets[g + 1] || offsets[g] < 0) return XFH_ERR_INVALID_ARG;
+        if (offsets[g + 1] - offsets[g] > max_group) max_group = offsets[g + 1] - offsets[g];
+    }
+    if (max_group > XFH_MAX_GROUP) return XFH_ERR_INVALID_ARG;
+    for (int p = 0; p < nnz; ++p) if (indices[p] < 0 || indices[p] >= n_rows) return XFH_ERR_INVALID_ARG;
+    HIPCK(c, hipSetDevice(c->cfg.device));
+    MatchWs& w = c->mws;
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t bt = al((size_t)n_rows * 256 + 16), bo = al((size_t)(n_groups + 1) * 4), bi = al((size_t)nnz * 4 + 16), br = al((size_t)n_groups * 4);
+    int rc = grow(c, &w.b2_buf, &w.cap_b2, bt + bo + bi + 2 * br);
+    if (rc != XFH_OK) return rc;
+    char* p0 = (char*)w.b2_buf;
+    float* dt = (float*)p0; int* doff = (int*)(p0 + bt); int* dind = (int*)(p0 + bt + bo);
+    int* o0 = (int*)(p0 + bt + bo + bi); int* o1 = (int*)((char*)o0 + br);
+    if (n_rows > 0) HIPCK(c, hipMemcpyAsync(dt, table, (size_t)n_rows * 256, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(doff, offsets, (size_t)(n_groups + 1) * 4, hipMemcpyHostToDevice, c->stream));
+    if (nnz > 0) HIPCK(c, hipMemcpyAsync(dind, indices, (size_t)nnz * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, launch_distinctive(c, dt, doff, dind, n_groups, max_group, o0, o1));
+    HIPCK(c, hipMemcpyAsync(best_pos, o0, (size_t)n_groups * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipMemcpyAsync(best_median, o1, (size_t)n_groups * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));
     return XFH_OK;
 }

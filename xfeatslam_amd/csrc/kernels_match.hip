@@ -9,6 +9,7 @@
 //   k_mnn_final   : ordered compaction and distances (:371-403).
 //   k_dist_i32    : dense (int)(512 * ||a-b||^2), ORBmatcher::DescriptorDistance (:2246-2247).
 //   k_best2_csr   : best / second-best distance over candidate lists (the SearchBy* inner loop, :75-119).
+//   k_distinctive_csr : MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:329-403), one wave per map point.
 //
 // Numerics: normalised rows and the 64-term dot products are bit-identical to the oracle
 // (fp64 sum of squares -> fp32 sqrt/max/div; one fp32 fma chain in k order, which is what
@@ -447,6 +448,72 @@ hipError_t launch_best2(xfh_ctx* c, const float* q, int nq, const float* tg, con
     if (nq <= 0) return hipSuccess;
     launch_k(c, XFH_K_BEST2, -1, k_best2_csr, dim3((nq + 3) / 4), dim3(256), 0, q, nq, tg, offsets, indices, init_dist,
              best_idx, best_dist, second_idx, second_dist);
+    return hipGetLastError();
+}
+
+// ---- k_distinctive_csr: MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:329-403), batched -------
+// One wave per group (map point).  Rows are taken 64 at a time, lane = row: the lane keeps its descriptor in
+// registers and walks the group (row j comes through the scalar cache), storing the exact integer distances of
+// its row in LDS; the median sorted[(N-1)/2] is then found by rank counting (distances are small integers, N is
+// the number of observations of a map point, typically < 30), and a (median, row) key minimum over the wave
+// keeps the FIRST row with the least median (:392-400, strict '<').
+__global__ __launch_bounds__(64)
+void k_distinctive_csr(const float* __restrict__ table, const int* __restrict__ offsets, const int* __restrict__ indices,
+                       int n_groups, int ldn, int* __restrict__ best_pos, int* __restrict__ best_median) {
+    extern __shared__ int sd[];                        // [64][ldn], ldn odd
+    const int g = blockIdx.x, lane = threadIdx.x;
+    const int beg = offsets[g], N = offsets[g + 1] - beg;
+    if (N <= 0) { if (lane == 0) { best_pos[g] = -1; best_median[g] = 0x7fffffff; } return; }
+    const int k = (N - 1) / 2;                         // (size_t)(0.5 * (N - 1)), :394
+    u64 best = ~0ull;
+    int* row = sd + lane * ldn;
+    for (int r0 = 0; r0 < N; r0 += 64) {
+        const int i = r0 + lane;
+        if (i < N) {
+            f32x4 a[16];
+            const f32x4* ar = (const f32x4*)(table + (size_t)indices[beg + i] * 64);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) a[q] = ar[q];
+            for (int j = 0; j < N; ++j) {
+                const f32x4* br = (const f32x4*)(table + (size_t)indices[beg + j] * 64);      // wave-uniform
+                double acc = 0.0;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const f32x4 bv = br[q];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const double df = (double)(a[q][e] - bv[e]); acc = fma(df, df, acc); }
+                }
+                const float nd = (float)acc;
+                row[j] = (j == i) ? 0 : (int)(nd * 512.0f);                                    // :375, DescriptorDistance
+            }
+            int med = 0;
+            for (int j = 0; j < N; ++j) {
+                const int v = row[j];
+                int less = 0, leq = 0;
+                for (int m = 0; m < N; ++m) { const int x = row[m]; less += x < v ? 1 : 0; leq += x <= v ? 1 : 0; }
+                if (less <= k && k < leq) med = v;
+            }
+            const u64 key = ((u64)(unsigned)med << 32) | (u64)(unsigned)i;
+            best = key < best ? key : best;
+        }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { const u64 o = __shfl_xor(best, m); best = o < best ? o : best; }
+    if (lane == 0) { best_pos[g] = (int)(best & 0xFFFFFFFFull); best_median[g] = (int)(best >> 32); }
+}
+
+hipError_t launch_distinctive(xfh_ctx* c, const float* table, const int* offsets, const int* indices, int n_groups, int max_group,
+                              int* best_pos, int* best_median) {
+    if (n_groups <= 0) return hipSuccess;
+    const int ldn = (max_group < 1 ? 1 : max_group) | 1;
+    const size_t lds = (size_t)64 * ldn * sizeof(int);
+    static size_t attr = 0;
+    if (lds > attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_distinctive_csr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)64 * (XFH_MAX_GROUP | 1) * sizeof(int)));
+        if (e != hipSuccess) return e;
+        attr = (size_t)64 * (XFH_MAX_GROUP | 1) * sizeof(int);
+    }
+    launch_k(c, XFH_K_DISTINCTIVE, -1, k_distinctive_csr, dim3(n_groups), dim3(64), lds, table, offsets, indices, n_groups, ldn, best_pos, best_median);
     return hipGetLastError();
 }
 

@@ -106,6 +106,16 @@ class Context:
                                   *[o.ctypes.data for o in out]), self.h)
         return tuple(o[:nq] for o in out)
 
+    def distinctive_csr(self, table, offsets, indices):
+        """MapPoint::ComputeDistinctiveDescriptors over CSR groups of descriptor rows ->
+        (position inside the group of the descriptor with the least median distance, that median)"""
+        tb = np.ascontiguousarray(table, np.float32)
+        off = np.ascontiguousarray(offsets, np.int32); ind = np.ascontiguousarray(indices, np.int32)
+        ng = len(off) - 1
+        pos = np.zeros(max(ng, 1), np.int32); med = np.zeros(max(ng, 1), np.int32)
+        check(lib().xfh_distinctive_csr(self.h, tb.ctypes.data, len(tb), off.ctypes.data, ind.ctypes.data, ng, pos.ctypes.data, med.ctypes.data), self.h)
+        return pos[:ng], med[:ng]
+
     # -- timing ---------------------------------------------------------------------------
     def timing_enable(self, kernel_id: int, layer_mask: int = 0):
         check(lib().xfh_timing_enable(self.h, kernel_id, layer_mask), self.h)
