@@ -73,5 +73,18 @@ inline void launch_k(xfh_ctx* c, int kernel_id, int layer, K kern, dim3 grid, di
     else hipLaunchKernelGGL(kern, grid, block, shmem, c->stream, args...);
 }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: remember per kernel which devices have it
+// (one 64-bit mask per call site; device ids < 64)
+#define XFH_SET_LDS_ATTR_ONCE(c, kern, bytes)                                                                   \
+    do {                                                                                                       \
+        static unsigned long long done_mask_ = 0ull;                                                           \
+        const unsigned long long bit_ = 1ull << ((c)->cfg.device & 63);                                        \
+        if (!(done_mask_ & bit_)) {                                                                            \
+            hipError_t e_ = hipFuncSetAttribute((const void*)(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
+            if (e_ != hipSuccess) return e_;                                                                   \
+            done_mask_ |= bit_;                                                                                \
+        }                                                                                                      \
+    } while (0)
+
 // launchers (kernels_*.hip)
 hipError_t run_extract(xfh_ctx* c, const uint8_t* d_gray, int B, int H0, int W0, int lap0, int lap1, uint8_t* d_records);

@@ -356,12 +356,7 @@ static hipError_t conv_mfma_launch(xfh_ctx* c, const ConvArgs& a, int B, int* np
     const int ntile = aa.tiles_x * tiles_y;
     if (npart_out) *npart_out = ntile;
     auto kern = k_conv_mfma<CIN, COUT, KS, ST, WM, WN, NT, WW, PRO, EPI, CBMAX, TPC>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    XFH_SET_LDS_ATTR_ONCE(c, kern, LDS);
     launch_k(c, XFH_K_CONV_MFMA, layer, kern, dim3(ntile, 1, B), dim3(64 * WM * WN), LDS, aa);
     return hipGetLastError();
 }

@@ -507,12 +507,7 @@ hipError_t launch_distinctive(xfh_ctx* c, const float* table, const int* offsets
     if (n_groups <= 0) return hipSuccess;
     const int ldn = (max_group < 1 ? 1 : max_group) | 1;
     const size_t lds = (size_t)64 * ldn * sizeof(int);
-    static size_t attr = 0;
-    if (lds > attr) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_distinctive_csr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)64 * (XFH_MAX_GROUP | 1) * sizeof(int)));
-        if (e != hipSuccess) return e;
-        attr = (size_t)64 * (XFH_MAX_GROUP | 1) * sizeof(int);
-    }
+    XFH_SET_LDS_ATTR_ONCE(c, k_distinctive_csr, (size_t)64 * (XFH_MAX_GROUP | 1) * sizeof(int));
     launch_k(c, XFH_K_DISTINCTIVE, -1, k_distinctive_csr, dim3(n_groups), dim3(64), lds, table, offsets, indices, n_groups, ldn, best_pos, best_median);
     return hipGetLastError();
 }

@@ -753,13 +753,11 @@ hipError_t run_extract(xfh_ctx* c, const uint8_t* d_gray, int B, int H0, int W0,
                        H, W, c->cfg.nms_threshold, c->cand, c->cand_cap, c->cand_count);
     CK(hipGetLastError());
     if (nf <= SEL_FAST_MAX) {
-        static bool attr_f = false;
-        if (!attr_f) { CK(hipFuncSetAttribute((const void*)k_select, hipFuncAttributeMaxDynamicSharedMemorySize, SEL_LDS_KEYS * 8)); attr_f = true; }
+        XFH_SET_LDS_ATTR_ONCE(c, k_select, SEL_LDS_KEYS * 8);
         launch_k(c, XFH_K_SELECT, -1, k_select, dim3(B), dim3(1024), SEL_LDS_KEYS * 8, (const u64*)c->cand, c->cand_cap, (const int*)c->cand_count, W, nf,
                  lap0, lap1, c->slot_src, c->sel_key, c->sel_n, d_records, rec);
     } else {
-        static bool attr = false;
-        if (!attr) { CK(hipFuncSetAttribute((const void*)k_select_generic, hipFuncAttributeMaxDynamicSharedMemorySize, SEL_LDS_KEYS * 8)); attr = true; }
+        XFH_SET_LDS_ATTR_ONCE(c, k_select_generic, SEL_LDS_KEYS * 8);
         launch_k(c, XFH_K_SELECT, -1, k_select_generic, dim3(B), dim3(1024), SEL_LDS_KEYS * 8, c->cand, c->cand_cap, (const int*)c->cand_count, W, nf,
                  lap0, lap1, c->slot_src, c->sel_key, c->sel_n, d_records, rec);
     }
