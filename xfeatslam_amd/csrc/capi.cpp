@@ -137,6 +137,8 @@ int xfh_create(const xfh_config* cfg, xfh_ctx** out) {
 
 int xfh_destroy(xfh_ctx* c) {
     if (!c) return XFH_OK;
+    hipSetDevice(c->cfg.device);
+    if (c->stream && c->stream != c->own_stream) hipStreamSynchronize(c->stream);     // work queued on a caller's stream
     if (c->own_stream) hipStreamSynchronize(c->own_stream);
     if (c->aux_stream) hipStreamSynchronize(c->aux_stream);
     auto F = [](void* p) { if (p) hipFree(p); };
