@@ -513,14 +513,6 @@ hipError_t launch_distinctive(xfh_ctx* c, const float* table, const int* offsets
 }
 
 // ---------------------------------------------------------------------------------------
-static hipError_t ensure(void** p, size_t* cap, size_t need_bytes) {
-    if (*cap >= need_bytes && *p) return hipSuccess;
-    if (*p) { hipError_t e = hipFree(*p); if (e != hipSuccess) return e; *p = nullptr; }
-    hipError_t e = hipMalloc(p, need_bytes);
-    if (e == hipSuccess) *cap = need_bytes;
-    return e;
-}
-
 hipError_t launch_mnn(xfh_ctx* c, const float* d1, int n1, const float* d2, int n2, float min_cossim,
                       int* idx1, int* idx2, float* dist, int* n_matches) {
     hipError_t e;
