@@ -16,5 +16,7 @@ rm -rf $O/prof $O/pmc_fetch $O/pmc_write
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o bench -- python $R/bench.py --steps 20 --cpu-frames 0 ) > $O/bench_prof.json 2> $O/bench_prof.err
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o bench -- python $R/bench.py --steps 5 --warmup 2 --match-iters 10 --cpu-frames 0 ) > $O/pmc_fetch.json 2> $O/pmc_fetch.err
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o bench -- python $R/bench.py --steps 5 --warmup 2 --match-iters 10 --cpu-frames 0 ) > $O/pmc_write.json 2> $O/pmc_write.err
+rm -rf $O/prof_serial
+( cd /tmp && XFH_AUX_STREAM=0 timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/prof_serial -o bench -- python $R/bench.py --steps 10 --warmup 3 --match-iters 10 --cpu-frames 0 ) > $O/bench_prof_serial.json 2> $O/bench_prof_serial.err
 ls $O/prof $O/pmc_fetch $O/pmc_write
 echo round done

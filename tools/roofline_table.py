@@ -1,0 +1,83 @@
+#!/usr/bin/env python
+"""profiles/<tag>_roofline_table.md: every kernel of one default bench step (B frames, one stream) against its bound.
+
+Input: the rocprofv3 kernel trace of `XFH_AUX_STREAM=0 python bench.py` (gpurun_out/prof_serial/*kernel_trace.csv,
+tools/gpu_round.sh): with the keypoint branch on the main stream no two kernels overlap, so a launch's duration
+is the kernel's own speed (the product runs that branch on a second stream, which shortens the step by ~3 %).
+Launches are attributed to the batched steps by their grid (grid.z == B, or grid.x == B for the per-frame
+kernels); algorithmic flops / bytes per launch come from the layer table: a convolution
+reads its raw input map once, writes its raw output map once and does 2*H*W*Cout*Cin*k^2 flops per frame.
+Peaks: f32 MFMA 157.3 TFLOP/s, HBM 8 TB/s (/opt/skills/guides/MI355X_MICROARCH.md)."""
+import collections, csv, glob, json, os, re, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+f = glob.glob(os.path.join(ROOT, "gpurun_out", "prof_serial", "*kernel_trace.csv"))[0]
+cfg = json.loads(open(os.path.join(ROOT, "gpurun_out", "bench_prof_serial.json")).read().strip().splitlines()[-1])["config"]
+B, H, W = cfg["frames_per_gpu_per_step"] // cfg["sub_batches_in_flight"], cfg["height"] // 32 * 32, cfg["width"] // 32 * 32
+PEAK_TF, PEAK_TB = 157.3, 8.0
+# (cin, cout, k, stride) -> list of output sizes (h, w) of the layers that run on that instance
+def conv_layers():
+    h2, w2, h4, w4, h8, w8, h16, w16, h32, w32 = H // 2, W // 2, H // 4, W // 4, H // 8, W // 8, H // 16, W // 16, H // 32, W // 32
+    return {(1, 4, 3, 1): (H, W), (4, 8, 3, 2): (h2, w2), (8, 8, 3, 1): (h2, w2), (8, 24, 3, 2): (h4, w4), (24, 24, 3, 1): (h4, w4),
+            (24, 64, 3, 2): (h8, w8), (64, 64, 3, 1, "8"): (h8, w8), (64, 64, 1, 1): (h8, w8), (64, 64, 3, 2): (h16, w16),
+            (64, 64, 3, 1, "16"): (h16, w16), (64, 128, 3, 2): (h32, w32), (128, 128, 3, 1): (h32, w32), (128, 64, 1, 1): (h32, w32)}
+L = conv_layers()
+agg = collections.defaultdict(list)
+for r in csv.DictReader(open(f)):
+    gz, gx = int(r["Grid_Size_Z"]), int(r["Grid_Size_X"]) // max(int(r["Workgroup_Size_X"]), 1)
+    n = r["Kernel_Name"]
+    batched = gz == B or (gx == B and any(k in n for k in ("k_bn_finalize", "k_select")))
+    if batched or "k_mnn" in n or "k_rownorm" in n:
+        agg[n].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+steps = len(agg[[k for k in agg if "k_preproc" in k][0]])
+rows = []
+for n, d in agg.items():
+    us = sum(d) / len(d) / 1e3
+    per_step = len(d) / steps if "k_mnn" not in n and "k_rownorm" not in n else 1
+    flops = bytes_ = None; bound = "latency"
+    m = re.match(r"void k_conv_(mfma|direct)<(\d+), (\d+), (\d+), (\d+)(?:, (\d+), (\d+), (\d+), (\d+))?", n)
+    if m:
+        if m.group(1) == "mfma":
+            cin, cout, k, st, ww = int(m.group(2)), int(m.group(3)), int(m.group(4)), int(m.group(5)), int(m.group(9))
+        else:
+            cin, cout, st, k, ww = int(m.group(2)), int(m.group(3)), int(m.group(4)), 3, 16
+        key = (cin, cout, k, st)
+        if key == (64, 64, 3, 1):
+            key = key + (("8" if ww == 16 else "16"),)
+        ho, wo = L[key]
+        flops = 2.0 * ho * wo * cout * cin * k * k * B
+        bytes_ = 4.0 * B * (ho * st * wo * st * cin + ho * wo * cout)
+        bound = "mfma" if m.group(1) == "mfma" and flops / bytes_ > PEAK_TF / PEAK_TB else "hbm"
+    elif "k_mnn_gemm" in n:
+        flops, bytes_, bound = 2.0 * 4096 * 4096 * 64, 2 * 4096 * 256.0, "mfma"
+    elif "k_heads_kp" in n:
+        bytes_, bound = 4.0 * B * (H // 8 * (W // 8) * 64 + H * W), "valu"
+        flops = 2.0 * B * (H // 8) * (W // 8) * 65 * 64
+    elif "k_preproc" in n: bytes_, bound = B * H * W * 5.0, "hbm"
+    elif "k_norm_aux" in n: bytes_, bound = B * H * W * (4 + 4 + 0.25), "hbm"
+    elif "k_b2in" in n: bytes_, bound = 4.0 * B * (H // 4) * (W // 4) * 24 * 2, "hbm"
+    elif "k_fuse_in" in n: bytes_, bound = 4.0 * B * 64 * ((H // 8) * (W // 8) * 2 + (H // 16) * (W // 16) + (H // 32) * (W // 32)), "hbm"
+    elif "k_feats_norm" in n: bytes_, bound = 4.0 * B * (H // 8) * (W // 8) * 64 * 2, "hbm"
+    elif "k_heads_heat" in n: bytes_, bound = 4.0 * B * (H // 8) * (W // 8) * 65, "hbm"
+    elif "k_nms_score" in n: bytes_, bound = 4.0 * B * H * W, "hbm"
+    elif "k_desc" in n: bytes_, bound = B * 4096.0 * (4 * 256 + 284), "hbm"
+    rows.append((us * per_step, n, len(d), per_step, us, flops, bytes_, bound))
+rows.sort(key=lambda r: -r[0])
+tot = sum(r[0] for r in rows if "k_mnn" not in r[1] and "k_rownorm" not in r[1])
+out = os.path.join(ROOT, "profiles", f"{tag}_roofline_table.md")
+with open(out, "w") as o:
+    o.write(f"# Every kernel of the default bench step against its bound (B = {B} frames of {H}x{W}, one stream, 1 x MI355X)\n\n"
+            f"Source: rocprofv3 --kernel-trace of `XFH_AUX_STREAM=0 python bench.py` (all kernels serial on one stream; tools/gpu_round.sh), launches with the batched grid only; {steps} steps.\n"
+            f"`alg` = algorithmic flops / HBM bytes per launch (raw input map read once + raw output map written once; no halo, no weights);\n"
+            f"achieved = alg / average duration; % of the bound's peak (f32 MFMA {PEAK_TF} TFLOP/s, HBM {PEAK_TB} TB/s).  `latency` = per-frame single\n"
+            f"workgroup or dependent-launch bound kernels (no meaningful roofline).  Extraction kernels sum to {tot:.0f} us per step = {tot / B:.1f} us per frame.\n\n"
+            "| kernel | launches/step | avg us | us/step | bound | alg GFLOP | alg MB | achieved | % of peak |\n|---|---|---|---|---|---|---|---|---|\n")
+    for tot_us, n, cnt, per, us, fl, by, bound in rows:
+        nm = re.sub(r"\(.*", "", n.replace("void ", ""))
+        if bound == "mfma": ach, pct = f"{fl / us / 1e6:.1f} TFLOP/s", f"{fl / us / 1e6 / PEAK_TF * 100:.0f} %"
+        elif bound == "hbm": ach, pct = f"{by / us / 1e6:.2f} TB/s", f"{by / us / 1e6 / PEAK_TB * 100:.0f} %"
+        elif bound == "valu": ach, pct = f"{fl / us / 1e6:.1f} TFLOP/s (VALU)", "-"
+        else: ach, pct = "-", "-"
+        o.write(f"| `{nm}` | {per:.0f} | {us:.1f} | {tot_us:.1f} | {bound} | {fl / 1e9:.2f} | {by / 1e6:.1f} | {ach} | {pct} |\n" if fl and by else
+                f"| `{nm}` | {per:.0f} | {us:.1f} | {tot_us:.1f} | {bound} | {'-' if not fl else f'{fl / 1e9:.2f}'} | {'-' if not by else f'{by / 1e6:.1f}'} | {ach} | {pct} |\n")
+print(open(out).read())

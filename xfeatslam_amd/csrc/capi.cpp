@@ -229,7 +229,7 @@ int xfh_load_weights(xfh_ctx* c, const void* blob, size_t nbytes) {
                 rc = upload(c, &c->w.alt[i], pack_mfma(e.p, L.cout, L.cin, L.ks, coutp, 32));
             if (rc == XFH_OK && L.ks == 3 && L.cin == 64 && L.cout == 64 && L.stride == 1)                 // 7, 10, 11, 16, 17: three taps per chunk
                 rc = upload(c, &c->w.alt2[i], pack_mfma(e.p, L.cout, L.cin, L.ks, coutp, 64, 3));
-            if (rc == XFH_OK && i == 3)                                                                // block1.3: all nine taps in one chunk
+            if (rc == XFH_OK && L.ks == 3 && L.cin <= 24 && L.cout == 24)                              // 3, 4, 5: all nine taps in one chunk (persistent kernels, block1.3)
                 rc = upload(c, &c->w.alt[i], pack_mfma(e.p, L.cout, L.cin, L.ks, coutp, 64, 9));
         }
         if (rc != XFH_OK) return rc;

@@ -338,6 +338,185 @@ void k_conv_mfma(ConvArgs a) {
 }
 
 // ------------------------------------------------------------------------------------
+// k_conv_mfma_p: persistent form of k_conv_mfma for the layers whose whole weight matrix fits in LDS next to one
+// input tile (the 1x1 layers, the 24->24 and 8->24 3x3 layers).  These layers have short K loops (32-108 MFMAs per
+// wave and tile), so k_conv_mfma spends as long staging a tile as computing it.  Here a workgroup
+//   - loads the weights ONCE and walks over tiles  blockIdx.x, blockIdx.x + gridDim.x, ...  (frames x tiles),
+//   - issues the global loads of the NEXT tile before the MFMAs of the current one (registers hold them), and applies
+//     BN + ReLU when it moves them to LDS afterwards,
+//   - has no barrier inside the K loop (all taps resident).
+// Same arithmetic, same tiles and the same statistics partials as k_conv_mfma: the two are interchangeable bit for bit.
+template <int CIN, int COUT, int KS, int ST, int WM, int WN, int NT, int WW, int PRO, int EPI>
+__global__ __launch_bounds__(64 * WM * WN)
+void k_conv_mfma_p(ConvArgs a, int ntile, int total) {
+    constexpr int NTHR = 64 * WM * WN;
+    constexpr int WH = 32 / WW, TH = WM * WH, TW = WW;
+    constexpr int COUTP = WN * NT * 32;
+    constexpr int PAD = KS / 2;
+    constexpr int TIH = (TH - 1) * ST + KS, TIW = (TW - 1) * ST + KS;
+    constexpr int CP = CIN + 4;
+    constexpr int KTOT = KS * KS * CIN;
+    constexpr int WS = KTOT + 4;                 // WS/4 odd: conflict-free ds_read_b128
+    constexpr int G = CIN / 8;
+    constexpr int NITEM = TIH * TIW * G;
+    constexpr int NE = NTHR / G * G;             // staging threads: a multiple of G, so that a thread keeps one channel group
+    constexpr int NIT = (NITEM + NE - 1) / NE;
+    constexpr int IN_FLOATS = TIH * TIW * CP;
+    constexpr int W_FLOATS = COUTP * WS;
+    static_assert(NIT <= 32, "inside mask");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_in = smem;
+    float* s_w = smem + IN_FLOATS;
+    double* s_red = (double*)(s_w + W_FLOATS);   // [WM][COUTP][2]
+
+    const int t = threadIdx.x;
+    // ---- all weights, once: global [n][KTOT] (k-permuted per group of 8) -> LDS rows of WS floats
+    for (int f = t; f < COUTP * (KTOT / 4); f += NTHR) {
+        const int n = f / (KTOT / 4), c4 = f % (KTOT / 4);
+        *(f32x4*)(s_w + n * WS + c4 * 4) = *(const f32x4*)(a.w + (size_t)f * 4);
+    }
+    const int g = t % G;                         // this thread's channel group in every item it stages
+    const int wave = t >> 6, lane = t & 63, i = lane & 31, h = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    const int pr = i / WW, pc = i % WW;
+    const int ly = (wm * WH + pr) * ST, lx = pc * ST;
+
+    f32x4 v0[NIT], v1[NIT];
+    unsigned inside = 0u;
+    auto load_tile = [&](int tile) {              // global -> registers (raw values), remembers which items lie inside the image
+        const int b = tile / ntile, tl = tile - b * ntile;
+        const int tx0 = (tl % a.tiles_x) * TW, ty0 = (tl / a.tiles_x) * TH;
+        const float* in = a.in + (size_t)b * a.in_stride;
+        inside = 0u;
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int item = t + k * NE;
+            const int pix = item / G;
+            const int iy = pix / TIW, ix = pix % TIW;
+            const int gy = ty0 * ST - PAD + iy, gx = tx0 * ST - PAD + ix;
+            v0[k] = f32x4{0.f, 0.f, 0.f, 0.f}; v1[k] = v0[k];
+            if (t < NE && item < NITEM && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win) {
+                const float* p = in + ((size_t)gy * a.Win + gx) * CIN + g * 8;
+                v0[k] = *(const f32x4*)p; v1[k] = *(const f32x4*)(p + 4);
+                inside |= 1u << k;
+            }
+        }
+    };
+    auto store_tile = [&](int tile) {             // registers -> activated, k-permuted LDS tile
+        f32x4 m0, m1, r0, r1;
+        if constexpr (PRO == PRO_BN) {
+            const int b = tile / ntile;
+            const float* st = a.in_stat + (size_t)b * 2 * CIN + g * 8;
+            m0 = *(const f32x4*)st; m1 = *(const f32x4*)(st + 4); r0 = *(const f32x4*)(st + CIN); r1 = *(const f32x4*)(st + CIN + 4);
+        }
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int item = t + k * NE;
+            if (t < NE && item < NITEM) {
+                f32x4 x0 = v0[k], x1 = v1[k];
+                if constexpr (PRO == PRO_BN) {
+                    if (inside & (1u << k)) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            x0[q] = fmaxf((x0[q] - m0[q]) * r0[q], 0.f);
+                            x1[q] = fmaxf((x1[q] - m1[q]) * r1[q], 0.f);
+                        }
+                    }
+                }
+                float* d = s_in + (item / G) * CP + g * 8;
+                *(f32x4*)d = f32x4{x0.x, x0.z, x1.x, x1.z};
+                *(f32x4*)(d + 4) = f32x4{x0.y, x0.w, x1.y, x1.w};
+            }
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile >= total) return;
+    load_tile(tile);
+    store_tile(tile);
+    __syncthreads();                              // weights and the first tile are in LDS
+    while (true) {
+        const int next = tile + gridDim.x;
+        const bool has_next = next < total;
+        if (has_next) load_tile(next);            // in flight during the MFMAs below
+
+        f32x16 acc[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < KS * KS; ++tap) {
+            const int ky = tap / KS, kx = tap % KS;
+            const float* pa = s_in + ((ly + ky) * TIW + lx + kx) * CP + 4 * h;
+            const float* pw = s_w + (wn * NT * 32 + i) * WS + tap * CIN + 4 * h;
+#pragma unroll
+            for (int kk = 0; kk < CIN / 8; ++kk) {
+                const f32x4 av = *(const f32x4*)(pa + kk * 8);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const f32x4 bv = *(const f32x4*)(pw + n * 32 * WS + kk * 8);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc[n], 0, 0, 0);
+                }
+            }
+        }
+
+        // ---- epilogue of `tile` (C/D layout: channel (lane&31) of tile n, pixels (r&3) + 8*(r>>2) + 4*h)
+        const int b = tile / ntile, tl = tile - b * ntile;
+        const int tx0 = (tl % a.tiles_x) * TW, ty0 = (tl / a.tiles_x) * TH;
+        float* outp = a.out + (size_t)b * a.out_stride;
+        double sum[NT], sq[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int co = (wn * NT + n) * 32 + i;
+            sum[n] = 0.0; sq[n] = 0.0;
+            float bias = 0.f;
+            if constexpr (EPI == EPI_BIAS) bias = (co < COUT) ? a.bias[co] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int px = (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int oy = ty0 + wm * WH + px / WW, ox = tx0 + px % WW;
+                if (oy < a.Hout && ox < a.Wout && co < COUT) {
+                    float v = acc[n][r];
+                    if constexpr (EPI == EPI_BIAS) v += bias;
+                    outp[((size_t)oy * a.Wout + ox) * COUT + co] = v;
+                    if constexpr (EPI == EPI_STATS) { const double dv = (double)v; sum[n] += dv; sq[n] = fma(dv, dv, sq[n]); }
+                }
+            }
+        }
+        if constexpr (EPI == EPI_STATS) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                sum[n] += __shfl_xor(sum[n], 32);
+                sq[n] += __shfl_xor(sq[n], 32);
+                if (h == 0) {
+                    const int co = (wn * NT + n) * 32 + i;
+                    s_red[(wm * COUTP + co) * 2 + 0] = sum[n];
+                    s_red[(wm * COUTP + co) * 2 + 1] = sq[n];
+                }
+            }
+        }
+        __syncthreads();                          // every wave is done with s_in; s_red is complete
+        if constexpr (EPI == EPI_STATS) {
+            for (int co = t; co < COUT; co += NTHR) {
+                double S = 0.0, SS = 0.0;
+#pragma unroll
+                for (int m = 0; m < WM; ++m) { S += s_red[(m * COUTP + co) * 2 + 0]; SS += s_red[(m * COUTP + co) * 2 + 1]; }
+                double* p = a.part + (size_t)b * a.part_stride + ((size_t)tl * COUT + co) * 2;
+                p[0] = S; p[1] = SS;
+            }
+        }
+        if (!has_next) break;
+        store_tile(next);
+        __syncthreads();
+        tile = next;
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // host side: layer -> template instance
 template <int CIN, int COUT, int KS, int ST, int WM, int WN, int NT, int WW, int PRO, int EPI, int CBMAX = 64, int TPC = 1>
 static hipError_t conv_mfma_launch(xfh_ctx* c, const ConvArgs& a, int B, int* npart_out, int layer) {
@@ -359,6 +538,33 @@ static hipError_t conv_mfma_launch(xfh_ctx* c, const ConvArgs& a, int B, int* np
     XFH_SET_LDS_ATTR_ONCE(c, kern, LDS);
     launch_k(c, XFH_K_CONV_MFMA, layer, kern, dim3(ntile, 1, B), dim3(64 * WM * WN), LDS, aa);
     return hipGetLastError();
+}
+
+template <int CIN, int COUT, int KS, int ST, int WM, int WN, int NT, int WW, int PRO, int EPI>
+static hipError_t conv_mfma_p_launch(xfh_ctx* c, const ConvArgs& a, int B, int* npart_out, int layer) {
+    constexpr int WH = 32 / WW, TH = WM * WH, TW = WW;
+    constexpr int COUTP = WN * NT * 32;
+    constexpr int TIH = (TH - 1) * ST + KS, TIW = (TW - 1) * ST + KS;
+    constexpr size_t LDS = sizeof(float) * ((size_t)TIH * TIW * (CIN + 4) + (size_t)COUTP * (KS * KS * CIN + 4)) + sizeof(double) * WM * COUTP * 2;
+    static_assert(LDS <= 160 * 1024, "LDS budget");
+    ConvArgs aa = a;
+    aa.tiles_x = (a.Wout + TW - 1) / TW;
+    const int ntile = aa.tiles_x * ((a.Hout + TH - 1) / TH);
+    if (npart_out) *npart_out = ntile;
+    auto kern = k_conv_mfma_p<CIN, COUT, KS, ST, WM, WN, NT, WW, PRO, EPI>;
+    XFH_SET_LDS_ATTR_ONCE(c, kern, LDS);
+    const int total = ntile * B;
+    const int per_cu = (int)((160 * 1024) / LDS) > 4 ? 4 : (int)((160 * 1024) / LDS);
+    const int grid = total < 256 * per_cu ? total : 256 * per_cu;
+    launch_k(c, XFH_K_CONV_MFMA, layer, kern, dim3(grid), dim3(64 * WM * WN), LDS, aa, ntile, total);
+    return hipGetLastError();
+}
+
+// persistent kernels for the short-K layers of large batches; XFH_PERSIST=0 falls back to k_conv_mfma
+static bool persistent(int B) {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("XFH_PERSIST"); v = e ? atoi(e) : 1; }
+    return v != 0 && B > 8;
 }
 
 template <int CIN, int COUT, int ST, int PRO>
@@ -438,13 +644,21 @@ hipError_t launch_basic_layer(xfh_ctx* c, int li, const float* in, size_t in_str
         case 0: e = conv_direct_launch<1, 4, 1, PRO_IN>(c, a, B, &np, li); break;
         case 1: e = conv_direct_launch<4, 8, 2, PRO_BN>(c, a, B, &np, li); break;
         case 2: e = conv_direct_launch<8, 8, 1, PRO_BN>(c, a, B, &np, li); break;
-        case 3:     // all nine taps of the weights in one LDS chunk (no barrier inside the K = 72 loop): 49.5 -> 46.2 us at B = 32;
+        case 3:
+            if (persistent(B)) { a.w = c->w.alt[li]; e = conv_mfma_p_launch<8, 24, 3, 2, 4, 1, 1, 16, PRO_BN, EPI_STATS>(c, a, B, &np, li); break; }
+            // all nine taps of the weights in one LDS chunk (no barrier inside the K = 72 loop): 49.5 -> 46.2 us at B = 32;
                     // the same form measured slower for the 24 -> 24 layers (95 vs 91 us).  XFH_CONV_CFG=0: one tap per chunk
             if (conv_cfg()) { a.w = c->w.alt[li]; e = conv_mfma_launch<8, 24, 3, 2, 4, 1, 1, 16, PRO_BN, EPI_STATS, 64, 9>(c, a, B, &np, li); }
             else e = conv_mfma_launch<8, 24, 3, 2, 4, 1, 1, 16, PRO_BN, EPI_STATS>(c, a, B, &np, li);
             break;
-        case 4: e = conv_mfma_launch<24, 24, 3, 1, 4, 1, 1, 16, PRO_PLAIN, EPI_STATS>(c, a, B, &np, li); break;  // input = b2in
-        case 5: e = conv_mfma_launch<24, 24, 3, 1, 4, 1, 1, 16, PRO_BN, EPI_STATS>(c, a, B, &np, li); break;
+        case 4:                                                                                                 // input = b2in
+            if (persistent(B)) { a.w = c->w.alt[li]; e = conv_mfma_p_launch<24, 24, 3, 1, 4, 1, 1, 16, PRO_PLAIN, EPI_STATS>(c, a, B, &np, li); }
+            else e = conv_mfma_launch<24, 24, 3, 1, 4, 1, 1, 16, PRO_PLAIN, EPI_STATS>(c, a, B, &np, li);
+            break;
+        case 5:
+            if (persistent(B)) { a.w = c->w.alt[li]; e = conv_mfma_p_launch<24, 24, 3, 1, 4, 1, 1, 16, PRO_BN, EPI_STATS>(c, a, B, &np, li); }
+            else e = conv_mfma_launch<24, 24, 3, 1, 4, 1, 1, 16, PRO_BN, EPI_STATS>(c, a, B, &np, li);
+            break;
         case 6: e = conv_mfma_launch<24, 64, 3, 2, 4, 1, 2, 16, PRO_BN, EPI_STATS>(c, a, B, &np, li); break;
         case 7: case 17: case 16: {
             // the dominant 3x3 64->64 instance: 8x16 pixels x 64 channels per workgroup, 8 waves (4 x 2),
@@ -469,7 +683,10 @@ hipError_t launch_basic_layer(xfh_ctx* c, int li, const float* in, size_t in_str
             }
             break;
         }
-        case 8: e = conv_mfma_launch<64, 64, 1, 1, 4, 1, 2, 16, PRO_BN, EPI_STATS>(c, a, B, &np, li); break;
+        case 8:
+            if (persistent(B)) e = conv_mfma_p_launch<64, 64, 1, 1, 4, 1, 2, 16, PRO_BN, EPI_STATS>(c, a, B, &np, li);
+            else e = conv_mfma_launch<64, 64, 1, 1, 4, 1, 2, 16, PRO_BN, EPI_STATS>(c, a, B, &np, li);
+            break;
         case 9: e = conv_mfma_launch<64, 64, 3, 2, 2, 2, 1, 8, PRO_BN, EPI_STATS>(c, a, B, &np, li); break;
         case 10: case 11:
             if (small_batch(B)) { a.w = c->w.alt2[li]; e = conv_mfma_launch<64, 64, 3, 1, 2, 2, 1, 8, PRO_BN, EPI_STATS, 64, 3>(c, a, B, &np, li); }   // three taps per chunk
@@ -482,9 +699,13 @@ hipError_t launch_basic_layer(xfh_ctx* c, int li, const float* in, size_t in_str
             break;
         case 15: e = conv_mfma_launch<128, 64, 1, 1, 1, 2, 1, 8, PRO_BN, EPI_STATS>(c, a, B, &np, li); break;
         case 18: case 20:                                                                                      // inputs: feats / unfold(xhat)
-            e = conv_mfma_launch<64, 64, 1, 1, 4, 1, 2, 16, PRO_PLAIN, EPI_STATS>(c, a, B, &np, li); break;
+            if (persistent(B)) e = conv_mfma_p_launch<64, 64, 1, 1, 4, 1, 2, 16, PRO_PLAIN, EPI_STATS>(c, a, B, &np, li);
+            else e = conv_mfma_launch<64, 64, 1, 1, 4, 1, 2, 16, PRO_PLAIN, EPI_STATS>(c, a, B, &np, li);
+            break;
         case 19: case 21: case 22:
-            e = conv_mfma_launch<64, 64, 1, 1, 4, 1, 2, 16, PRO_BN, EPI_STATS>(c, a, B, &np, li); break;
+            if (persistent(B)) e = conv_mfma_p_launch<64, 64, 1, 1, 4, 1, 2, 16, PRO_BN, EPI_STATS>(c, a, B, &np, li);
+            else e = conv_mfma_launch<64, 64, 1, 1, 4, 1, 2, 16, PRO_BN, EPI_STATS>(c, a, B, &np, li);
+            break;
         default: return hipErrorInvalidValue;
     }
     (void)bn;
@@ -508,6 +729,7 @@ hipError_t launch_fusion_out(xfh_ctx* c, int Hh, int Wh, int B) {
         a.in_part = c->part[17]; a.in_part_stride = c->part_stride[17]; a.in_npart = c->npart[17];
         a.in_count = (double)Hh * (double)Wh; a.in_stat_out = c->stat[17];
     }
+    if (persistent(B)) return conv_mfma_p_launch<64, 64, 1, 1, 4, 1, 2, 16, PRO_BN, EPI_BIAS>(c, a, B, nullptr, 23);
     return conv_mfma_launch<64, 64, 1, 1, 4, 1, 2, 16, PRO_BN, EPI_BIAS>(c, a, B, nullptr, 23);
 }
 
