@@ -26,7 +26,7 @@ agg = collections.defaultdict(list)
 for r in csv.DictReader(open(f)):
     gz, gx = int(r["Grid_Size_Z"]), int(r["Grid_Size_X"]) // max(int(r["Workgroup_Size_X"]), 1)
     n = r["Kernel_Name"]
-    batched = gz == B or (gx == B and any(k in n for k in ("k_bn_finalize", "k_select")))
+    batched = gz == B or (gx == B and any(k in n for k in ("k_bn_finalize", "k_select"))) or "k_conv_mfma_p" in n   # persistent kernels only run for B > 8
     if batched or "k_mnn" in n or "k_rownorm" in n:
         agg[n].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 steps = len(agg[[k for k in agg if "k_preproc" in k][0]])
@@ -35,9 +35,9 @@ for n, d in agg.items():
     us = sum(d) / len(d) / 1e3
     per_step = len(d) / steps if "k_mnn" not in n and "k_rownorm" not in n else 1
     flops = bytes_ = None; bound = "latency"
-    m = re.match(r"void k_conv_(mfma|direct)<(\d+), (\d+), (\d+), (\d+)(?:, (\d+), (\d+), (\d+), (\d+))?", n)
+    m = re.match(r"void k_conv_(mfma_p|mfma|direct)<(\d+), (\d+), (\d+), (\d+)(?:, (\d+), (\d+), (\d+), (\d+))?", n)
     if m:
-        if m.group(1) == "mfma":
+        if m.group(1) != "direct":
             cin, cout, k, st, ww = int(m.group(2)), int(m.group(3)), int(m.group(4)), int(m.group(5)), int(m.group(9))
         else:
             cin, cout, st, k, ww = int(m.group(2)), int(m.group(3)), int(m.group(4)), 3, 16
@@ -47,7 +47,7 @@ for n, d in agg.items():
         ho, wo = L[key]
         flops = 2.0 * ho * wo * cout * cin * k * k * B
         bytes_ = 4.0 * B * (ho * st * wo * st * cin + ho * wo * cout)
-        bound = "mfma" if m.group(1) == "mfma" and flops / bytes_ > PEAK_TF / PEAK_TB else "hbm"
+        bound = "mfma" if m.group(1) != "direct" and flops / bytes_ > PEAK_TF / PEAK_TB else "hbm"
     elif "k_mnn_gemm" in n:
         flops, bytes_, bound = 2.0 * 4096 * 4096 * 64, 2 * 4096 * 256.0, "mfma"
     elif "k_heads_kp" in n:
