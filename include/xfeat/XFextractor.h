@@ -82,7 +82,7 @@ public:
 
     // reference: XFextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST)
     XFextractor(int _nfeatures, float _scaleFactor, int _nlevels, int _iniThFAST, int _minThFAST,
-                int max_height = 1088, int max_width = 1920, int device = 0, const char* weights_path = nullptr)
+                int max_height = 1088, int max_width = 1920, int device = 0, const char* weights_path = nullptr, int flags = 0)
         : nfeatures(_nfeatures), scaleFactor(_scaleFactor), nlevels(_nlevels), iniThFAST(_iniThFAST), minThFAST(_minThFAST) {
         // scale tables, XFextractor.cc:80-96
         mvScaleFactor.resize(nlevels); mvLevelSigma2.resize(nlevels);
@@ -110,7 +110,7 @@ public:
         mnFeaturesPerLevel[nlevels - 1] = std::max(nfeatures - sum, 0);
 
         xfh_config cfg; xfh_config_default(&cfg);
-        cfg.device = device; cfg.max_height = max_height; cfg.max_width = max_width; cfg.nfeatures = nfeatures; cfg.max_batch = 1;
+        cfg.device = device; cfg.max_height = max_height; cfg.max_width = max_width; cfg.nfeatures = nfeatures; cfg.max_batch = 1; cfg.flags = flags;
         int rc = xfh_create(&cfg, &ctx);
         if (rc != XFH_OK) throw std::runtime_error(std::string("XFextractor: xfh_create: ") + xfh_strerror(rc));
         std::string path = weights_path ? weights_path : getModelWeightsPath("weights/xfeat.xfhw");

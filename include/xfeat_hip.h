@@ -64,8 +64,14 @@ typedef struct {
     int32_t max_batch;     /* frames per xfh_extract_batch* call                              */
     int32_t bn_mode;       /* XFH_BN_*                                                        */
     float nms_threshold;   /* 0.05 in the reference (XFextractor.cc:277)                      */
-    int32_t reserved[8];
+    int32_t flags;         /* XFH_FLAG_*; 0 = the reference's behaviour                        */
+    int32_t reserved[7];
 } xfh_config;
+
+/* flags.  XFH_FLAG_RESCALE_KEYPOINTS: report keypoints in INPUT-image coordinates, x * (W/W32), y * (H/H32) in fp32
+ * as upstream XFeat does.  The reference multiplies by a Long-typed factor, i.e. by 1 (XFextractor.cc:304-305,
+ * SURVEY.md Q2): for inputs whose sides are not multiples of 32 its keypoints stay in the resized frame. */
+#define XFH_FLAG_RESCALE_KEYPOINTS 1
 
 /* fills the defaults: device 0, 480x640, nfeatures 4096, max_batch 1, threshold 0.05 */
 void xfh_config_default(xfh_config* cfg);

@@ -43,6 +43,7 @@ def lib():
         L.xfo_create.argtypes = [C.c_void_p, C.c_size_t]
         L.xfo_destroy.argtypes = [C.c_void_p]
         L.xfo_set_bn_mode.argtypes = [C.c_void_p, C.c_int]
+        L.xfo_set_rescale.argtypes = [C.c_void_p, C.c_int]
         L.xfo_set_threads.argtypes = [C.c_int]
         L.xfo_get_threads.restype = C.c_int
         L.xfo_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -69,13 +70,14 @@ def get_threads() -> int:
 class Oracle:
     """CPU restatement of XFextractor::operator() (reference src/XFextractor.cc:250-356)."""
 
-    def __init__(self, blob: bytes, bn_mode: int = 0):
+    def __init__(self, blob: bytes, bn_mode: int = 0, rescale: bool = False):
         self._blob = blob
         self._h = lib().xfo_create(blob, len(blob))
         if not self._h:
             raise RuntimeError("oracle: bad weight blob")
         if lib().xfo_set_bn_mode(self._h, bn_mode) != 0:
             raise RuntimeError("oracle: blob has no BatchNorm running statistics")
+        lib().xfo_set_rescale(self._h, 1 if rescale else 0)
 
     def __del__(self):
         if getattr(self, "_h", None):

@@ -98,7 +98,7 @@ def _interp(x, pos, H, W, mode):
     return x.permute(0, 2, 3, 1).squeeze(-2)
 
 
-def extract(gray: np.ndarray, weights, nfeatures: int = 4096, lapping=(0, 0), taps=None, eval_mode: bool = False):
+def extract(gray: np.ndarray, weights, nfeatures: int = 4096, lapping=(0, 0), taps=None, eval_mode: bool = False, rescale: bool = False):
     """XFextractor::operator() (XFextractor.cc:250-356).  Returns
     (kps[nfeatures] structured, desc[nfeatures,64], n_valid, mono_index)."""
     from .oracle import KP_DTYPE
@@ -141,8 +141,11 @@ def extract(gray: np.ndarray, weights, nfeatures: int = 4096, lapping=(0, 0), ta
         sc = sc.gather(-1, idxs)[:, :nfeatures]
         feats = _interp(M1, mkpts, _H, _W, "bilinear")                               # :298
         feats = F.normalize(feats, dim=-1)                                           # :301
-        sf = torch.tensor([rw, rh], dtype=mkpts.dtype).view(1, 1, -1)                # :304 (Long!)
-        mkpts = mkpts * sf
+        if rescale:     # not the reference: upstream XFeat multiplies in floating point
+            mkpts = mkpts * torch.tensor([rw, rh]).view(1, 1, -1)
+        else:
+            sf = torch.tensor([rw, rh], dtype=mkpts.dtype).view(1, 1, -1)            # :304 (Long!)
+            mkpts = mkpts * sf
         if taps is not None:
             taps.update(sel=mkpts.clone(), sel_scores=sc.clone())
         # pack (:310-356)

@@ -47,6 +47,7 @@ struct xfo_ctx {
     float* kp3_w; float kp3_b[65];      /* [ci][65] */
     float* bn_stat[XFO_NUM_LAYERS];     /* optional running statistics as (mean[C], rstd[C]) */
     int bn_mode;                        /* 0 = batch statistics (the reference), 1 = running statistics */
+    int rescale;                        /* 0 = the reference's Long-typed no-op (Q2), 1 = float rescale to input coordinates */
     /* intermediates of the last call */
     int H, W;                           /* after resize */
     float* t[128]; int64_t tn[128];
@@ -162,6 +163,7 @@ int xfo_set_bn_mode(xfo_ctx* c, int mode) {
     c->bn_mode = mode;
     return 0;
 }
+int xfo_set_rescale(xfo_ctx* c, int on) { c->rescale = on ? 1 : 0; return 0; }
 int xfo_get_tensor(xfo_ctx* c, int id, const float** ptr, int64_t* count) {
     if (id < 0 || id >= 128 || !c->t[id]) return -1;
     *ptr = c->t[id]; *count = c->tn[id];
@@ -563,8 +565,11 @@ int xfo_extract(xfo_ctx* c, const uint8_t* gray, int H0, int W0, int nfeatures, 
         sample_bilinear(m1n, h8, w8, 64, xx, y, H, W, d);
         l2_normalize(d, 64, dn);
         int slot;
-        if (xx >= lap0 && xx <= lap1) slot = stereo--; else slot = mono++;   /* :332-343 */
-        kps[slot].x = (float)xx; kps[slot].y = (float)y; kps[slot].size = 1.f; kps[slot].angle = -1.f;
+        /* rescale mode 1 (not the reference): mkpts.float() * (rw, rh) as upstream XFeat does, rw = W0 / W in fp32 */
+        const float kx = c->rescale ? (float)xx * (float)((double)W0 / (double)W) : (float)xx;
+        const float ky = c->rescale ? (float)y * (float)((double)H0 / (double)H) : (float)y;
+        if (kx >= (float)lap0 && kx <= (float)lap1) slot = stereo--; else slot = mono++;   /* :332-343 */
+        kps[slot].x = kx; kps[slot].y = ky; kps[slot].size = 1.f; kps[slot].angle = -1.f;
         kps[slot].response = cand[i].score; kps[slot].octave = 0; kps[slot].class_id = -1;
         memcpy(desc + (size_t)slot * 64, dn, sizeof dn);
         ++nv;

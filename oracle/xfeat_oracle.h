@@ -65,6 +65,9 @@ xfo_ctx* xfo_create(const void* weight_blob, size_t nbytes);
 void xfo_destroy(xfo_ctx* c);
 /* 0 = BatchNorm on batch statistics (what the reference does), 1 = on the running statistics stored in
  * the blob (upstream-XFeat eval() semantics); returns -1 if the blob carries no running statistics */
+/* 0 (default) = the reference's Long-typed keypoint rescale, a no-op; 1 = float rescale to input-image
+ * coordinates as upstream XFeat does (optional) */
+int xfo_set_rescale(xfo_ctx* c, int on);
 int xfo_set_bn_mode(xfo_ctx* c, int mode);
 void xfo_set_threads(int n); /* OpenMP threads for the heavy loops (<=0: library default) */
 int xfo_get_threads(void);

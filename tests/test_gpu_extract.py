@@ -190,3 +190,23 @@ def test_running_stats_mode(gpu_lib, oracle_mod):
     assert kp_set(ok0) != kp_set(recs[0][0])
     assert gpu_lib.xfh_load_weights(ctx.h, WT.pack_blob(WT.make_synthetic(1234, 6.0)), len(WT.pack_blob(WT.make_synthetic(1234, 6.0)))) == 5
     ctx.close()
+
+
+def test_keypoint_rescale_flag(gpu_lib, oracle_mod):
+    """XFH_FLAG_RESCALE_KEYPOINTS (upstream-XFeat coordinates) against the oracle in the same mode; the default stays the
+    reference's no-op rescale.  The lapping-area split follows the reported x."""
+    from xfeatslam_amd.extractor import Context
+    blob = WT.pack_blob(WT.make_synthetic(1234, 3.0))
+    img = synth.image(170, 230, 3)
+    for flags in (0, capi.FLAG_RESCALE_KEYPOINTS):
+        ok, od, onv, omono = oracle_mod.Oracle(blob, rescale=bool(flags)).extract(img, 300, (100, 150))
+        ctx = Context(nfeatures=300, max_height=170, max_width=230, flags=flags); ctx.load_weights(blob)
+        (hk, hd, hnv, hmono, _), = ctx.extract_batch(img[None], (100, 150))
+        ctx.close()
+        assert (hnv, hmono) == (onv, omono)
+        for f in ("x", "y", "size", "angle", "octave", "class_id"):
+            assert np.array_equal(hk[f], ok[f]), f                                # identical slots and coordinates
+        assert np.abs(hk["response"] - ok["response"]).max() < 1e-6 and np.abs(hd - od).max() < DESC_TOL
+        if flags:
+            v = hk["size"] > 0
+            assert hk["y"][v].max() > 160 - 8 and np.any(hk["x"][v] != np.round(hk["x"][v]))

@@ -32,7 +32,10 @@ T = dict(X=0, XSTAT=1, SKIP_POOL=2, XUNFOLD=3, B2IN=4, FUSE_IN=5, FEATS=6, M1N=7
 class Config(C.Structure):
     _fields_ = [("device", C.c_int32), ("max_height", C.c_int32), ("max_width", C.c_int32),
                 ("nfeatures", C.c_int32), ("max_batch", C.c_int32), ("bn_mode", C.c_int32),
-                ("nms_threshold", C.c_float), ("reserved", C.c_int32 * 8)]
+                ("nms_threshold", C.c_float), ("flags", C.c_int32), ("reserved", C.c_int32 * 7)]
+
+
+FLAG_RESCALE_KEYPOINTS = 1
 
 
 # every symbol include/xfeat_hip.h declares: (name, restype, argtypes)

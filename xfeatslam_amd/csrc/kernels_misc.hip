@@ -359,7 +359,7 @@ __device__ __forceinline__ void bitonic_sort(u64* a, int n, int t) {
 
 __global__ __launch_bounds__(1024)
 void k_select_generic(u64* __restrict__ cand, size_t cand_cap, const int* __restrict__ cand_count, int W, int nfeatures,
-              int lap0, int lap1, int* __restrict__ slot_src, u64* __restrict__ sel_key, int* __restrict__ sel_n,
+              int lap0, int lap1, float rw, int* __restrict__ slot_src, u64* __restrict__ sel_key, int* __restrict__ sel_n,
               uint8_t* __restrict__ records, size_t rec_bytes) {
     extern __shared__ __attribute__((aligned(16))) u64 skeys[];
     __shared__ int wsumF[16], wsumB[16], wsumV[16];
@@ -395,7 +395,7 @@ void k_select_generic(u64* __restrict__ cand, size_t cand_cap, const int* __rest
             const float score = ord2f(~(unsigned)(key >> 32));
             const int x = (int)((unsigned)(key & 0xFFFFFFFFull) % (unsigned)W);
             valid = score > 0.f;                                          // XFextractor.cc:313
-            back = valid && (x >= lap0 && x <= lap1);                     // :332
+            { const float xf = (float)x * rw; back = valid && (xf >= (float)lap0 && xf <= (float)lap1); }   // :332 (rw = 1 unless XFH_FLAG_RESCALE_KEYPOINTS)
             sel_key[(size_t)b * nfeatures + i] = key;
         }
         const bool front = valid && !back;
@@ -486,7 +486,7 @@ __device__ __forceinline__ void hybrid_bitonic(u64 (&key)[KPT], u64* sk, int t) 
 }
 // validity, slots and bookkeeping for the sorted keys held KPT per thread
 template <int KPT>
-__device__ __forceinline__ void place_sorted(const u64 (&key)[KPT], int t, int b, int N, int W, int nfeatures, int lap0, int lap1,
+__device__ __forceinline__ void place_sorted(const u64 (&key)[KPT], int t, int b, int N, int W, int nfeatures, int lap0, int lap1, float rw,
                                              int* __restrict__ slot_src, u64* __restrict__ sel_key, int* __restrict__ sel_n,
                                              uint8_t* __restrict__ records, size_t rec_bytes, int n_cand, int* wsumF, int* wsumB) {
     const int lane = t & 63, wave = t >> 6;
@@ -502,7 +502,7 @@ __device__ __forceinline__ void place_sorted(const u64 (&key)[KPT], int t, int b
             const float score = ord2f(~(unsigned)(key[q] >> 32));
             const int x = (int)((unsigned)(key[q] & 0xFFFFFFFFull) % (unsigned)W);
             const bool valid = score > 0.f;                               // XFextractor.cc:313
-            back[q] = valid && (x >= lap0 && x <= lap1);                  // :332
+            { const float xf = (float)x * rw; back[q] = valid && (xf >= (float)lap0 && xf <= (float)lap1); }   // :332 (rw = 1 unless XFH_FLAG_RESCALE_KEYPOINTS)
             front[q] = valid && !back[q];
             sel_key[(size_t)b * nfeatures + i] = key[q];
         }
@@ -535,7 +535,7 @@ __device__ __forceinline__ void place_sorted(const u64 (&key)[KPT], int t, int b
 
 __global__ __launch_bounds__(1024)
 void k_select(const u64* __restrict__ cand, size_t cand_cap, const int* __restrict__ cand_count, int W, int nfeatures,
-              int lap0, int lap1, int* __restrict__ slot_src, u64* __restrict__ sel_key, int* __restrict__ sel_n,
+              int lap0, int lap1, float rw, int* __restrict__ slot_src, u64* __restrict__ sel_key, int* __restrict__ sel_n,
               uint8_t* __restrict__ records, size_t rec_bytes) {
     extern __shared__ __attribute__((aligned(16))) u64 sk[];        // 16384 keys
     __shared__ int hist[256];
@@ -553,7 +553,7 @@ void k_select(const u64* __restrict__ cand, size_t cand_cap, const int* __restri
 #pragma unroll
         for (int q = 0; q < 4; ++q) key[q] = (4 * t + q < C) ? gk[4 * t + q] : ~0ull;
         hybrid_bitonic<4>(key, sk, t);
-        place_sorted<4>(key, t, b, N, W, nfeatures, lap0, lap1, slot_src, sel_key, sel_n, records, rec_bytes, n_cand, wsumF, wsumB);
+        place_sorted<4>(key, t, b, N, W, nfeatures, lap0, lap1, rw, slot_src, sel_key, sel_n, records, rec_bytes, n_cand, wsumF, wsumB);
         return;
     }
     // ---- more than 4096 candidates: radix select down to N, then the 4-per-thread sort -----------
@@ -607,13 +607,13 @@ void k_select(const u64* __restrict__ cand, size_t cand_cap, const int* __restri
     for (int q = 0; q < 4; ++q) key[q] = sk[4 * t + q];
     __syncthreads();
     hybrid_bitonic<4>(key, sk, t);
-    place_sorted<4>(key, t, b, N, W, nfeatures, lap0, lap1, slot_src, sel_key, sel_n, records, rec_bytes, n_cand, wsumF, wsumB);
+    place_sorted<4>(key, t, b, N, W, nfeatures, lap0, lap1, rw, slot_src, sel_key, sel_n, records, rec_bytes, n_cand, wsumF, wsumB);
 }
 
 // ---- k_desc: one wave per output slot, lane = descriptor channel ---------------------------------
 __global__ __launch_bounds__(256)
 void k_desc(const float* __restrict__ m1n, size_t m_stride, const int* __restrict__ slot_src, const u64* __restrict__ sel_key,
-            int H, int W, int nfeatures, uint8_t* __restrict__ records, size_t rec_bytes, size_t kps_off, size_t desc_off) {
+            int H, int W, int nfeatures, float rw, float rh, uint8_t* __restrict__ records, size_t rec_bytes, size_t kps_off, size_t desc_off) {
     const int b = blockIdx.z;
     const int slot = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (slot >= nfeatures) return;
@@ -649,9 +649,9 @@ void k_desc(const float* __restrict__ m1n, size_t m_stride, const int* __restric
     const float nrm = fmaxf((float)sqrt(ss), 1e-12f);
     dd[lane] = v / nrm;
     if (lane < 7) {
-        // KeyPoint(x, y, 1, -1, score): octave 0, class_id -1 (XFextractor.cc:329); the Long
-        // rescale at :304-305 multiplies by 1
-        const float val = lane == 0 ? (float)x : lane == 1 ? (float)y : lane == 2 ? 1.f : lane == 3 ? -1.f : score;
+        // KeyPoint(x, y, 1, -1, score): octave 0, class_id -1 (XFextractor.cc:329); the Long rescale at :304-305
+        // multiplies by 1: rw = rh = 1 unless XFH_FLAG_RESCALE_KEYPOINTS asks for input coordinates
+        const float val = lane == 0 ? (float)x * rw : lane == 1 ? (float)y * rh : lane == 2 ? 1.f : lane == 3 ? -1.f : score;
         if (lane < 5) kp[lane] = val;
         else ((int*)kp)[lane] = (lane == 5) ? 0 : -1;
     }
@@ -675,6 +675,8 @@ hipError_t run_extract(xfh_ctx* c, const uint8_t* d_gray, int B, int H0, int W0,
     const size_t xs = (size_t)c->Hmax * c->Wmax;
     const int nf = c->cfg.nfeatures;
     const size_t rec = xfh_record_bytes(nf);
+    const bool resc = (c->cfg.flags & XFH_FLAG_RESCALE_KEYPOINTS) != 0;
+    const float rw = resc ? (float)((double)W0 / (double)W) : 1.0f, rh = resc ? (float)((double)H0 / (double)H) : 1.0f;
 
     // image -> float, resize, InstanceNorm statistics
     const int npre = (H * W + 1023) / 1024;
@@ -755,14 +757,14 @@ hipError_t run_extract(xfh_ctx* c, const uint8_t* d_gray, int B, int H0, int W0,
     if (nf <= SEL_FAST_MAX) {
         XFH_SET_LDS_ATTR_ONCE(c, k_select, SEL_LDS_KEYS * 8);
         launch_k(c, XFH_K_SELECT, -1, k_select, dim3(B), dim3(1024), SEL_LDS_KEYS * 8, (const u64*)c->cand, c->cand_cap, (const int*)c->cand_count, W, nf,
-                 lap0, lap1, c->slot_src, c->sel_key, c->sel_n, d_records, rec);
+                 lap0, lap1, rw, c->slot_src, c->sel_key, c->sel_n, d_records, rec);
     } else {
         XFH_SET_LDS_ATTR_ONCE(c, k_select_generic, SEL_LDS_KEYS * 8);
         launch_k(c, XFH_K_SELECT, -1, k_select_generic, dim3(B), dim3(1024), SEL_LDS_KEYS * 8, c->cand, c->cand_cap, (const int*)c->cand_count, W, nf,
-                 lap0, lap1, c->slot_src, c->sel_key, c->sel_n, d_records, rec);
+                 lap0, lap1, rw, c->slot_src, c->sel_key, c->sel_n, d_records, rec);
     }
     CK(hipGetLastError());
-    launch_k(c, XFH_K_DESC, -1, k_desc, dim3((nf + 3) / 4, 1, B), dim3(256), 0, c->m1n, c->raw_stride[17], c->slot_src, c->sel_key, H, W, nf,
+    launch_k(c, XFH_K_DESC, -1, k_desc, dim3((nf + 3) / 4, 1, B), dim3(256), 0, c->m1n, c->raw_stride[17], c->slot_src, c->sel_key, H, W, nf, rw, rh,
                        d_records, rec, xfh_record_kps_offset(), xfh_record_desc_offset(nf));
     return hipGetLastError();
 }

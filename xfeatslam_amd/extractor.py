@@ -19,12 +19,13 @@ from .capi import KP_DTYPE, Config, check, lib
 class Context:
     """Owns one xfh_ctx (one per GPU)."""
 
-    def __init__(self, nfeatures=4096, max_height=480, max_width=640, max_batch=1, device=0, nms_threshold=0.05, bn_mode=0):
+    def __init__(self, nfeatures=4096, max_height=480, max_width=640, max_batch=1, device=0, nms_threshold=0.05, bn_mode=0, flags=0):
         cfg = Config()
         lib().xfh_config_default(C.byref(cfg))
         cfg.device, cfg.max_height, cfg.max_width = device, max_height, max_width
         cfg.nfeatures, cfg.max_batch, cfg.nms_threshold = nfeatures, max_batch, nms_threshold
         cfg.bn_mode = bn_mode          # 0 = batch statistics (the reference), 1 = running statistics (upstream eval())
+        cfg.flags = flags              # capi.FLAG_*; 0 = the reference's behaviour
         h = C.c_void_p()
         check(lib().xfh_create(C.byref(cfg), C.byref(h)))
         self.h = h
