@@ -150,6 +150,36 @@ public:
         return mono;
     }
 
+    // Split form (not in the reference): submit() enqueues the frame and returns, collect() waits and fills the outputs
+    // like operator().  Lets the Tracking thread keep both cameras of a stereo rig (two XFextractor objects) or the next
+    // frame in flight without a second CPU thread.
+    void submit(const Mat& image, std::vector<int>& vLappingArea) {
+        pending_empty = image.empty();
+        if (pending_empty) return;
+        const int lap0 = vLappingArea.size() > 0 ? vLappingArea[0] : 0, lap1 = vLappingArea.size() > 1 ? vLappingArea[1] : 0;
+        const int rc = xfh_extract_submit(ctx, image.data, image.rows, image.cols, (int)image.step, lap0, lap1);
+        if (rc != XFH_OK) throw std::runtime_error(std::string("XFextractor::submit: ") + xfh_strerror(rc) + " " + xfh_last_hip_error(ctx));
+    }
+    int collect(std::vector<KeyPoint>& _keypoints, Mat& _descriptors) {
+        if (pending_empty) return -1;
+#if XFEAT_HAVE_OPENCV
+        _descriptors.create(nfeatures, 64, CV_32F);
+#else
+        _descriptors.create(nfeatures, 64, 4);
+#endif
+        int n_valid = 0, mono = 0;
+        const int rc = xfh_extract_collect(ctx, kbuf.data(), _descriptors.template ptr<float>(0), &n_valid, &mono);
+        if (rc != XFH_OK) throw std::runtime_error(std::string("XFextractor::collect: ") + xfh_strerror(rc) + " " + xfh_last_hip_error(ctx));
+        _keypoints.assign(nfeatures, KeyPoint());
+        for (int i = 0; i < nfeatures; ++i) {
+            const xfh_keypoint& k = kbuf[i];
+            KeyPoint& o = _keypoints[i];
+            o.pt.x = k.x; o.pt.y = k.y; o.size = k.size; o.angle = k.angle; o.response = k.response; o.octave = k.octave; o.class_id = k.class_id;
+        }
+        if (n_valid == 0) _descriptors.release();
+        return mono;
+    }
+
     int inline GetLevels() { return nlevels; }
     float inline GetScaleFactor() { return (float)scaleFactor; }
     std::vector<float> inline GetScaleFactors() { return mvScaleFactor; }
@@ -180,6 +210,7 @@ protected:
     std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;
     xfh_ctx* ctx = nullptr;
     std::vector<xfh_keypoint> kbuf;
+    bool pending_empty = false;
 };
 
 }  // namespace ORB_SLAM3

@@ -95,6 +95,13 @@ int xfh_load_weights_file(xfh_ctx* ctx, const char* path);
 int xfh_extract(xfh_ctx* ctx, const uint8_t* gray, int H, int W, int stride_bytes, int lap_x0, int lap_x1,
                 xfh_keypoint* kps_out, float* desc_out, int* n_valid, int* mono_index);
 
+/* Split form of xfh_extract: submit copies the image into the ctx's pinned staging buffer and
+ * enqueues H2D, the kernels and the D2H copy of the record, then returns; collect waits for them and unpacks.  One
+ * submission may be outstanding per ctx (a second submit before collect overwrites the first).  Between the two the
+ * caller is free to work -- e.g. submit the right image of a stereo pair on a second ctx, or track the previous frame. */
+int xfh_extract_submit(xfh_ctx* ctx, const uint8_t* gray, int H, int W, int stride_bytes, int lap_x0, int lap_x1);
+int xfh_extract_collect(xfh_ctx* ctx, xfh_keypoint* kps_out, float* desc_out, int* n_valid, int* mono_index);
+
 /* the upstream name of the same call (README.md:9, xfeat_cpp `detectAndCompute`) */
 int xfh_detect_and_compute(xfh_ctx* ctx, const uint8_t* gray, int H, int W, int stride_bytes,
                            int lap_x0, int lap_x1, xfh_keypoint* kps_out, float* desc_out,

@@ -210,3 +210,39 @@ def test_keypoint_rescale_flag(gpu_lib, oracle_mod):
         if flags:
             v = hk["size"] > 0
             assert hk["y"][v].max() > 160 - 8 and np.any(hk["x"][v] != np.round(hk["x"][v]))
+
+
+def test_submit_collect_stereo_pair(gpu_lib, weights_dense):
+    """xfh_extract_submit / xfh_extract_collect: two ctx (the reference's mpXFextractorLeft / Right, Tracking.cc:597-600)
+    with both frames in flight give the same records as two blocking xfh_extract calls."""
+    import time
+    from xfeatslam_amd.capi import KP_DTYPE
+    L = capi.lib()
+    _, blob = weights_dense
+    nf, H, W = 1000, 480, 640
+    imgs = [synth.image(H, W, 5), synth.image(H, W, 6)]
+    ctxs = []
+    for _ in range(2):
+        c = _ctx(nf, H, W); c.load_weights(blob); ctxs.append(c)
+    def blocking(c, im, lap):
+        k = np.zeros(nf, KP_DTYPE); d = np.zeros((nf, 64), np.float32); nv, mono = C.c_int(), C.c_int()
+        capi.check(L.xfh_extract(c.h, im.ctypes.data, H, W, W, lap[0], lap[1], k.ctypes.data, d.ctypes.data, C.byref(nv), C.byref(mono)), c.h)
+        return k, d, nv.value, mono.value
+    laps = [(0, 0), (0, 1000)]                                # Frame.cc:311 / :495
+    ref = [blocking(c, im, lap) for c, im, lap in zip(ctxs, imgs, laps)]
+    t0 = time.perf_counter(); [blocking(c, im, lap) for c, im, lap in zip(ctxs, imgs, laps)]; t_seq = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for c, im, lap in zip(ctxs, imgs, laps):
+        capi.check(L.xfh_extract_submit(c.h, im.ctypes.data, H, W, W, lap[0], lap[1]), c.h)
+    out = []
+    for c in ctxs:
+        k = np.zeros(nf, KP_DTYPE); d = np.zeros((nf, 64), np.float32); nv, mono = C.c_int(), C.c_int()
+        capi.check(L.xfh_extract_collect(c.h, k.ctypes.data, d.ctypes.data, C.byref(nv), C.byref(mono)), c.h)
+        out.append((k, d, nv.value, mono.value))
+    t_par = time.perf_counter() - t0
+    for a, b in zip(ref, out):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2:] == b[2:]
+    assert L.xfh_extract_collect(ctxs[0].h, out[0][0].ctypes.data, out[0][1].ctypes.data, None, None) == 1   # nothing pending
+    print(f"stereo pair: sequential {t_seq * 1e3:.2f} ms, both in flight {t_par * 1e3:.2f} ms")
+    for c in ctxs:
+        c.close()

@@ -48,6 +48,8 @@ SYMBOLS = [
     ("xfh_load_weights", _i, [_vp, _vp, _sz]),
     ("xfh_load_weights_file", _i, [_vp, C.c_char_p]),
     ("xfh_extract", _i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _pi, _pi]),
+    ("xfh_extract_submit", _i, [_vp, _vp, _i, _i, _i, _i, _i]),
+    ("xfh_extract_collect", _i, [_vp, _vp, _vp, _pi, _pi]),
     ("xfh_detect_and_compute", _i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _pi, _pi]),
     ("xfh_record_bytes", _sz, [_i]),
     ("xfh_record_kps_offset", _sz, []),

@@ -322,19 +322,29 @@ int xfh_extract_batch(xfh_ctx* c, const uint8_t* gray, int B, int H, int W, int 
     return XFH_OK;
 }
 
-int xfh_extract(xfh_ctx* c, const uint8_t* gray, int H, int W, int stride, int lap0, int lap1,
-                xfh_keypoint* kps, float* desc, int* n_valid, int* mono_index) {
+// xfh_extract = submit + collect.  The split form lets the caller overlap its own work (or the other camera of a
+// stereo rig on a second ctx) with the GPU and the D2H copy of the record.
+int xfh_extract_submit(xfh_ctx* c, const uint8_t* gray, int H, int W, int stride, int lap0, int lap1) {
     int rc = check_extract(c, gray, 1, H, W);
     if (rc != XFH_OK) return rc;
-    if (!kps || !desc || stride < W) return XFH_ERR_INVALID_ARG;
+    if (stride < W) return XFH_ERR_INVALID_ARG;
     HIPCK(c, hipSetDevice(c->cfg.device));
-    const int nf = c->cfg.nfeatures;
-    const size_t rec = xfh_record_bytes(nf);
+    const size_t rec = xfh_record_bytes(c->cfg.nfeatures);
     for (int y = 0; y < H; ++y) memcpy(c->h_gray + (size_t)y * W, gray + (size_t)y * stride, (size_t)W);
     HIPCK(c, hipMemcpyAsync(c->d_gray, c->h_gray, (size_t)H * W, hipMemcpyHostToDevice, c->stream));
     HIPCK(c, run_extract(c, c->d_gray, 1, H, W, lap0, lap1, c->d_records));
     HIPCK(c, hipMemcpyAsync(c->h_records, c->d_records, rec, hipMemcpyDeviceToHost, c->stream));
+    c->pending = true;
+    return XFH_OK;
+}
+
+int xfh_extract_collect(xfh_ctx* c, xfh_keypoint* kps, float* desc, int* n_valid, int* mono_index) {
+    if (!c || !kps || !desc) return XFH_ERR_INVALID_ARG;
+    if (!c->pending) return XFH_ERR_INVALID_ARG;           // nothing was submitted
+    HIPCK(c, hipSetDevice(c->cfg.device));
     HIPCK(c, hipStreamSynchronize(c->stream));
+    c->pending = false;
+    const int nf = c->cfg.nfeatures;
     const RecordHeader* h = (const RecordHeader*)c->h_records;
     memcpy(kps, c->h_records + xfh_record_kps_offset(), (size_t)nf * sizeof(xfh_keypoint));
     memcpy(desc, c->h_records + xfh_record_desc_offset(nf), (size_t)nf * 64 * sizeof(float));
@@ -343,6 +353,13 @@ int xfh_extract(xfh_ctx* c, const uint8_t* gray, int H, int W, int stride, int l
     return XFH_OK;
 }
 
+int xfh_extract(xfh_ctx* c, const uint8_t* gray, int H, int W, int stride, int lap0, int lap1,
+                xfh_keypoint* kps, float* desc, int* n_valid, int* mono_index) {
+    if (!kps || !desc) return XFH_ERR_INVALID_ARG;
+    const int rc = xfh_extract_submit(c, gray, H, W, stride, lap0, lap1);
+    if (rc != XFH_OK) return rc;
+    return xfh_extract_collect(c, kps, desc, n_valid, mono_index);
+}
 int xfh_detect_and_compute(xfh_ctx* c, const uint8_t* gray, int H, int W, int stride, int lap0, int lap1,
                            xfh_keypoint* kps, float* desc, int* n_valid, int* mono_index) {
     return xfh_extract(c, gray, H, W, stride, lap0, lap1, kps, desc, n_valid, mono_index);

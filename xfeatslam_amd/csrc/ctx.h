@@ -56,6 +56,8 @@ struct xfh_ctx {
     uint8_t* h_records = nullptr;               // pinned
     uint8_t* h_gray = nullptr;                  // pinned
 
+    bool pending = false;                       // xfh_extract_submit without its xfh_extract_collect yet
+
     MatchWs mws;
     KTimer timer;
 };
