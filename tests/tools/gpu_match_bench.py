@@ -3,7 +3,7 @@
 XFH_GEMM_VARIANT (one subprocess per variant).  Development tool."""
 import os, subprocess, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 def child():

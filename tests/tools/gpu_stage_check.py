@@ -12,7 +12,7 @@ import traceback
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from xfeatslam_amd import capi, synth, weights as WT          # noqa: E402
 from xfeatslam_amd.extractor import Context                   # noqa: E402
