@@ -246,3 +246,29 @@ def test_submit_collect_stereo_pair(gpu_lib, weights_dense):
     print(f"stereo pair: sequential {t_seq * 1e3:.2f} ms, both in flight {t_par * 1e3:.2f} ms")
     for c in ctxs:
         c.close()
+
+
+def test_random_sizes_all_batch_regimes(gpu_lib, oracle_mod):
+    """seeded fuzz over image sizes that are not multiples of the tile sizes, feature counts, lapping areas and batch sizes
+    (B = 1: single-frame tiles, B <= 8: consumer-side statistics, B > 8: k_bn_finalize + persistent short-K kernels):
+    every frame of every batch must reproduce the oracle's keypoints, slots and descriptors."""
+    from xfeatslam_amd.extractor import Context
+    rng = np.random.RandomState(2024)
+    blob = WT.pack_blob(WT.make_synthetic(1234, 4.0))
+    orc = oracle_mod.Oracle(blob)
+    for trial in range(6):
+        H, W = int(rng.randint(64, 330)), int(rng.randint(64, 420))
+        nf = int(rng.choice([64, 300, 1000, 5000]))
+        B = int(rng.choice([1, 3, 9, 11]))
+        x0 = int(rng.randint(0, W)); lap = (x0, int(x0 + rng.randint(0, W)))
+        fr = synth.frames(B, H, W, seed=100 + trial)
+        ctx = Context(nfeatures=nf, max_height=H, max_width=W, max_batch=B); ctx.load_weights(blob)
+        recs = ctx.extract_batch(fr, lap)
+        ctx.close()
+        for b in range(B):
+            ok, od, onv, omono = orc.extract(fr[b], nf, lap)
+            hk, hd, hnv, hmono, _ = recs[b]
+            assert (hnv, hmono) == (onv, omono), (trial, H, W, nf, B, b)
+            for f in ("x", "y", "size", "angle", "octave", "class_id"):
+                assert np.array_equal(hk[f], ok[f]), (trial, H, W, nf, B, b, f)
+            assert np.abs(hd - od).max() < DESC_TOL

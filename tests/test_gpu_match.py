@@ -169,3 +169,18 @@ def test_distinctive_csr_matches_oracle(mctx, oracle_mod):
     assert L.xfh_distinctive_csr(mctx.h, tb.ctypes.data, 2000, off2.ctypes.data, ind2.ctypes.data, 1, o[0].ctypes.data, o[1].ctypes.data) == 1
     off3 = np.array([0, 2], np.int32); ind3 = np.array([0, 2000], np.int32)
     assert L.xfh_distinctive_csr(mctx.h, tb.ctypes.data, 2000, off3.ctypes.data, ind3.ctypes.data, 1, o[0].ctypes.data, o[1].ctypes.data) == 1
+
+
+def test_mnn_random_shapes(mctx, oracle_mod):
+    """seeded fuzz over ragged sizes around the 64 / 128 / 256 tile edges, with duplicated and all-zero rows"""
+    rng = np.random.RandomState(77)
+    for trial in range(12):
+        n1, n2 = int(rng.randint(1, 700)), int(rng.randint(1, 700))
+        d1, d2 = synth.descriptor_sets(n1, n2, noise=float(rng.uniform(0.05, 0.6)), zero_rows=int(rng.randint(0, 4)))
+        for _ in range(int(rng.randint(0, 6))):
+            d2[rng.randint(0, n2)] = d2[rng.randint(0, n2)]
+            d1[rng.randint(0, n1)] = d1[rng.randint(0, n1)]
+        thr = float(rng.choice([-1.0, 0.5, 0.9]))
+        a = oracle_mod.match_mnn(d1, d2, thr); b = mctx.match_mnn(d1, d2, thr)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (trial, n1, n2, thr)
+        assert np.array_equal(a[2], b[2], equal_nan=True)
