@@ -269,6 +269,9 @@ def test_random_sizes_all_batch_regimes(gpu_lib, oracle_mod):
             ok, od, onv, omono = orc.extract(fr[b], nf, lap)
             hk, hd, hnv, hmono, _ = recs[b]
             assert (hnv, hmono) == (onv, omono), (trial, H, W, nf, B, b)
-            for f in ("x", "y", "size", "angle", "octave", "class_id"):
-                assert np.array_equal(hk[f], ok[f]), (trial, H, W, nf, B, b, f)
-            assert np.abs(hd - od).max() < DESC_TOL
+            # slot ORDER among keypoints whose scores differ by one ulp may swap (device expf vs glibc expf):
+            # compare the sets, the front / back padding layout and the descriptors joined by position
+            assert kp_set(hk) == kp_set(ok), (trial, H, W, nf, B, b)
+            assert np.array_equal(hk["size"] == 0, ok["size"] == 0)
+            dd, ds, n = joined_desc_diff(hk, hd, ok, od)
+            assert n == onv and dd < DESC_TOL and ds < 1e-6

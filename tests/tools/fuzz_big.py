@@ -1,0 +1,42 @@
+"""larger seeded fuzz campaign against the oracle (development tool; `python tests/tools/fuzz_big.py SEED` on the GPU box)"""
+import sys, numpy as np
+sys.path.insert(0, "/root/repo")
+from xfeatslam_amd import capi, synth, weights as WT
+from xfeatslam_amd.extractor import Context
+from oracle import oracle as O
+rng = np.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
+bad = 0
+for gain in (1.0, 4.0):
+    blob = WT.pack_blob(WT.make_synthetic(1234, gain)); orc = O.Oracle(blob)
+    for trial in range(14):
+        H, W = int(rng.randint(32, 500)), int(rng.randint(32, 700))
+        nf = int(rng.choice([1, 64, 300, 1000, 4096, 5000])); B = int(rng.choice([1, 2, 8, 9, 16]))
+        x0 = int(rng.randint(0, W)); lap = (x0, int(x0 + rng.randint(0, W)))
+        fr = synth.frames(B, H, W, seed=1000 + trial)
+        if trial % 5 == 0: fr[0] = 0
+        ctx = Context(nfeatures=nf, max_height=H, max_width=W, max_batch=B); ctx.load_weights(blob)
+        recs = ctx.extract_batch(fr, lap); ctx.close()
+        for b in range(B):
+            ok, od, onv, omono = orc.extract(fr[b], nf, lap)
+            hk, hd, hnv, hmono, _ = recs[b]
+            # slot order among keypoints whose scores differ by one ulp (device vs glibc expf) may swap: compare sets + layout
+            ks = lambda k: set(zip(k["x"][k["size"] > 0].tolist(), k["y"][k["size"] > 0].tolist()))
+            good = (hnv, hmono) == (onv, omono) and ks(hk) == ks(ok) and np.array_equal(hk["size"] == 0, ok["size"] == 0)
+            if good and hnv:
+                po = {(float(k["x"]), float(k["y"])): i for i, k in enumerate(ok) if k["size"] > 0}
+                good = max(float(np.abs(hd[i] - od[po[(float(k["x"]), float(k["y"]))]]).max()) for i, k in enumerate(hk) if k["size"] > 0) < 1e-4
+            if not good:
+                bad += 1; print("MISMATCH", gain, trial, H, W, nf, B, b, hnv, onv, hmono, omono, flush=True)
+print("extract fuzz done, mismatches:", bad, flush=True)
+ctx = Context(nfeatures=64, max_height=32, max_width=32)
+badm = 0
+for trial in range(150):
+    n1, n2 = int(rng.randint(1, 1500)), int(rng.randint(1, 1500))
+    d1, d2 = synth.descriptor_sets(n1, n2, noise=float(rng.uniform(0.02, 0.8)), zero_rows=int(rng.randint(0, 5)))
+    for _ in range(int(rng.randint(0, 10))):
+        d2[rng.randint(0, n2)] = d2[rng.randint(0, n2)]; d1[rng.randint(0, n1)] = d1[rng.randint(0, n1)]
+    thr = float(rng.choice([-1.0, 0.5, 0.9]))
+    a = O.match_mnn(d1, d2, thr); b = ctx.match_mnn(d1, d2, thr)
+    if not (np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2], equal_nan=True)):
+        badm += 1; print("MATCH MISMATCH", trial, n1, n2, thr, flush=True)
+print("match fuzz done, mismatches:", badm, flush=True)
