@@ -34,7 +34,7 @@ typedef enum {
     XFH_ERR_NO_WEIGHTS = 4,       /* extract called before xfh_load_weights                   */
     XFH_ERR_BAD_WEIGHTS = 5,      /* blob magic / tensor table / shapes wrong                 */
     XFH_ERR_HIP = 6,              /* a HIP runtime call failed; see xfh_last_hip_error        */
-    XFH_ERR_NO_DEVICE = 7,        /* no gfx950 device visible: the library never falls back   */
+    XFH_ERR_NO_DEVICE = 7,        /* device ordinal absent or not gfx950: the library never falls back */
     XFH_ERR_OUT_OF_MEMORY = 8,
     XFH_ERR_BATCH_TOO_LARGE = 9,
     XFH_ERR_IO = 10
@@ -135,6 +135,17 @@ int xfh_match_mnn(xfh_ctx* ctx, const float* d1, int n1, const float* d2, int n2
  * outputs device pointers; *d_n_matches is one int in device memory.  Asynchronous. */
 int xfh_match_mnn_device(xfh_ctx* ctx, const float* d_d1, int n1, const float* d_d2, int n2,
                          float min_cossim, int* d_idx1, int* d_idx2, float* d_dist, int* d_n_matches);
+
+/* Prepared descriptor sets (device-resident hand-off).  A tracker matches every frame against several
+ * others (previous frame, key frames, loop candidates): xfh_match_prepare_device normalises the n x 64 rows once
+ * (F::normalize, ORBmatcher.cc:358-359) and stores them as the "panel image" the GEMM kernel reads
+ * (xfh_match_image_bytes(n) bytes of device memory owned by the caller); xfh_match_mnn_prepared_device then runs
+ * ORBmatcher::match on two images with the same results as xfh_match_mnn_device on the rows they were made from,
+ * in two kernel launches instead of three.  Device pointers, asynchronous on the ctx stream. */
+size_t xfh_match_image_bytes(int n);
+int xfh_match_prepare_device(xfh_ctx* ctx, const float* d_desc, int n, void* d_image);
+int xfh_match_mnn_prepared_device(xfh_ctx* ctx, const void* d_image1, int n1, const void* d_image2, int n2,
+                                  float min_cossim, int* d_idx1, int* d_idx2, float* d_dist, int* d_n_matches);
 
 /* ORBmatcher::DescriptorDistance (ORBmatcher.cc:2242-2250), XFeat branch:
  * (int)(float(cv::norm(a, b, NORM_L2SQR)) * 512).  Scalar host version, stateless. */

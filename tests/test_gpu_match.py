@@ -33,6 +33,26 @@ def test_mnn_matches_oracle(mctx, oracle_mod, n1, n2, zero, noise):
     assert np.all(np.diff(b[0]) > 0)                             # ascending queryIdx, one match per row
 
 
+@pytest.mark.parametrize("n1,n2,zero", [(256, 256, 0), (300, 200, 7), (4096, 4096, 100), (1000, 4097, 0), (257, 255, 3)])
+def test_mnn_prepared_images_match_oracle(mctx, oracle_mod, n1, n2, zero):
+    """xfh_match_prepare_device + xfh_match_mnn_prepared_device (two launches) = xfh_match_mnn on the same rows; prepared and raw
+    calls may alternate on one ctx (the arg-max keys are re-zeroed by whichever style ran last)."""
+    d1, d2 = synth.descriptor_sets(n1, n2, zero_rows=zero, noise=0.3)
+    a = oracle_mod.match_mnn(d1, d2)
+    p1, p2 = mctx.match_prepare(d1), mctx.match_prepare(d2)
+    for rep in range(3):
+        b = mctx.match_mnn_prepared(p1, p2)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2], equal_nan=True)
+        if rep == 1:
+            c = mctx.match_mnn(d2, d1)           # a raw call in between leaves other keys behind
+            r = oracle_mod.match_mnn(d2, d1)
+            assert np.array_equal(c[0], r[0]) and np.array_equal(c[1], r[1])
+    for thr in (0.5, 0.95):
+        a2 = oracle_mod.match_mnn(d1, d2, thr); b2 = mctx.match_mnn_prepared(p1, p2, thr)
+        assert np.array_equal(a2[0], b2[0]) and np.array_equal(a2[1], b2[1])
+    p1[0].free(); p2[0].free()
+
+
 @pytest.mark.parametrize("name", ["match_256", "match_300x200_zero7", "match_4096", "match_4096_zero100"])
 def test_mnn_matches_golden(mctx, name):
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
@@ -75,8 +95,8 @@ def test_mnn_edge_cases(mctx, oracle_mod):
 
 @pytest.mark.parametrize("n1,n2", [(700, 900), (4096, 4096), (130, 260)])
 def test_mnn_ties_across_candidate_groups(mctx, oracle_mod, n1, n2):
-    """The kernel keeps value maxima per group of 4 d2 rows / 16 d1 rows and names the member afterwards
-    (k_mnn_fix).  Duplicated descriptors give exact ties inside a group, across neighbouring groups,
+    """The kernel keeps value maxima per group of 16 d2 rows / 16 d1 rows and names the member afterwards
+    (k_mnn_post).  Duplicated descriptors give exact ties inside a group, across neighbouring groups,
     across 128/256-row tiles and across workgroups; the first index must win on both axes."""
     rs = np.random.RandomState(n1 + n2)
     d1, d2 = synth.descriptor_sets(n1, n2, noise=0.25)

@@ -1,0 +1,8 @@
+#!/bin/bash
+# builds tools/probes/mnn_probe (gfx950); the binary travels to the GPU box with the repo snapshot
+set -e
+cd "$(dirname "$0")"
+F="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Wno-unused-value"
+/opt/rocm/bin/hipcc $F -fno-honor-nans -c mnn_probe_gemm.hip -o /tmp/mnn_probe_gemm.o
+/opt/rocm/bin/hipcc $F -c mnn_probe.hip -o /tmp/mnn_probe.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 /tmp/mnn_probe.o /tmp/mnn_probe_gemm.o -o mnn_probe

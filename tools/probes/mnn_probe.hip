@@ -1,0 +1,188 @@
+// mnn_probe.hip -- correctness + timing of the match path kernels on the GPU box (development probe, not part of the
+// library): k_rownorm_img -> k_mnn_gemm_img (variants) -> k_mnn_post against a brute-force reference that uses the
+// same arithmetic (fp64 norm, one fp32 fma chain in k order), for several shapes incl. ragged ones, ties and zero rows.
+// Build: tools/probes/build_mnn_probe.sh ; run on the GPU box: tools/probes/mnn_probe
+#include "../../xfeatslam_amd/csrc/mnn_prepost.hip.h"
+#include <hip/hip_ext.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+#include <algorithm>
+
+const char* probe_gemm_name(int v);
+void probe_gemm(int v, hipStream_t s, hipEvent_t e0, hipEvent_t e1, const float* i1, int n1, const float* i2, int n2, u64* bR, u64* bC, u64* pairs);
+
+// reference: plain normalised rows, then per row of A the first index of the maximum dot product over B
+__global__ void k_ref_norm(const float* d, int n, float* o) {
+    const int row = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
+    if (row >= n) return;
+    const f32x4 v = *(const f32x4*)(d + (size_t)row * 64 + sub * 4);
+    double ss = (double)v.x * (double)v.x + (double)v.y * (double)v.y + (double)v.z * (double)v.z + (double)v.w * (double)v.w;
+    ss += __shfl_xor(ss, 1); ss += __shfl_xor(ss, 2); ss += __shfl_xor(ss, 4); ss += __shfl_xor(ss, 8);
+    const float nrm = fmaxf((float)sqrt(ss), 1e-12f);
+    *(f32x4*)(o + (size_t)row * 64 + sub * 4) = f32x4{v.x / nrm, v.y / nrm, v.z / nrm, v.w / nrm};
+}
+__global__ void k_ref_best(const float* a, int na, const float* b, int nb, float* bv, int* bi) {
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= na) return;
+    float ar[64];
+    for (int k = 0; k < 64; ++k) ar[k] = a[(size_t)row * 64 + k];
+    float best = -INFINITY; int idx = 0;
+    for (int j = 0; j < nb; ++j) {
+        float acc = 0.f;
+        for (int k = 0; k < 64; ++k) acc = fmaf(ar[k], b[(size_t)j * 64 + k], acc);
+        if (acc > best) { best = acc; idx = j; }
+    }
+    bv[row] = best; bi[row] = idx;
+}
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+struct Case { int n1, n2, zero, dup; };
+
+static unsigned lcg(unsigned& s) { s = s * 1664525u + 1013904223u; return s; }
+static float gauss(unsigned& s) {
+    float u1 = ((lcg(s) >> 8) + 1) / 16777217.0f, u2 = (lcg(s) >> 8) / 16777216.0f;
+    return sqrtf(-2.f * logf(u1)) * cosf(6.2831853f * u2);
+}
+
+int main(int argc, char** argv) {
+    const int iters = argc > 1 ? atoi(argv[1]) : 200;
+    hipStream_t s; CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    CK(hipFuncSetAttribute((const void*)k_mnn_post<0>, hipFuncAttributeMaxDynamicSharedMemorySize, MNN_POST_LDS));
+    CK(hipFuncSetAttribute((const void*)k_mnn_post<1>, hipFuncAttributeMaxDynamicSharedMemorySize, MNN_POST_LDS));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const Case cases[] = {{4096, 4096, 0, 0}, {4096, 4096, 100, 64}, {1000, 777, 5, 9}, {300, 200, 7, 3}, {257, 4097, 0, 2}, {1, 5, 0, 0}, {129, 127, 0, 0}};
+    const int NV = 5, NVT = 7;      // variants >= NV are timing-only (results invalid by construction)
+    bool all_ok = true;
+    for (const Case& cs : cases) {
+        const int n1 = cs.n1, n2 = cs.n2;
+        const int P1 = (n1 + MNN_PANEL - 1) / MNN_PANEL, P2 = (n2 + MNN_PANEL - 1) / MNN_PANEL;
+        std::vector<float> h1((size_t)n1 * 64), h2((size_t)n2 * 64);
+        unsigned seed = 12345u + n1 * 7 + n2;
+        for (auto& v : h1) v = gauss(seed);
+        // d2 = noisy permuted copy of d1 rows (so that mutual matches exist), like synth.descriptor_sets
+        for (int j = 0; j < n2; ++j) {
+            const int src = (int)(lcg(seed) % (unsigned)n1);
+            for (int k = 0; k < 64; ++k) h2[(size_t)j * 64 + k] = h1[(size_t)src * 64 + k] + 0.3f * gauss(seed);
+        }
+        for (int z = 0; z < cs.zero && z < n1; ++z) { const int r = (z * 37) % n1; memset(&h1[(size_t)r * 64], 0, 256); }
+        for (int z = 0; z < cs.zero && z < n2; ++z) { const int r = (z * 53 + 1) % n2; memset(&h2[(size_t)r * 64], 0, 256); }
+        for (int z = 0; z < cs.dup; ++z) {          // exact duplicates: ties inside and across candidate groups / panels
+            const int a = (z * 131 + 2) % n2, b = (z * 977 + 300) % n2; memcpy(&h2[(size_t)b * 64], &h2[(size_t)a * 64], 256);
+            const int c = (z * 211 + 1) % n1, d = (z * 613 + 17) % n1; memcpy(&h1[(size_t)d * 64], &h1[(size_t)c * 64], 256);
+        }
+        float *d1, *d2, *img1, *img2, *p1, *p2, *rv1, *rv2, *dist; int *ri1, *ri2, *idx1, *idx2, *nm; u64 *bR, *bC, *pairs;
+        CK(hipMalloc(&d1, h1.size() * 4)); CK(hipMalloc(&d2, h2.size() * 4));
+        CK(hipMalloc(&img1, (size_t)P1 * MNN_PANEL_FLOATS * 4)); CK(hipMalloc(&img2, (size_t)P2 * MNN_PANEL_FLOATS * 4));
+        CK(hipMalloc(&p1, h1.size() * 4)); CK(hipMalloc(&p2, h2.size() * 4));
+        CK(hipMalloc(&rv1, n1 * 4)); CK(hipMalloc(&rv2, n2 * 4)); CK(hipMalloc(&ri1, n1 * 4)); CK(hipMalloc(&ri2, n2 * 4));
+        CK(hipMalloc(&bR, n1 * 8)); CK(hipMalloc(&bC, n2 * 8)); CK(hipMalloc(&pairs, n1 * 8));
+        const int nmax = std::min(n1, n2);
+        CK(hipMalloc(&idx1, nmax * 4)); CK(hipMalloc(&idx2, nmax * 4)); CK(hipMalloc(&dist, nmax * 4)); CK(hipMalloc(&nm, 4));
+        { std::vector<u64> e(n1, MNN_PAIR_EMPTY); CK(hipMemcpy(pairs, e.data(), n1 * 8, hipMemcpyHostToDevice)); }
+        CK(hipMemcpy(d1, h1.data(), h1.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(d2, h2.data(), h2.size() * 4, hipMemcpyHostToDevice));
+        // reference
+        hipLaunchKernelGGL(k_ref_norm, dim3((n1 + 15) / 16), dim3(256), 0, s, d1, n1, p1);
+        hipLaunchKernelGGL(k_ref_norm, dim3((n2 + 15) / 16), dim3(256), 0, s, d2, n2, p2);
+        hipLaunchKernelGGL(k_ref_best, dim3((n1 + 255) / 256), dim3(256), 0, s, p1, n1, p2, n2, rv1, ri1);
+        hipLaunchKernelGGL(k_ref_best, dim3((n2 + 255) / 256), dim3(256), 0, s, p2, n2, p1, n1, rv2, ri2);
+        CK(hipStreamSynchronize(s));
+        std::vector<float> v1(n1), v2(n2); std::vector<int> i1(n1), i2(n2);
+        CK(hipMemcpy(v1.data(), rv1, n1 * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(i1.data(), ri1, n1 * 4, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(v2.data(), rv2, n2 * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(i2.data(), ri2, n2 * 4, hipMemcpyDeviceToHost));
+        std::vector<int> r1, r2; std::vector<float> rd;
+        for (int i = 0; i < n1; ++i) if (i2[i1[i]] == i) { r1.push_back(i); r2.push_back(i1[i]); rd.push_back(sqrtf(2.0f * (1.0f - v1[i]))); }
+
+        auto rownorm = [&](hipEvent_t a, hipEvent_t b) {
+            const dim3 g((P1 + P2) * 16);
+            if (a) hipExtLaunchKernelGGL(k_rownorm_img, g, dim3(256), 0, s, a, b, 0, (const float*)d1, n1, (const float*)d2, n2, P1, img1, img2, bR, bC);
+            else hipLaunchKernelGGL(k_rownorm_img, g, dim3(256), 0, s, (const float*)d1, n1, (const float*)d2, n2, P1, img1, img2, bR, bC);
+        };
+        auto post = [&](hipEvent_t a, hipEvent_t b) {
+            const int nb = (n1 + 15) / 16, ncoll = mnn_ncoll(n1); const dim3 g(nb + ncoll);
+            if (a) hipExtLaunchKernelGGL(k_mnn_post<0>, g, dim3(256), MNN_POST_LDS, s, a, b, 0, (const float*)img1, n1, (const float*)img2, n2, (const u64*)bR, (const u64*)bC, -1.0f, pairs, nb, ncoll, 0, bR, bC, idx1, idx2, dist, nm, (long long*)nullptr);
+            else hipLaunchKernelGGL(k_mnn_post<0>, g, dim3(256), MNN_POST_LDS, s, (const float*)img1, n1, (const float*)img2, n2, (const u64*)bR, (const u64*)bC, -1.0f, pairs, nb, ncoll, 0, bR, bC, idx1, idx2, dist, nm, (long long*)nullptr);
+        };
+        for (int v = 0; v < NV; ++v) {
+            rownorm(nullptr, nullptr);
+            probe_gemm(v, s, nullptr, nullptr, img1, n1, img2, n2, bR, bC, pairs);
+            post(nullptr, nullptr);
+            CK(hipStreamSynchronize(s));
+            // level-1 keys
+            std::vector<u64> kR(n1), kC(n2);
+            CK(hipMemcpy(kR.data(), bR, n1 * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(kC.data(), bC, n2 * 8, hipMemcpyDeviceToHost));
+            int badR = 0, badC = 0;
+            for (int i = 0; i < n1; ++i) {
+                const float M = ord2f((unsigned)(kR[i] >> 32)); const int g = (int)(0xFFFFFFFFu - (unsigned)(kR[i] & 0xFFFFFFFFull));
+                if (memcmp(&M, &v1[i], 4) != 0 || g != i1[i] / MNN_CGROUP) { if (badR < 3) printf("   row %d: got (%.9g, grp %d) want (%.9g, idx %d)\n", i, M, g, v1[i], i1[i]); ++badR; }
+            }
+            for (int j = 0; j < n2; ++j) {
+                const float M = ord2f((unsigned)(kC[j] >> 32)); const int g = (int)(0xFFFFFFFFu - (unsigned)(kC[j] & 0xFFFFFFFFull));
+                if (memcmp(&M, &v2[j], 4) != 0 || g != i2[j] / MNN_RGROUP) { if (badC < 3) printf("   col %d: got (%.9g, grp %d) want (%.9g, idx %d)\n", j, M, g, v2[j], i2[j]); ++badC; }
+            }
+            int n = -1; CK(hipMemcpy(&n, nm, 4, hipMemcpyDeviceToHost));
+            bool okm = n == (int)r1.size();
+            if (okm && n > 0) {
+                std::vector<int> o1(n), o2(n); std::vector<float> od(n);
+                CK(hipMemcpy(o1.data(), idx1, n * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(o2.data(), idx2, n * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(od.data(), dist, n * 4, hipMemcpyDeviceToHost));
+                okm = o1 == r1 && o2 == r2 && memcmp(od.data(), rd.data(), n * 4) == 0;
+            }
+            const bool ok = badR == 0 && badC == 0 && okm;
+            all_ok &= ok;
+            printf("case %4d x %4d (zero %d dup %d) variant %d [%s]: keys rows %s cols %s, matches %d (ref %zu) %s\n", n1, n2, cs.zero, cs.dup, v, probe_gemm_name(v),
+                   badR ? "BAD" : "ok", badC ? "BAD" : "ok", n, r1.size(), ok ? "OK" : "MISMATCH");
+        }
+        if (n1 == 4096 && n2 == 4096 && cs.zero == 0) {
+            // ---- timing
+            auto time_kernel = [&](const char* name, auto&& launch) {
+                for (int i = 0; i < 10; ++i) launch(nullptr, nullptr);
+                CK(hipStreamSynchronize(s));
+                double tot = 0, best = 1e9;
+                for (int i = 0; i < iters; ++i) {
+                    launch(e0, e1); CK(hipEventSynchronize(e1));
+                    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); tot += ms; best = std::min(best, (double)ms);
+                }
+                CK(hipEventRecord(e0, s));
+                for (int i = 0; i < iters; ++i) launch(nullptr, nullptr);
+                CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+                float msg; CK(hipEventElapsedTime(&msg, e0, e1));
+                printf("  %-34s kernel avg %7.2f us  min %7.2f us | back-to-back %7.2f us/launch\n", name, tot / iters * 1e3, best * 1e3, msg / iters * 1e3);
+                return tot / iters * 1e3;
+            };
+            {   // wall-clock stamps (100 MHz) inside k_mnn_post, in sequence after the GEMM
+                long long* st; CK(hipMalloc(&st, 64 * 8));
+                for (int rep = 0; rep < 3; ++rep) {
+                    CK(hipMemset(st, 0, 64 * 8));
+                    rownorm(nullptr, nullptr); probe_gemm(1, s, nullptr, nullptr, img1, n1, img2, n2, bR, bC, pairs);
+                    hipLaunchKernelGGL(k_mnn_post<1>, dim3((n1 + 15) / 16 + mnn_ncoll(n1)), dim3(256), MNN_POST_LDS, s, (const float*)img1, n1, (const float*)img2, n2, (const u64*)bR, (const u64*)bC, -1.0f, pairs, (n1 + 15) / 16, mnn_ncoll(n1), 0, bR, bC, idx1, idx2, dist, nm, st);
+                    CK(hipStreamSynchronize(s));
+                    long long h[64]; CK(hipMemcpy(h, st, 64 * 8, hipMemcpyDeviceToHost));
+                    printf("  post stamps (us after block 0 start): block0 loads %.2f chain %.2f second %.2f stored %.2f | collector start %.2f", (h[1] - h[0]) / 100.0, (h[2] - h[0]) / 100.0, (h[3] - h[0]) / 100.0, (h[4] - h[0]) / 100.0, (h[16] - h[0]) / 100.0);
+                    printf(" | last collector: counted-before %.2f own-polled %.2f end %.2f\n", (h[17] - h[0]) / 100.0, (h[18] - h[0]) / 100.0, (h[26] - h[0]) / 100.0);
+                }
+                hipFree(st);
+            }
+            time_kernel("k_rownorm_img", rownorm);
+            time_kernel("k_mnn_post", post);
+            for (int v = 0; v < NVT; ++v) {
+                rownorm(nullptr, nullptr);
+                char nmb[64]; snprintf(nmb, sizeof nmb, "gemm %s", probe_gemm_name(v));
+                const double us = time_kernel(nmb, [&](hipEvent_t a, hipEvent_t b) { probe_gemm(v, s, a, b, img1, n1, img2, n2, bR, bC, pairs); });
+                printf("      -> %.1f TFLOP/s = %.1f %% of 157.3\n", 2.0 * n1 * n2 * 64 / (us * 1e-6) / 1e12, 2.0 * n1 * n2 * 64 / (us * 1e-6) / 157.3e12 * 100);
+                // whole call, back to back on the stream
+                for (int i = 0; i < 10; ++i) { rownorm(nullptr, nullptr); probe_gemm(v, s, nullptr, nullptr, img1, n1, img2, n2, bR, bC, pairs); post(nullptr, nullptr); }
+                CK(hipEventRecord(e0, s));
+                for (int i = 0; i < iters; ++i) { rownorm(nullptr, nullptr); probe_gemm(v, s, nullptr, nullptr, img1, n1, img2, n2, bR, bC, pairs); post(nullptr, nullptr); }
+                CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+                float msg; CK(hipEventElapsedTime(&msg, e0, e1));
+                printf("      whole call (3 kernels, back to back): %.2f us\n", msg / iters * 1e3);
+            }
+        }
+        hipFree(d1); hipFree(d2); hipFree(img1); hipFree(img2); hipFree(p1); hipFree(p2); hipFree(rv1); hipFree(rv2); hipFree(ri1); hipFree(ri2);
+        hipFree(bR); hipFree(bC); hipFree(pairs); hipFree(idx1); hipFree(idx2); hipFree(dist); hipFree(nm);
+    }
+    printf("%s\n", all_ok ? "ALL OK" : "SOME MISMATCH");
+    return all_ok ? 0 : 1;
+}

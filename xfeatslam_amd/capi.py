@@ -58,6 +58,9 @@ SYMBOLS = [
     ("xfh_extract_batch_device", _i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     ("xfh_match_mnn", _i, [_vp, _vp, _i, _vp, _i, _f, _vp, _vp, _vp, _pi]),
     ("xfh_match_mnn_device", _i, [_vp, _vp, _i, _vp, _i, _f, _vp, _vp, _vp, _vp]),
+    ("xfh_match_image_bytes", _sz, [_i]),
+    ("xfh_match_prepare_device", _i, [_vp, _vp, _i, _vp]),
+    ("xfh_match_mnn_prepared_device", _i, [_vp, _vp, _i, _vp, _i, _f, _vp, _vp, _vp, _vp]),
     ("xfh_descriptor_distance", _i, [_vp, _vp]),
     ("xfh_distance_i32", _i, [_vp, _vp, _i, _vp, _i, _vp]),
     ("xfh_distance_i32_device", _i, [_vp, _vp, _i, _vp, _i, _vp]),

@@ -80,6 +80,10 @@ int xfh_create(const xfh_config* cfg, xfh_ctx** out) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return XFH_ERR_NO_DEVICE;
     if (cfg->device < 0 || cfg->device >= ndev) return XFH_ERR_NO_DEVICE;
+    {   // the code objects in this library are gfx950 only
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess || strncmp(prop.gcnArchName, "gfx950", 6) != 0) return XFH_ERR_NO_DEVICE;
+    }
     xfh_ctx* c = new xfh_ctx();
     c->cfg = *cfg;
     if (c->cfg.nms_threshold <= 0.f) c->cfg.nms_threshold = 0.05f;
@@ -131,6 +135,18 @@ int xfh_create(const xfh_config* cfg, xfh_ctx** out) {
     if (hipHostMalloc((void**)&c->h_gray, (size_t)B * cfg->max_height * cfg->max_width, hipHostMallocDefault) != hipSuccess) return fail(XFH_ERR_OUT_OF_MEMORY);
 #undef A
     (void)rc;
+    // matcher workspace for frame-against-frame calls and the pinned output mirror of xfh_match_mnn: no allocation on the call path
+    if (match_ws_reserve(c, cfg->nfeatures, cfg->nfeatures) != hipSuccess) return fail(XFH_ERR_OUT_OF_MEMORY);
+    {
+        MatchWs& w = c->mws;
+        w.cap_out = (size_t)cfg->nfeatures * 12 + 256;
+        if (hipMalloc((void**)&w.o_buf, w.cap_out) != hipSuccess) return fail(XFH_ERR_OUT_OF_MEMORY);
+        if (hipHostMalloc((void**)&w.h_out, w.cap_out, hipHostMallocDefault) != hipSuccess) return fail(XFH_ERR_OUT_OF_MEMORY);
+        w.cap_hout = w.cap_out;
+        w.cap_in = 2 * (((size_t)cfg->nfeatures * 256 + 255) & ~(size_t)255);
+        if (hipMalloc((void**)&w.h_d1, w.cap_in) != hipSuccess) return fail(XFH_ERR_OUT_OF_MEMORY);
+    }
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return fail(XFH_ERR_HIP);
     *out = c;
     return XFH_OK;
 }
@@ -151,7 +167,8 @@ int xfh_destroy(xfh_ctx* c) {
     if (c->h_records) hipHostFree(c->h_records);
     if (c->h_gray) hipHostFree(c->h_gray);
     MatchWs& w = c->mws;
-    F(w.bestR); F(w.b2_buf); F(w.h_d1); F(w.o_idx1); F(w.o_tab); F(w.norm1);
+    F(w.img1); F(w.keys); F(w.b2_buf); F(w.h_d1); F(w.o_buf); F(w.o_tab);
+    if (w.h_out) hipHostFree(w.h_out);
     if (c->timer.ev) { for (int i = 0; i < 2 * KTimer::MAXEV; ++i) if (c->timer.ev[i]) hipEventDestroy(c->timer.ev[i]); free(c->timer.ev); }
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->ev_join) hipEventDestroy(c->ev_join);
@@ -175,8 +192,11 @@ static bool blob_find(const void* blob, size_t nbytes, const char* name, BlobEnt
         if (strncmp((const char*)q, name, 48) == 0) {
             memcpy(&e->ndim, q + 48, 4); memcpy(e->dims, q + 52, 16);
             uint64_t off; memcpy(&off, q + 68, 8);
-            size_t cnt = 1; for (uint32_t k = 0; k < e->ndim && k < 4; ++k) cnt *= e->dims[k];
-            if ((size_t)(data - p) + 4 * (off + cnt) > nbytes) return false;
+            if (e->ndim > 4) return false;
+            const uint64_t total = (nbytes - (size_t)(data - p)) / 4;            // floats in the data section
+            uint64_t cnt = 1;
+            for (uint32_t k = 0; k < e->ndim; ++k) { if (e->dims[k] != 0 && cnt > total / e->dims[k]) return false; cnt *= e->dims[k]; }
+            if (off > total || cnt > total - off) return false;                  // overflow-safe: off + cnt <= total
             e->p = (const float*)(data + 4 * off);
             return true;
         }
@@ -215,7 +235,7 @@ int xfh_load_weights(xfh_ctx* c, const void* blob, size_t nbytes) {
     for (int i = 0; i < XFH_NUM_LAYERS; ++i) {
         const LayerSpec& L = XFH_LAYERS[i];
         snprintf(nm, sizeof nm, "%s.layer.0.weight", L.name);
-        if (!blob_find(blob, nbytes, nm, &e) || (int)e.dims[0] != L.cout || (int)e.dims[1] != L.cin || (int)e.dims[2] != L.ks) return XFH_ERR_BAD_WEIGHTS;
+        if (!blob_find(blob, nbytes, nm, &e) || e.ndim != 4 || (int)e.dims[0] != L.cout || (int)e.dims[1] != L.cin || (int)e.dims[2] != L.ks || (int)e.dims[3] != L.ks) return XFH_ERR_BAD_WEIGHTS;
         int rc;
         if (i < 3) {
             std::vector<float> o((size_t)9 * L.cin * L.cout);
@@ -368,7 +388,7 @@ int xfh_detect_and_compute(xfh_ctx* c, const uint8_t* gray, int H, int W, int st
 // ------------------------------------------------------------------------- matching
 int xfh_descriptor_distance(const float* a, const float* b) {
     double s = 0.0;
-    for (int k = 0; k < 64; ++k) { const float d = a[k] - b[k]; s += (double)d * (double)d; }
+    for (int k = 0; k < 64; ++k) { const double d = (double)(a[k] - b[k]); s = fma(d, d, s); }      // the device kernels' expression (k_dist_i32)
     const float nd = (float)s;
     return (int)(nd * 512);
 }
@@ -385,9 +405,32 @@ int xfh_match_mnn_device(xfh_ctx* c, const float* d1, int n1, const float* d2, i
                          int* idx1, int* idx2, float* dist, int* n_matches) {
     if (!c || n1 < 0 || n2 < 0 || !n_matches) return XFH_ERR_INVALID_ARG;
     if ((n1 > 0 && !d1) || (n2 > 0 && !d2)) return XFH_ERR_INVALID_ARG;
+    if (n1 > 0 && n2 > 0 && (!idx1 || !idx2 || !dist)) return XFH_ERR_INVALID_ARG;
     if ((((uintptr_t)d1) | ((uintptr_t)d2)) & 15) return XFH_ERR_INVALID_ARG;
     HIPCK(c, hipSetDevice(c->cfg.device));
     HIPCK(c, launch_mnn(c, d1, n1, d2, n2, min_cossim, idx1, idx2, dist, n_matches));
+    return XFH_OK;
+}
+
+size_t xfh_match_image_bytes(int n) { return n <= 0 ? 0 : (size_t)((n + 255) / 256) * 256 * 64 * sizeof(float); }
+
+int xfh_match_prepare_device(xfh_ctx* c, const float* d, int n, void* image) {
+    if (!c || n < 0) return XFH_ERR_INVALID_ARG;
+    if (n == 0) return XFH_OK;
+    if (!d || !image || ((((uintptr_t)d) | ((uintptr_t)image)) & 15)) return XFH_ERR_INVALID_ARG;
+    HIPCK(c, hipSetDevice(c->cfg.device));
+    HIPCK(c, launch_match_prepare(c, d, n, (float*)image));
+    return XFH_OK;
+}
+
+int xfh_match_mnn_prepared_device(xfh_ctx* c, const void* image1, int n1, const void* image2, int n2, float min_cossim,
+                                  int* idx1, int* idx2, float* dist, int* n_matches) {
+    if (!c || n1 < 0 || n2 < 0 || !n_matches) return XFH_ERR_INVALID_ARG;
+    if ((n1 > 0 && !image1) || (n2 > 0 && !image2)) return XFH_ERR_INVALID_ARG;
+    if (n1 > 0 && n2 > 0 && (!idx1 || !idx2 || !dist)) return XFH_ERR_INVALID_ARG;
+    if ((((uintptr_t)image1) | ((uintptr_t)image2)) & 15) return XFH_ERR_INVALID_ARG;
+    HIPCK(c, hipSetDevice(c->cfg.device));
+    HIPCK(c, launch_mnn_prepared(c, (const float*)image1, n1, (const float*)image2, n2, min_cossim, idx1, idx2, dist, n_matches));
     return XFH_OK;
 }
 
@@ -400,30 +443,36 @@ int xfh_match_mnn(xfh_ctx* c, const float* d1, int n1, const float* d2, int n2, 
     MatchWs& w = c->mws;
     const size_t b1 = (size_t)n1 * 64 * 4, b2 = (size_t)n2 * 64 * 4;
     const size_t b1p = (b1 + 255) & ~(size_t)255;
-    int rc = grow(c, (void**)&w.h_d1, &w.cap_in, b1p + b2);
+    int rc = grow(c, (void**)&w.h_d1, &w.cap_in, b1p + b2);              // sized for nfeatures x nfeatures in xfh_create
     if (rc != XFH_OK) return rc;
     w.h_d2 = (float*)((char*)w.h_d1 + b1p);
     const int nm = n1 < n2 ? n1 : n2;
-    rc = grow(c, (void**)&w.o_idx1, &w.cap_out, (size_t)nm * 12 + 256);
-    if (rc != XFH_OK) return rc;
-    w.o_idx2 = w.o_idx1 + nm; w.o_dist = (float*)(w.o_idx2 + nm); w.o_n = (int*)(w.o_dist + nm);
+    const size_t ob = (size_t)nm * 12 + 256;                              // n at 0, idx1 / idx2 / dist from byte 256 on
+    if ((rc = grow(c, (void**)&w.o_buf, &w.cap_out, ob)) != XFH_OK) return rc;
+    if (w.cap_hout < ob) {
+        if (w.h_out) { hipHostFree(w.h_out); w.h_out = nullptr; w.cap_hout = 0; }
+        HIPCK(c, hipHostMalloc((void**)&w.h_out, ob, hipHostMallocDefault));
+        w.cap_hout = ob;
+    }
+    int* o_n = w.o_buf; int* o_idx1 = w.o_buf + 64; int* o_idx2 = o_idx1 + nm; float* o_dist = (float*)(o_idx2 + nm);
     HIPCK(c, hipMemcpyAsync(w.h_d1, d1, b1, hipMemcpyHostToDevice, c->stream));
     HIPCK(c, hipMemcpyAsync(w.h_d2, d2, b2, hipMemcpyHostToDevice, c->stream));
-    HIPCK(c, launch_mnn(c, w.h_d1, n1, w.h_d2, n2, min_cossim, w.o_idx1, w.o_idx2, w.o_dist, w.o_n));
-    int n = 0;
-    HIPCK(c, hipMemcpyAsync(&n, w.o_n, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, launch_mnn(c, w.h_d1, n1, w.h_d2, n2, min_cossim, o_idx1, o_idx2, o_dist, o_n));
+    // one asynchronous copy of the whole output block into pinned memory (<= 48 KB at 4096 rows), then one wait
+    HIPCK(c, hipMemcpyAsync(w.h_out, w.o_buf, ob, hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));
-    if (n > 0) {
-        HIPCK(c, hipMemcpy(idx1, w.o_idx1, (size_t)n * 4, hipMemcpyDeviceToHost));
-        HIPCK(c, hipMemcpy(idx2, w.o_idx2, (size_t)n * 4, hipMemcpyDeviceToHost));
-        HIPCK(c, hipMemcpy(dist, w.o_dist, (size_t)n * 4, hipMemcpyDeviceToHost));
-    }
+    const int n = w.h_out[0];
+    if (n < 0 || n > nm) { c->hip_err = "k_mnn_post: collector timed out"; return XFH_ERR_HIP; }
+    memcpy(idx1, w.h_out + 64, (size_t)n * 4);
+    memcpy(idx2, w.h_out + 64 + nm, (size_t)n * 4);
+    memcpy(dist, w.h_out + 64 + 2 * (size_t)nm, (size_t)n * 4);
     *n_matches = n;
     return XFH_OK;
 }
 
 int xfh_distance_i32_device(xfh_ctx* c, const float* d1, int n1, const float* d2, int n2, int32_t* out) {
     if (!c || n1 < 0 || n2 < 0) return XFH_ERR_INVALID_ARG;
+    if (n1 > 0 && n2 > 0 && (!d1 || !d2 || !out)) return XFH_ERR_INVALID_ARG;
     HIPCK(c, hipSetDevice(c->cfg.device));
     HIPCK(c, launch_dist_i32(c, d1, n1, d2, n2, out));
     return XFH_OK;
@@ -454,7 +503,7 @@ int xfh_best2_csr_device(xfh_ctx* c, const float* q, int nq, const float* tg, in
                          int* best_idx, int* best_dist, int* second_idx, int* second_dist) {
     if (!c || nq < 0 || nt < 0) return XFH_ERR_INVALID_ARG;
     if (nq == 0) return XFH_OK;
-    if (!q || !offsets || !best_idx || !best_dist || !second_idx || !second_dist) return XFH_ERR_INVALID_ARG;
+    if (!q || !offsets || !indices || !tg || !best_idx || !best_dist || !second_idx || !second_dist) return XFH_ERR_INVALID_ARG;
     if ((((uintptr_t)q) | ((uintptr_t)tg)) & 15) return XFH_ERR_INVALID_ARG;
     HIPCK(c, hipSetDevice(c->cfg.device));
     HIPCK(c, launch_best2(c, q, nq, tg, offsets, indices, init_dist, best_idx, best_dist, second_idx, second_dist));

@@ -95,18 +95,25 @@ struct KTimer {
 
 // ---- matcher workspace ----------------------------------------------------------------
 struct MatchWs {
-    u64* bestR = nullptr; u64* bestC = nullptr; size_t cap_best = 0;   // packed arg-max keys per d1 row / d2 row
+    float* img1 = nullptr; float* img2 = nullptr; size_t cap_p1 = 0, cap_p2 = 0;   // panel images of the two sets (capacity in panels of 256 rows)
+    u64* keys = nullptr; u64* bestR = nullptr; u64* pairs = nullptr; u64* bestC = nullptr;   // one allocation: arg-max keys per d1 / d2 row, (column, value) pairs
+    bool keys_clean = true;                                            // bestR / bestC are all zero (allocation or a prepared-image call)
     float* h_d1 = nullptr; float* h_d2 = nullptr; size_t cap_in = 0;   // device staging of host inputs
-    int* o_idx1 = nullptr; int* o_idx2 = nullptr; float* o_dist = nullptr; int* o_n = nullptr; size_t cap_out = 0;
+    int* o_buf = nullptr; size_t cap_out = 0;                          // device outputs of the host call: n, idx1[nm], idx2[nm], dist[nm]
+    int* h_out = nullptr; size_t cap_hout = 0;                         // pinned mirror of o_buf
     int32_t* o_tab = nullptr; size_t cap_tab = 0;
-    float* norm1 = nullptr; float* norm2 = nullptr; size_t cap_norm = 0;   // normalised, k-permuted rows
     void* b2_buf = nullptr; size_t cap_b2 = 0;                             // staging for the host-pointer best2 call
 };
 
 // ---- launchers implemented in the .hip files ------------------------------------------
 struct xfh_ctx;
+hipError_t match_ws_reserve(xfh_ctx* c, int n1, int n2);
 hipError_t launch_mnn(xfh_ctx* c, const float* d1, int n1, const float* d2, int n2, float min_cossim,
                       int* idx1, int* idx2, float* dist, int* n_matches);
+hipError_t launch_match_prepare(xfh_ctx* c, const float* d, int n, float* img);
+hipError_t launch_mnn_prepared(xfh_ctx* c, const float* img1, int n1, const float* img2, int n2, float min_cossim,
+                               int* idx1, int* idx2, float* dist, int* n_matches);
+hipError_t launch_mnn_gemm(xfh_ctx* c, const float* img1, int n1, const float* img2, int n2, u64* bestR, u64* bestC, u64* pairs);   // kernels_mnn_gemm.hip
 hipError_t launch_dist_i32(xfh_ctx* c, const float* d1, int n1, const float* d2, int n2, int32_t* out);
 hipError_t launch_distinctive(xfh_ctx* c, const float* table, const int* offsets, const int* indices, int n_groups, int max_group,
                               int* best_pos, int* best_median);

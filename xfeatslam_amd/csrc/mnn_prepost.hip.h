@@ -1,0 +1,252 @@
+// mnn_prepost.hip.h -- the kernels around the match GEMM: k_rownorm_img (normalise + panel images) and k_mnn_post
+// (second arg-max level, mutual check, ordered output).  Included by kernels_match.hip and tools/probes/mnn_probe.hip.
+#pragma once
+#include "mnn_layout.h"
+
+// k_rownorm_img: F::normalize of both descriptor sets (ORBmatcher.cc:358-359: fp64 sum of squares, fp32
+// sqrt / max(.,1e-12) / divide) written as panel images; rows past the end of a set are written as zeros
+// (the GEMM masks their products).  Also resets the arg-max keys (bestR == nullptr: one set only, no keys -- the
+// prepare form).  16 lanes per row, 16 rows per block;
+// blocks [0, P1*16) serve d1, the rest d2 (P = panels of the set).
+__global__ __launch_bounds__(256)
+void k_rownorm_img(const float* __restrict__ d1, int n1, const float* __restrict__ d2, int n2, int P1,
+                   float* __restrict__ img1, float* __restrict__ img2, u64* __restrict__ bestR, u64* __restrict__ bestC) {
+    const int t = threadIdx.x, sub = t & 15;
+    int blk = blockIdx.x;
+    const bool second = blk >= P1 * 16;
+    if (second) blk -= P1 * 16;
+    const int row = blk * 16 + (t >> 4);
+    const float* d = second ? d2 : d1;
+    const int n = second ? n2 : n1;
+    float* img = second ? img2 : img1;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (row < n) {
+        v = *(const f32x4*)(d + (size_t)row * 64 + sub * 4);
+        if (sub == 0 && bestR) (second ? bestC : bestR)[row] = 0ull;
+    }
+    double ss = (double)v.x * (double)v.x + (double)v.y * (double)v.y + (double)v.z * (double)v.z + (double)v.w * (double)v.w;
+    ss += __shfl_xor(ss, 1); ss += __shfl_xor(ss, 2); ss += __shfl_xor(ss, 4); ss += __shfl_xor(ss, 8);
+    const float nrm = fmaxf((float)sqrt(ss), 1e-12f);
+    const float a = v.x / nrm, b = v.y / nrm, c = v.z / nrm, e = v.w / nrm;
+    // this lane holds elements 4*sub .. 4*sub+3; its pair lane (sub^1) holds the other half of the group of 8.
+    // even lane writes the piece of the even elements (e0 e2 e4 e6), odd lane the piece of the odd ones.
+    const bool odd = sub & 1;
+    const float sx = odd ? a : b, sy = odd ? c : e;            // what the partner needs from me
+    const float rx = __shfl_xor(sx, 1), ry = __shfl_xor(sy, 1);
+    const f32x4 outv = odd ? f32x4{rx, ry, b, e} : f32x4{a, c, rx, ry};
+    const int r256 = row & (MNN_PANEL - 1);
+    const int pos = mnn_pos(r256);
+    *(f32x4*)(img + (size_t)(row >> 8) * MNN_PANEL_FLOATS + mnn_piece(pos, sub >> 1, odd ? 1 : 0)) = outv;
+}
+
+// panel base + 16 * position of a row, and its swizzle term
+__device__ __forceinline__ const float* mnn_row(const float* img, int row, int& s) {
+    const int pos = mnn_pos(row & (MNN_PANEL - 1));
+    s = mnn_swz(pos);
+    return img + (size_t)(row >> 8) * MNN_PANEL_FLOATS + pos * 16;
+}
+
+// k_mnn_post: second level of the arg-max, the mutual check (ORBmatcher.cc:367-372), the min_cossim gate (:361)
+// and the ordered output (:371-403) in one launch.  Blocks 0 .. gridDim.x-2: sixteen lanes per d1 row, sixteen rows
+// per workgroup (= one d1 row group of the bestC keys).
+//   bestR[row] = (M, gc): the row maximum M sits in d2 rows 16*gc .. 16*gc+15 -> lane c recomputes <row, 16*gc + c>;
+//   the first one equal to M is m12[row] (torch.max returns the first index of the maximum).
+//   bestC[col] = (Mc, gr): m21[col] is the first d1 row of 16*gr .. 16*gr+15 whose dot product equals Mc.  `row` is a
+//   mutual match iff Mc == M, row lies in that group and no earlier row of the group reaches Mc -- lane c recomputes
+//   <16*gr + c, col> for the rows before `row` only; those rows are the workgroup's own 16 rows.
+// The kernel is bound by dependent memory round trips and by the number of cache-line requests, so all global reads
+// are cooperative and coalesced (one 16-byte piece per lane; a 16-lane group fetches one 256-byte row per instruction)
+// and go through LDS, where lane c then reads "its" candidate row: the workgroup's own 16 d1 rows once (sA), and for
+// every row its 16 candidate d2 rows (sB).  Two dependent round trips remain: bestR -> candidates (+ their bestC keys).
+// Each row publishes (column or -1, value) as one 8-byte agent-scope atomic store.  The last `ncoll` blocks are the
+// collectors (grid = nb + ncoll, nb = ceil(n1/16)): they poll the pairs (agent-scope atomic loads; MNN_PAIR_EMPTY = not
+// yet written; the data is its own flag, so no ticket and no fence) and write the matches in ascending idx1 with
+// dist = sqrt(2 (1 - cos)).  The writers never wait, so the collectors cannot dead-lock whatever the dispatch order
+// is; their spin is bounded.  mnn_ncoll(n1) = min(16, blocks of 256 rows).  zero_keys: the last collector clears
+// bestR / bestC afterwards (the prepared-image call style has no k_rownorm_img to do it).
+#define MNN_PAIR_EMPTY 0xFFFFFFFE00000000ull
+#define MNN_SPIN_LIMIT (1 << 22)
+__host__ __device__ inline int mnn_ncoll(int n1) { const int nq = (n1 + 255) >> 8; return nq < 16 ? (nq < 1 ? 1 : nq) : 16; }
+#define MNN_POST_LD 68                 // LDS row pitch in floats (272 B: per-lane rows are read conflict free)
+#define MNN_POST_LDS ((16 + 256) * MNN_POST_LD * 4)
+template <int TS>            // TS (probes only): wall-clock stamps of block 0 / the collector into `stamps`
+__global__ __launch_bounds__(256)
+void k_mnn_post(const float* __restrict__ img1, int n1, const float* __restrict__ img2, int n2,
+                const u64* __restrict__ bestR, const u64* __restrict__ bestC, float min_cossim,
+                u64* __restrict__ pairs, int nb, int ncoll, int zero_keys, u64* __restrict__ zR, u64* __restrict__ zC, int* __restrict__ idx1, int* __restrict__ idx2, float* __restrict__ dist, int* __restrict__ n_matches,
+                long long* __restrict__ stamps) {
+    extern __shared__ __attribute__((aligned(16))) float spost[];
+    const int t = threadIdx.x;
+#define MNN_STAMP(k) do { if (TS && t == 0 && (blockIdx.x == 0 || blockIdx.x + 1 == gridDim.x)) stamps[(blockIdx.x ? 16 : 0) + (k)] = wall_clock64(); } while (0)
+    MNN_STAMP(0);
+    if ((int)blockIdx.x < nb) {
+        float* sA = spost;                               // [16 rows][68]: row in natural piece order (piece p = 2g + half at 4p)
+        float* sB = spost + 16 * MNN_POST_LD;            // [16 row groups][16 candidates][68]
+        const int c = t & 15, grp = t >> 4;
+        const int row = blockIdx.x * 16 + grp;           // the image holds whole panels: rows up to the panel end are readable (zeros)
+        const u64 kr = (row < n1) ? bestR[row] : 0ull;
+        {
+            int sa;
+            const float* ra = mnn_row(img1, row, sa);
+            *(f32x4*)(sA + grp * MNN_POST_LD + c * 4) = *(const f32x4*)(ra + (c >> 2) * 4096 + (((c & 3) ^ sa) << 2));
+        }
+        const float M = ord2f((unsigned)(kr >> 32));
+        const int gc = (int)(0xFFFFFFFFu - (unsigned)(kr & 0xFFFFFFFFull));
+        const int col = gc * MNN_CGROUP + c;
+        const bool have = kr != 0ull && col < n2;
+        const u64 kcand = have ? bestC[col] : 0ull;
+        if (kr != 0ull) {                                // candidate rows 16*gc .. 16*gc+15 (inside the panel image: readable)
+            f32x4 pv[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                int sb;
+                const float* rb = mnn_row(img2, gc * MNN_CGROUP + j, sb);
+                pv[j] = *(const f32x4*)(rb + (c >> 2) * 4096 + (((c & 3) ^ sb) << 2));
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) *(f32x4*)(sB + (grp * 16 + j) * MNN_POST_LD + c * 4) = pv[j];
+        }
+        MNN_STAMP(1);
+        __syncthreads();
+        // <row, col>: one fp32 fma chain in k order -- the arithmetic of the MFMA loop (k = 2j of lane-half 0, then 2j+1)
+        const float* pa = sA + grp * MNN_POST_LD;
+        const float* pb = sB + (grp * 16 + c) * MNN_POST_LD;
+        float dv = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const f32x4 a0 = *(const f32x4*)(pa + g * 8), a1 = *(const f32x4*)(pa + g * 8 + 4);
+            const f32x4 b0 = *(const f32x4*)(pb + g * 8), b1 = *(const f32x4*)(pb + g * 8 + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { dv = fmaf(a0[j], b0[j], dv); dv = fmaf(a1[j], b1[j], dv); }
+        }
+        MNN_STAMP(2);
+        unsigned eq = (have && dv == M) ? (1u << c) : 0u;
+        eq |= __shfl_xor(eq, 1); eq |= __shfl_xor(eq, 2); eq |= __shfl_xor(eq, 4); eq |= __shfl_xor(eq, 8);
+        int cs;
+        if (eq) cs = __builtin_ctz(eq);
+        else {      // cannot happen while the recomputation is bit-identical (NaN rows aside); stay deterministic anyway
+            u64 k = have ? mnn_pack_key(dv, (unsigned)c) : 0ull;
+            k = mnn_umax64(k, __shfl_xor(k, 1)); k = mnn_umax64(k, __shfl_xor(k, 2)); k = mnn_umax64(k, __shfl_xor(k, 4)); k = mnn_umax64(k, __shfl_xor(k, 8));
+            cs = (int)(0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull)) & 15;
+        }
+        const int cstar = gc * MNN_CGROUP + cs;
+        const u64 kc = __shfl(kcand, (t & 48) | cs);                       // the lane of this wave that holds column cstar
+        const float Mc = ord2f((unsigned)(kc >> 32));
+        const int gr = (int)(0xFFFFFFFFu - (unsigned)(kc & 0xFFFFFFFFull));
+        bool mutual = false;
+        if (kr != 0ull && cstar < n2 && kc != 0ull && Mc == M && (row >> 4) == gr) {      // uniform over the 16 lanes of a row
+            const float* pg = sA + c * MNN_POST_LD;                        // d1 row 16*gr + c is row c of this workgroup
+            const float* ps = sB + (grp * 16 + cs) * MNN_POST_LD;
+            float d2v = 0.f;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const f32x4 a0 = *(const f32x4*)(pg + g * 8), a1 = *(const f32x4*)(pg + g * 8 + 4);
+                const f32x4 b0 = *(const f32x4*)(ps + g * 8), b1 = *(const f32x4*)(ps + g * 8 + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { d2v = fmaf(a0[j], b0[j], d2v); d2v = fmaf(a1[j], b1[j], d2v); }
+            }
+            unsigned earlier = (c < grp && d2v == Mc) ? 1u : 0u;
+            earlier |= __shfl_xor(earlier, 1); earlier |= __shfl_xor(earlier, 2); earlier |= __shfl_xor(earlier, 4); earlier |= __shfl_xor(earlier, 8);
+            mutual = earlier == 0u;
+        }
+        MNN_STAMP(3);
+        if (min_cossim > 0.f) mutual = mutual && (M > min_cossim);
+        if (c == 0 && row < n1) {
+            const u64 pr = ((u64)(unsigned)(mutual ? cstar : -1) << 32) | (u64)__builtin_bit_cast(unsigned, M);
+            __hip_atomic_store(pairs + row, pr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        MNN_STAMP(4);
+        return;
+    }
+    // ---- collectors.  Collector k owns the rows [k*span, (k+1)*span) (span = a multiple of 256) and writes their matches;
+    // it polls every row below its upper end: the rows before its range are only counted (they give its output offset),
+    // so the collectors need nothing from each other.  Thread t reads rows 256 q + t (coalesced); inside a block of 256
+    // rows the output order comes from a ballot scan in the wave plus the counts of the lower waves (LDS).
+    // The pairs are re-armed by the NEXT call's k_mnn_gemm_img (a collector must not: the others still read them).
+    int* wcnt = (int*)spost;                             // [qb own][4 waves], then [4] for the count of the rows before
+    const int lane = t & 63, wave = t >> 6;
+    const int k = blockIdx.x - nb;                       // collector index
+    const int nq = (n1 + 255) >> 8;                      // blocks of 256 rows
+    const int qspan = (nq + ncoll - 1) / ncoll;
+    const int q_lo = (k * qspan < nq) ? k * qspan : nq, q_hi = (q_lo + qspan < nq) ? q_lo + qspan : nq;
+    const u64 below = (1ull << lane) - 1ull;
+    int before_w = 0;                                    // matches in rows < 256*q_lo seen by THIS wave (same in all its lanes)
+    bool timeout = false;
+    for (int q0 = 0; q0 < q_lo; q0 += 16) {
+        u64 pr[16];
+        for (int spin = 0;; ++spin) {                   // 16 loads unconditionally: they are in flight together
+            bool pending = false;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int i = (q0 + u) * 256 + t;
+                pr[u] = (q0 + u < q_lo && i < n1) ? __hip_atomic_load(pairs + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0ull;
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) pending = pending || pr[u] == MNN_PAIR_EMPTY;
+            if (!pending) break;
+            if (spin > MNN_SPIN_LIMIT) { timeout = true; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) before_w += __popcll(__ballot((int)(unsigned)(pr[u] >> 32) >= 0 && pr[u] != MNN_PAIR_EMPTY));
+    }
+    if (TS) MNN_STAMP(1);
+    int run = 0;
+    for (int q0 = q_lo; q0 < q_hi; q0 += 4) {            // own rows, four blocks of 256 at a time
+        u64 pr[4];
+        for (int spin = 0;; ++spin) {
+            bool pending = false;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = (q0 + u) * 256 + t;
+                pr[u] = (q0 + u < q_hi && i < n1) ? __hip_atomic_load(pairs + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0ull;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) pending = pending || pr[u] == MNN_PAIR_EMPTY;
+            if (!pending) break;
+            if (spin > MNN_SPIN_LIMIT) { timeout = true; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (TS) MNN_STAMP(2);
+        int pre[4];
+        __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_s_barrier();      // wcnt of the previous round has been read (LDS only: no vmcnt wait)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool m = (int)(unsigned)(pr[u] >> 32) >= 0 && pr[u] != MNN_PAIR_EMPTY;
+            const u64 bal = __ballot(m);
+            pre[u] = m ? __popcll(bal & below) : -1;
+            if (lane == 0) wcnt[u * 4 + wave] = __popcll(bal);
+        }
+        if (q0 == q_lo && lane == 0) wcnt[16 + wave] = before_w;
+        __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_s_barrier();
+        if (q0 == q_lo) run = wcnt[16] + wcnt[17] + wcnt[18] + wcnt[19];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            int bef = 0, tot = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { const int v = wcnt[u * 4 + w]; if (w < wave) bef += v; tot += v; }
+            if (pre[u] >= 0) {
+                const int off = run + bef + pre[u];
+                idx1[off] = (q0 + u) * 256 + t; idx2[off] = (int)(unsigned)(pr[u] >> 32);
+                const float cd = 1.0f - __builtin_bit_cast(float, (unsigned)(pr[u] & 0xFFFFFFFFull));
+                dist[off] = sqrtf(2.0f * cd);
+            }
+            run += tot;
+        }
+    }
+    if (k == ncoll - 1) {                                // the last collector has seen every row
+        if (q_lo >= q_hi) {                              // (it owns no rows when nq < ncoll * qspan: its count is all in before_w)
+            if (lane == 0) wcnt[16 + wave] = before_w;
+            __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_s_barrier();
+            run = wcnt[16] + wcnt[17] + wcnt[18] + wcnt[19];
+        }
+        if (__syncthreads_or(timeout ? 1 : 0)) run = -1;   // a writer never showed up (cannot happen): report it instead of hanging
+        if (t == 0) *n_matches = run;
+        if (zero_keys) {                                 // every row has been published: nobody reads the keys any more
+            for (int i = t; i < n1; i += 256) zR[i] = 0ull;
+            for (int i = t; i < n2; i += 256) zC[i] = 0ull;
+        }
+    }
+    MNN_STAMP(10);
+#undef MNN_STAMP
+}

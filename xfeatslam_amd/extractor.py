@@ -91,6 +91,30 @@ class Context:
         k = nm.value
         return i1[:k].copy(), i2[:k].copy(), dist[:k].copy()
 
+    def match_prepare(self, desc: np.ndarray):
+        """xfh_match_prepare_device: upload n x 64 rows and build their panel image once -> (DeviceBuffer image, n)"""
+        d = np.ascontiguousarray(desc, np.float32)
+        n = len(d)
+        raw = capi.DeviceBuffer(max(d.nbytes, 16)).upload(d)
+        img = capi.DeviceBuffer(max(lib().xfh_match_image_bytes(n), 16))
+        check(lib().xfh_match_prepare_device(self.h, raw.ptr, n, img.ptr), self.h)
+        self.synchronize()
+        raw.free()
+        return img, n
+
+    def match_mnn_prepared(self, p1, p2, min_cossim: float = -1.0):
+        """xfh_match_mnn_prepared_device on two prepared sets (results identical to match_mnn on their rows)"""
+        (img1, n1), (img2, n2) = p1, p2
+        nm = max(1, min(n1, n2))
+        out = capi.DeviceBuffer(nm * 12 + 64)
+        check(lib().xfh_match_mnn_prepared_device(self.h, img1.ptr, n1, img2.ptr, n2, float(min_cossim),
+                                                  out.ptr + 64, out.ptr + 64 + 4 * nm, out.ptr + 64 + 8 * nm, out.ptr), self.h)
+        self.synchronize()
+        k = int(out.download(np.int32, 1)[0])
+        i1 = out.download(np.int32, nm, 64)[:k]; i2 = out.download(np.int32, nm, 64 + 4 * nm)[:k]; dist = out.download(np.float32, nm, 64 + 8 * nm)[:k]
+        out.free()
+        return i1, i2, dist
+
     def distance_i32(self, d1: np.ndarray, d2: np.ndarray) -> np.ndarray:
         d1 = np.ascontiguousarray(d1, np.float32); d2 = np.ascontiguousarray(d2, np.float32)
         out = np.zeros((len(d1), len(d2)), np.int32)
