@@ -37,7 +37,8 @@ typedef enum {
     XFH_ERR_NO_DEVICE = 7,        /* device ordinal absent or not gfx950: the library never falls back */
     XFH_ERR_OUT_OF_MEMORY = 8,
     XFH_ERR_BATCH_TOO_LARGE = 9,
-    XFH_ERR_IO = 10
+    XFH_ERR_IO = 10,
+    XFH_ERR_COMM = 11             /* RCCL missing or a collective failed; see xfh_last_hip_error */
 } xfh_status;
 
 /* mirrors cv::KeyPoint field for field (28 bytes): pt.x, pt.y, size, angle, response,
@@ -95,10 +96,13 @@ int xfh_load_weights_file(xfh_ctx* ctx, const char* path);
 int xfh_extract(xfh_ctx* ctx, const uint8_t* gray, int H, int W, int stride_bytes, int lap_x0, int lap_x1,
                 xfh_keypoint* kps_out, float* desc_out, int* n_valid, int* mono_index);
 
-/* Split form of xfh_extract: submit copies the image into the ctx's pinned staging buffer and
- * enqueues H2D, the kernels and the D2H copy of the record, then returns; collect waits for them and unpacks.  One
- * submission may be outstanding per ctx (a second submit before collect overwrites the first).  Between the two the
- * caller is free to work -- e.g. submit the right image of a stereo pair on a second ctx, or track the previous frame. */
+/* Split form of xfh_extract: submit copies the image into a pinned staging buffer of the ctx and
+ * enqueues H2D and the kernels, which write the record straight into pinned host memory, then returns; collect waits
+ * for the oldest submission and unpacks it (only the valid rows are copied, the padding is filled on the host).  Up to
+ * XFH_MAX_INFLIGHT submissions may be outstanding per ctx (a further submit returns XFH_ERR_INVALID_ARG until one is
+ * collected), so frame t+1 can be uploaded and computed while the caller still copies out / tracks frame t; or submit the
+ * right image of a stereo pair on a second ctx. */
+#define XFH_MAX_INFLIGHT 2
 int xfh_extract_submit(xfh_ctx* ctx, const uint8_t* gray, int H, int W, int stride_bytes, int lap_x0, int lap_x1);
 int xfh_extract_collect(xfh_ctx* ctx, xfh_keypoint* kps_out, float* desc_out, int* n_valid, int* mono_index);
 
@@ -184,6 +188,37 @@ int xfh_distinctive_csr(xfh_ctx* ctx, const float* table, int n_rows, const int*
                         int* best_pos, int* best_median);
 int xfh_distinctive_csr_device(xfh_ctx* ctx, const float* d_table, int n_rows, const int* d_offsets, const int* d_indices,
                                int n_groups, int max_group, int* d_best_pos, int* d_best_median);
+
+/* ---- multi-GPU exchange (BASELINE.json configs[3]) ---------------------------------------------------
+ * Frames are independent: frame i of a batch goes to rank i mod R (one process and one ctx per GPU, every rank holds the
+ * weights) and the fixed-size records travel to the rank that runs the sequential SLAM state machine (the reference is
+ * one process, src/System.cc:197-233) with RCCL over xGMI.  These calls wrap librccl directly (dlopen at
+ * xfh_comm_create); no Python or torch is involved.  Rank 0 calls xfh_comm_unique_id and ships the 128 bytes to the
+ * other ranks by any means (TCP, MPI, a file); then every rank calls xfh_comm_create.
+ *   xfh_allgather_records   : ncclAllGather -- d_all receives world x B records, rank r's at offset r * B * record_bytes
+ *   xfh_gather_records_root : ncclSend / ncclRecv -- only `root` receives (same layout); cheaper when one rank consumes
+ *   xfh_gather_compact_root : only header + valid rows travel (a frame with n_valid of nfeatures rows sends n_valid * 284 B);
+ *                             shard r lands at d_all + r * xfh_compact_bytes_max(nfeatures, B) with shard_bytes[r] bytes, and
+ *                             xfh_unpack_compact restores a frame's padded form on the host.  Needs one host round trip for
+ *                             the sizes (the only blocking call of the three).
+ * All of them start when the ctx stream reaches the call (the records are complete) and run on the ctx's communication
+ * stream, so the next extraction overlaps them; `gen` (0 / 1) names the record buffer generation the call reads:
+ * xfh_comm_fence(ctx, gen) makes the ctx stream wait for the last collective on that generation before the buffer is
+ * overwritten, xfh_comm_synchronize waits on the host. */
+#define XFH_UNIQUE_ID_BYTES 128
+int xfh_comm_unique_id(void* id_out /* XFH_UNIQUE_ID_BYTES */);
+int xfh_comm_create(xfh_ctx* ctx, const void* unique_id, int rank, int world);
+int xfh_comm_destroy(xfh_ctx* ctx);
+int xfh_comm_rank(xfh_ctx* ctx);
+int xfh_comm_world(xfh_ctx* ctx);
+int xfh_allgather_records(xfh_ctx* ctx, const void* d_records, int B, void* d_all, int gen);
+int xfh_gather_records_root(xfh_ctx* ctx, const void* d_records, int B, void* d_all, int root, int gen);
+size_t xfh_compact_bytes_max(int nfeatures, int B);
+int xfh_gather_compact_root(xfh_ctx* ctx, const void* d_records, int B, void* d_all, size_t* shard_bytes /* [world], root only */, int root, int gen);
+int xfh_unpack_compact(const void* shard, size_t nbytes, int frame, int nfeatures, xfh_keypoint* kps_out, float* desc_out, int* n_valid, int* mono_index);
+int xfh_allgather_bytes(xfh_ctx* ctx, const void* d_send, size_t nbytes, void* d_recv, int gen);   /* e.g. timings, barriers */
+int xfh_comm_fence(xfh_ctx* ctx, int gen);
+int xfh_comm_synchronize(xfh_ctx* ctx);
 
 /* ---- plumbing ----------------------------------------------------------------------- */
 int xfh_synchronize(xfh_ctx* ctx);

@@ -68,3 +68,48 @@ def test_shard_arithmetic():
     assert xd.frames_per_rank(10, 4) == 3 and xd.frames_per_rank(8, 8) == 1
     g = [[f"r{r}j{j}" for j in range(3)] for r in range(4)]
     assert xd.unshard(g, 10, 4) == [f"r{i % 4}j{i // 4}" for i in range(10)]
+
+
+def _uid_worker(rank, world, port, out_dir):
+    import sys
+    sys.path.insert(0, ROOT)
+    uid = xd.exchange_unique_id(rank, world, "127.0.0.1", port, lambda: bytes(range(128)))
+    open(os.path.join(out_dir, f"uid{rank}.bin"), "wb").write(uid)
+
+
+def test_unique_id_bootstrap_world3(tmp_path):
+    """the out-of-band step of xfh_comm_create: rank 0 serves the 128-byte id over TCP, late and early joiners both get it"""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    mp.spawn(_uid_worker, args=(3, port, str(tmp_path)), nprocs=3, join=True)
+    for r in range(3):
+        assert open(tmp_path / f"uid{r}.bin", "rb").read() == bytes(range(128))
+
+
+def test_unpack_compact_host_side():
+    """xfh_unpack_compact (host code of the compact gather): a hand-packed shard of two frames restores the padded records"""
+    import ctypes as C
+    from xfeatslam_amd import capi
+    L = capi.lib()
+    nf, B = 8, 2
+    nv, mono = [5, 0], [3, 0]                      # frame 0: 3 front + 2 back rows, frame 1: empty
+    total = sum(nv)
+    hdr_b = (B * 16 + 255) & ~255; kps_b = (total * 28 + 255) & ~255
+    shard = np.zeros(256 + hdr_b + kps_b + total * 256, np.uint8)
+    shard[:12].view(np.int32)[:] = (B, nf, total)
+    for b in range(B):
+        shard[256 + 16 * b:256 + 16 * b + 16].view(np.int32)[:] = (nv[b], mono[b], 77, 0)
+    kps = np.zeros(total, capi.KP_DTYPE); kps["x"] = np.arange(total) + 1; kps["size"] = 1; kps["angle"] = -1; kps["class_id"] = -1
+    desc = np.arange(total * 64, dtype=np.float32).reshape(total, 64)
+    shard[256 + hdr_b:256 + hdr_b + total * 28] = kps.view(np.uint8)
+    shard[256 + hdr_b + kps_b:] = desc.reshape(-1).view(np.uint8)
+    for b in range(B):
+        ok = np.zeros(nf, capi.KP_DTYPE); od = np.full((nf, 64), 9, np.float32); a, m = C.c_int(), C.c_int()
+        assert L.xfh_unpack_compact(shard.ctypes.data, shard.nbytes, b, nf, ok.ctypes.data, od.ctypes.data, C.byref(a), C.byref(m)) == 0
+        assert (a.value, m.value) == (nv[b], mono[b])
+        if b == 0:
+            assert ok["x"].tolist() == [1, 2, 3, 0, 0, 0, 4, 5] and ok["class_id"].tolist() == [-1] * 8 and ok["angle"][3] == -1 and ok["size"][3] == 0
+            assert np.array_equal(od[:3], desc[:3]) and np.array_equal(od[6:], desc[3:5]) and not od[3:6].any()
+        else:
+            assert not ok["x"].any() and not od.any() and (ok["angle"] == -1).all()
+    assert L.xfh_unpack_compact(shard.ctypes.data, 300, 0, nf, ok.ctypes.data, od.ctypes.data, None, None) == 1      # truncated shard

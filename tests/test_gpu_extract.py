@@ -244,6 +244,22 @@ def test_submit_collect_stereo_pair(gpu_lib, weights_dense):
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2:] == b[2:]
     assert L.xfh_extract_collect(ctxs[0].h, out[0][0].ctypes.data, out[0][1].ctypes.data, None, None) == 1   # nothing pending
     print(f"stereo pair: sequential {t_seq * 1e3:.2f} ms, both in flight {t_par * 1e3:.2f} ms")
+    # one ctx, XFH_MAX_INFLIGHT = 2 frames in flight (frame t+1 uploaded and computed while frame t is collected), in order
+    c = ctxs[0]
+    seq = [imgs[0], imgs[1], imgs[0][::-1].copy(), imgs[1]]
+    want = [blocking(c, im, laps[0]) for im in seq]
+    capi.check(L.xfh_extract_submit(c.h, seq[0].ctypes.data, H, W, W, 0, 0), c.h)
+    got = []
+    for t in range(len(seq)):
+        if t + 1 < len(seq):
+            capi.check(L.xfh_extract_submit(c.h, seq[t + 1].ctypes.data, H, W, W, 0, 0), c.h)
+            if t == 0:
+                assert L.xfh_extract_submit(c.h, seq[0].ctypes.data, H, W, W, 0, 0) == 1      # ring full: collect first
+        k = np.full(nf, 7, KP_DTYPE); d = np.full((nf, 64), 7, np.float32); nv, mono = C.c_int(), C.c_int()
+        capi.check(L.xfh_extract_collect(c.h, k.ctypes.data, d.ctypes.data, C.byref(nv), C.byref(mono)), c.h)
+        got.append((k, d, nv.value, mono.value))
+    for a, b in zip(want, got):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2:] == b[2:]
     for c in ctxs:
         c.close()
 

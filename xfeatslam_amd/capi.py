@@ -21,7 +21,7 @@ assert KP_DTYPE.itemsize == 28
 
 OK = 0
 STATUS = {0: "OK", 1: "INVALID_ARG", 2: "EMPTY_IMAGE", 3: "BAD_SIZE", 4: "NO_WEIGHTS", 5: "BAD_WEIGHTS",
-          6: "HIP", 7: "NO_DEVICE", 8: "OUT_OF_MEMORY", 9: "BATCH_TOO_LARGE", 10: "IO"}
+          6: "HIP", 7: "NO_DEVICE", 8: "OUT_OF_MEMORY", 9: "BATCH_TOO_LARGE", 10: "IO", 11: "COMM"}
 ERR_EMPTY_IMAGE = 2
 ERR_NO_DEVICE = 7
 
@@ -68,6 +68,19 @@ SYMBOLS = [
     ("xfh_best2_csr_device", _i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     ("xfh_distinctive_csr", _i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp]),
     ("xfh_distinctive_csr_device", _i, [_vp, _vp, _i, _vp, _vp, _i, _i, _vp, _vp]),
+    ("xfh_comm_unique_id", _i, [_vp]),
+    ("xfh_comm_create", _i, [_vp, _vp, _i, _i]),
+    ("xfh_comm_destroy", _i, [_vp]),
+    ("xfh_comm_rank", _i, [_vp]),
+    ("xfh_comm_world", _i, [_vp]),
+    ("xfh_allgather_records", _i, [_vp, _vp, _i, _vp, _i]),
+    ("xfh_gather_records_root", _i, [_vp, _vp, _i, _vp, _i, _i]),
+    ("xfh_compact_bytes_max", _sz, [_i, _i]),
+    ("xfh_gather_compact_root", _i, [_vp, _vp, _i, _vp, C.POINTER(_sz), _i, _i]),
+    ("xfh_unpack_compact", _i, [_vp, _sz, _i, _i, _vp, _vp, _pi, _pi]),
+    ("xfh_allgather_bytes", _i, [_vp, _vp, _sz, _vp, _i]),
+    ("xfh_comm_fence", _i, [_vp, _i]),
+    ("xfh_comm_synchronize", _i, [_vp]),
     ("xfh_synchronize", _i, [_vp]),
     ("xfh_set_stream", _i, [_vp, _vp]),
     ("xfh_strerror", C.c_char_p, [_i]),
@@ -113,7 +126,7 @@ class XfhError(RuntimeError):
 def check(status: int, ctx=None):
     if status != OK:
         detail = ""
-        if ctx is not None and status == 6:
+        if ctx is not None and status in (6, 11):
             detail = lib().xfh_last_hip_error(ctx).decode()
         raise XfhError(status, detail)
 

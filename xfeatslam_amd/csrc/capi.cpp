@@ -30,6 +30,7 @@ const char* xfh_strerror(int s) {
         case XFH_ERR_OUT_OF_MEMORY: return "out of memory";
         case XFH_ERR_BATCH_TOO_LARGE: return "batch larger than ctx max_batch";
         case XFH_ERR_IO: return "file i/o error";
+        case XFH_ERR_COMM: return "RCCL error";
         default: return "unknown status";
     }
 }
@@ -133,6 +134,14 @@ int xfh_create(const xfh_config* cfg, xfh_ctx** out) {
     A(c->d_records, rec * B);
     if (hipHostMalloc((void**)&c->h_records, rec * B, hipHostMallocDefault) != hipSuccess) return fail(XFH_ERR_OUT_OF_MEMORY);
     if (hipHostMalloc((void**)&c->h_gray, (size_t)B * cfg->max_height * cfg->max_width, hipHostMallocDefault) != hipSuccess) return fail(XFH_ERR_OUT_OF_MEMORY);
+    c->s_hgray[0] = c->h_gray; c->s_dgray[0] = c->d_gray; c->s_hrec[0] = c->h_records;
+    for (int k = 1; k < xfh_ctx::SLOTS; ++k) {
+        A(c->s_dgray[k], (size_t)cfg->max_height * cfg->max_width);
+        if (hipHostMalloc((void**)&c->s_hgray[k], (size_t)cfg->max_height * cfg->max_width, hipHostMallocDefault) != hipSuccess) return fail(XFH_ERR_OUT_OF_MEMORY);
+        if (hipHostMalloc((void**)&c->s_hrec[k], rec, hipHostMallocDefault) != hipSuccess) return fail(XFH_ERR_OUT_OF_MEMORY);
+    }
+    for (int k = 0; k < xfh_ctx::SLOTS; ++k)
+        if (hipEventCreateWithFlags(&c->s_done[k], hipEventDisableTiming) != hipSuccess) return fail(XFH_ERR_HIP);
 #undef A
     (void)rc;
     // matcher workspace for frame-against-frame calls and the pinned output mirror of xfh_match_mnn: no allocation on the call path
@@ -154,6 +163,7 @@ int xfh_create(const xfh_config* cfg, xfh_ctx** out) {
 int xfh_destroy(xfh_ctx* c) {
     if (!c) return XFH_OK;
     hipSetDevice(c->cfg.device);
+    xfh_comm_destroy(c);
     if (c->stream && c->stream != c->own_stream) hipStreamSynchronize(c->stream);     // work queued on a caller's stream
     if (c->own_stream) hipStreamSynchronize(c->own_stream);
     if (c->aux_stream) hipStreamSynchronize(c->aux_stream);
@@ -166,6 +176,8 @@ int xfh_destroy(xfh_ctx* c) {
     F(c->cand); F(c->cand_count); F(c->slot_src); F(c->sel_key); F(c->sel_n); F(c->d_records);
     if (c->h_records) hipHostFree(c->h_records);
     if (c->h_gray) hipHostFree(c->h_gray);
+    for (int k = 1; k < xfh_ctx::SLOTS; ++k) { F(c->s_dgray[k]); if (c->s_hgray[k]) hipHostFree(c->s_hgray[k]); if (c->s_hrec[k]) hipHostFree(c->s_hrec[k]); }
+    for (int k = 0; k < xfh_ctx::SLOTS; ++k) if (c->s_done[k]) hipEventDestroy(c->s_done[k]);
     MatchWs& w = c->mws;
     F(w.img1); F(w.keys); F(w.b2_buf); F(w.h_d1); F(w.o_buf); F(w.o_tab);
     if (w.h_out) hipHostFree(w.h_out);
@@ -342,32 +354,54 @@ int xfh_extract_batch(xfh_ctx* c, const uint8_t* gray, int B, int H, int W, int 
     return XFH_OK;
 }
 
-// xfh_extract = submit + collect.  The split form lets the caller overlap its own work (or the other camera of a
-// stereo rig on a second ctx) with the GPU and the D2H copy of the record.
+// xfh_extract = submit + collect.  The split form lets the caller overlap its own work (the other camera of a stereo
+// rig on a second ctx, tracking of the previous frame, or simply the next frame: up to XFH_SLOTS submissions may be
+// outstanding, collected in order) with the GPU.  The record is written by the kernels straight into
+// pinned host memory; collect waits for the slot's event and copies only the valid rows (header + front / back
+// segments), padding the rest on the host (the reference's default KeyPoint / zero rows, XFextractor.cc:310-312).
 int xfh_extract_submit(xfh_ctx* c, const uint8_t* gray, int H, int W, int stride, int lap0, int lap1) {
     int rc = check_extract(c, gray, 1, H, W);
     if (rc != XFH_OK) return rc;
     if (stride < W) return XFH_ERR_INVALID_ARG;
+    if (c->s_count >= xfh_ctx::SLOTS) return XFH_ERR_INVALID_ARG;        // collect first
     HIPCK(c, hipSetDevice(c->cfg.device));
-    const size_t rec = xfh_record_bytes(c->cfg.nfeatures);
-    for (int y = 0; y < H; ++y) memcpy(c->h_gray + (size_t)y * W, gray + (size_t)y * stride, (size_t)W);
-    HIPCK(c, hipMemcpyAsync(c->d_gray, c->h_gray, (size_t)H * W, hipMemcpyHostToDevice, c->stream));
-    HIPCK(c, run_extract(c, c->d_gray, 1, H, W, lap0, lap1, c->d_records));
-    HIPCK(c, hipMemcpyAsync(c->h_records, c->d_records, rec, hipMemcpyDeviceToHost, c->stream));
-    c->pending = true;
+    const int k = (c->s_head + c->s_count) % xfh_ctx::SLOTS;
+    uint8_t* hg = c->s_hgray[k];
+    if (stride == W) memcpy(hg, gray, (size_t)H * W);
+    else for (int y = 0; y < H; ++y) memcpy(hg + (size_t)y * W, gray + (size_t)y * stride, (size_t)W);
+    HIPCK(c, hipMemcpyAsync(c->s_dgray[k], hg, (size_t)H * W, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, run_extract(c, c->s_dgray[k], 1, H, W, lap0, lap1, c->s_hrec[k], false));
+    HIPCK(c, hipEventRecord(c->s_done[k], c->stream));
+    ++c->s_count;
     return XFH_OK;
 }
 
 int xfh_extract_collect(xfh_ctx* c, xfh_keypoint* kps, float* desc, int* n_valid, int* mono_index) {
     if (!c || !kps || !desc) return XFH_ERR_INVALID_ARG;
-    if (!c->pending) return XFH_ERR_INVALID_ARG;           // nothing was submitted
+    if (c->s_count <= 0) return XFH_ERR_INVALID_ARG;           // nothing was submitted
     HIPCK(c, hipSetDevice(c->cfg.device));
-    HIPCK(c, hipStreamSynchronize(c->stream));
-    c->pending = false;
+    const int k = c->s_head;
+    HIPCK(c, hipEventSynchronize(c->s_done[k]));
+    c->s_head = (c->s_head + 1) % xfh_ctx::SLOTS; --c->s_count;
     const int nf = c->cfg.nfeatures;
-    const RecordHeader* h = (const RecordHeader*)c->h_records;
-    memcpy(kps, c->h_records + xfh_record_kps_offset(), (size_t)nf * sizeof(xfh_keypoint));
-    memcpy(desc, c->h_records + xfh_record_desc_offset(nf), (size_t)nf * 64 * sizeof(float));
+    const uint8_t* r = c->s_hrec[k];
+    const RecordHeader* h = (const RecordHeader*)r;
+    const xfh_keypoint* rk = (const xfh_keypoint*)(r + xfh_record_kps_offset());
+    const float* rd = (const float*)(r + xfh_record_desc_offset(nf));
+    int front = h->mono_index, back = h->n_valid - h->mono_index;
+    if (front < 0 || back < 0 || front + back > nf) { front = nf; back = 0; }          // never trust a torn header: copy everything
+    memcpy(kps, rk, (size_t)front * sizeof(xfh_keypoint));
+    memcpy(desc, rd, (size_t)front * 256);
+    const int pad = nf - front - back;
+    if (pad > 0) {
+        const xfh_keypoint dk = {0.f, 0.f, 0.f, -1.f, 0.f, 0, -1};                       // cv::KeyPoint()
+        for (int i = front; i < front + pad; ++i) kps[i] = dk;
+        memset(desc + (size_t)front * 64, 0, (size_t)pad * 256);
+    }
+    if (back > 0) {
+        memcpy(kps + (nf - back), rk + (nf - back), (size_t)back * sizeof(xfh_keypoint));
+        memcpy(desc + (size_t)(nf - back) * 64, rd + (size_t)(nf - back) * 64, (size_t)back * 256);
+    }
     if (n_valid) *n_valid = h->n_valid;
     if (mono_index) *mono_index = h->mono_index;
     return XFH_OK;

@@ -18,8 +18,10 @@ struct DevWeights {
     bool loaded = false;
 };
 
+struct XfhComm;
 struct xfh_ctx {
     xfh_config cfg;
+    XfhComm* comm = nullptr;        // RCCL communicator + communication stream (comm.cpp), created by xfh_comm_create
     int Hmax = 0, Wmax = 0;         // resized maxima (multiples of 32)
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;   // own_stream or an external one
@@ -52,11 +54,17 @@ struct xfh_ctx {
     int* slot_src = nullptr;                    // [B][nfeatures]
     u64* sel_key = nullptr;                     // [B][nfeatures]
     int* sel_n = nullptr;                       // [B]
-    uint8_t* d_records = nullptr;               // [B][record_bytes] for the host API
-    uint8_t* h_records = nullptr;               // pinned
-    uint8_t* h_gray = nullptr;                  // pinned
+    uint8_t* d_records = nullptr;               // [B][record_bytes] for the host API (xfh_extract_batch)
+    uint8_t* h_records = nullptr;               // pinned mirror, [B][record_bytes]
+    uint8_t* h_gray = nullptr;                  // pinned, [B] frames
 
-    bool pending = false;                       // xfh_extract_submit without its xfh_extract_collect yet
+    // xfh_extract_submit / _collect: a ring of XFH_SLOTS single-frame submissions.  Slot buffers: pinned image, device
+    // image, and a pinned record that the kernels write DIRECTLY (host memory is device visible: no D2H command, the
+    // stores cross PCIe while k_desc runs).  Slot 0 shares the batch buffers above.
+    static const int SLOTS = 2;
+    uint8_t* s_hgray[SLOTS] = {}; uint8_t* s_dgray[SLOTS] = {}; uint8_t* s_hrec[SLOTS] = {};
+    hipEvent_t s_done[SLOTS] = {};
+    int s_head = 0, s_count = 0;                // oldest outstanding slot, number outstanding
 
     MatchWs mws;
     KTimer timer;
@@ -89,4 +97,4 @@ inline void launch_k(xfh_ctx* c, int kernel_id, int layer, K kern, dim3 grid, di
     } while (0)
 
 // launchers (kernels_*.hip)
-hipError_t run_extract(xfh_ctx* c, const uint8_t* d_gray, int B, int H0, int W0, int lap0, int lap1, uint8_t* d_records);
+hipError_t run_extract(xfh_ctx* c, const uint8_t* d_gray, int B, int H0, int W0, int lap0, int lap1, uint8_t* d_records, bool write_padding = true);

@@ -613,7 +613,7 @@ void k_select(const u64* __restrict__ cand, size_t cand_cap, const int* __restri
 // ---- k_desc: one wave per output slot, lane = descriptor channel ---------------------------------
 __global__ __launch_bounds__(256)
 void k_desc(const float* __restrict__ m1n, size_t m_stride, const int* __restrict__ slot_src, const u64* __restrict__ sel_key,
-            int H, int W, int nfeatures, float rw, float rh, uint8_t* __restrict__ records, size_t rec_bytes, size_t kps_off, size_t desc_off) {
+            int H, int W, int nfeatures, float rw, float rh, uint8_t* __restrict__ records, size_t rec_bytes, size_t kps_off, size_t desc_off, int write_padding) {
     const int b = blockIdx.z;
     const int slot = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (slot >= nfeatures) return;
@@ -622,6 +622,7 @@ void k_desc(const float* __restrict__ m1n, size_t m_stride, const int* __restric
     float* dd = (float*)(rec + desc_off + (size_t)slot * 256);
     const int src = slot_src[(size_t)b * nfeatures + slot];
     if (src < 0) {
+        if (!write_padding) return;        // host-visible record (xfh_extract_submit): the host pads, nothing crosses PCIe
         // default cv::KeyPoint(): pt (0,0), size 0, angle -1, response 0, octave 0, class_id -1
         if (lane < 5) kp[lane] = (lane == 3) ? -1.f : 0.f;
         else if (lane < 7) ((int*)kp)[lane] = (lane == 5) ? 0 : -1;
@@ -667,7 +668,7 @@ hipError_t launch_finalize_image(xfh_ctx* c, int B, int npart, double count);
 #define CK(x) do { hipError_t _e = (x); if (_e != hipSuccess) return _e; } while (0)
 enum { PRO_PLAIN = 0, PRO_BN = 1, PRO_IN = 2 };
 
-hipError_t run_extract(xfh_ctx* c, const uint8_t* d_gray, int B, int H0, int W0, int lap0, int lap1, uint8_t* d_records) {
+hipError_t run_extract(xfh_ctx* c, const uint8_t* d_gray, int B, int H0, int W0, int lap0, int lap1, uint8_t* d_records, bool write_padding) {
     const int H = (H0 / 32) * 32, W = (W0 / 32) * 32;
     c->B = B; c->H0 = H0; c->W0 = W0; c->H = H; c->W = W;
     const int h4 = H / 4, w4 = W / 4, h8 = H / 8, w8 = W / 8;
@@ -765,6 +766,6 @@ hipError_t run_extract(xfh_ctx* c, const uint8_t* d_gray, int B, int H0, int W0,
     }
     CK(hipGetLastError());
     launch_k(c, XFH_K_DESC, -1, k_desc, dim3((nf + 3) / 4, 1, B), dim3(256), 0, c->m1n, c->raw_stride[17], c->slot_src, c->sel_key, H, W, nf, rw, rh,
-                       d_records, rec, xfh_record_kps_offset(), xfh_record_desc_offset(nf));
+                       d_records, rec, xfh_record_kps_offset(), xfh_record_desc_offset(nf), write_padding ? 1 : 0);
     return hipGetLastError();
 }

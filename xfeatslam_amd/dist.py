@@ -7,8 +7,12 @@ records (n_valid, mono_index, keypoints[nfeatures], desc[nfeatures x 64]; includ
 hands everything to rank 0, which feeds the strictly sequential SLAM state machine in
 timestamp order.  There is no other data-path collective.
 
-One process per GPU (`python -m torch.distributed.run --nproc-per-node N ...`), backend
-"nccl" (= RCCL on ROCm) for device tensors and "gloo" for the CPU tests.
+One process per GPU (`python -m torch.distributed.run --nproc-per-node N ...` only LAUNCHES the ranks
+and sets RANK / WORLD_SIZE / MASTER_*).  On the GPU the collective is the C ABI's (`xfh_comm_create`,
+`xfh_allgather_records`, `xfh_gather_records_root`, `xfh_gather_compact_root`: librccl called directly by
+libxfeat_hip.so, class `Comm` below); the 128-byte RCCL unique id travels from rank 0 to the others over a
+plain TCP socket (`exchange_unique_id`), so no torch is needed in the data path.  The torch/gloo functions
+further down serve the CPU tests of the shard / gather / unshard logic.
 """
 from __future__ import annotations
 
@@ -37,6 +41,94 @@ def unshard(gathered, n_frames: int, world: int):
     for i in range(n_frames):
         out.append(gathered[i % world][i // world])
     return out
+
+
+def exchange_unique_id(rank: int, world: int, addr: str, port: int, make_id, nbytes: int = 128, timeout: float = 120.0) -> bytes:
+    """rank 0 calls make_id() -> bytes and serves it to the world-1 other ranks on addr:port; the others connect
+    (retrying until rank 0 listens) and read it.  Plain TCP: this is the only out-of-band step RCCL needs."""
+    import socket
+    import time
+    if world <= 1:
+        return make_id()
+    if rank == 0:
+        uid = make_id()
+        assert len(uid) == nbytes
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as srv:
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind((addr, port))
+            srv.listen(world)
+            srv.settimeout(timeout)
+            for _ in range(world - 1):
+                conn, _ = srv.accept()
+                with conn:
+                    conn.sendall(uid)
+        return uid
+    deadline = time.time() + timeout
+    while True:
+        try:
+            with socket.create_connection((addr, port), timeout=5.0) as cl:
+                buf = b""
+                while len(buf) < nbytes:
+                    chunk = cl.recv(nbytes - len(buf))
+                    if not chunk:
+                        raise ConnectionError("short read")
+                    buf += chunk
+                return buf
+        except (ConnectionRefusedError, ConnectionError, OSError):
+            if time.time() > deadline:
+                raise
+            time.sleep(0.05)
+
+
+class Comm:
+    """RCCL communicator of one ctx through the C ABI (include/xfeat_hip.h, multi-GPU exchange)."""
+
+    def __init__(self, ctx, rank: int, world: int, addr: str = "127.0.0.1", port: int = 29533):
+        import ctypes as C
+        from . import capi
+        self.ctx, self.rank, self.world, self.capi, self.C = ctx, rank, world, capi, C
+        L = capi.lib()
+
+        def make_id():
+            buf = C.create_string_buffer(128)
+            capi.check(L.xfh_comm_unique_id(buf), ctx.h)
+            return buf.raw
+        uid = exchange_unique_id(rank, world, addr, port, make_id)
+        capi.check(L.xfh_comm_create(ctx.h, uid, rank, world), ctx.h)
+
+    def allgather_records(self, d_records: int, B: int, d_all: int, gen: int = 0):
+        self.capi.check(self.capi.lib().xfh_allgather_records(self.ctx.h, d_records, B, d_all, gen), self.ctx.h)
+
+    def gather_records_root(self, d_records: int, B: int, d_all: int, root: int = 0, gen: int = 0):
+        self.capi.check(self.capi.lib().xfh_gather_records_root(self.ctx.h, d_records, B, d_all or None, root, gen), self.ctx.h)
+
+    def gather_compact_root(self, d_records: int, B: int, d_all: int, root: int = 0, gen: int = 0):
+        sizes = (self.C.c_size_t * self.world)()
+        self.capi.check(self.capi.lib().xfh_gather_compact_root(self.ctx.h, d_records, B, d_all or None, sizes, root, gen), self.ctx.h)
+        return list(sizes)
+
+    def allgather_bytes(self, d_send: int, nbytes: int, d_recv: int, gen: int = 0):
+        self.capi.check(self.capi.lib().xfh_allgather_bytes(self.ctx.h, d_send, nbytes, d_recv, gen), self.ctx.h)
+
+    def fence(self, gen: int):
+        self.capi.check(self.capi.lib().xfh_comm_fence(self.ctx.h, gen), self.ctx.h)
+
+    def synchronize(self):
+        self.capi.check(self.capi.lib().xfh_comm_synchronize(self.ctx.h), self.ctx.h)
+
+    def barrier_max(self, value: float) -> float:
+        """all-gather of one double per rank through RCCL: doubles as the barrier, returns the maximum over ranks"""
+        import numpy as np
+        send = self.capi.DeviceBuffer(8).upload(np.array([value], np.float64))
+        recv = self.capi.DeviceBuffer(8 * self.world)
+        self.allgather_bytes(send.ptr, 8, recv.ptr, 0)
+        self.synchronize()
+        out = recv.download(np.float64, self.world)
+        send.free(); recv.free()
+        return float(out.max())
+
+    def close(self):
+        self.capi.lib().xfh_comm_destroy(self.ctx.h)
 
 
 def init_process_group(device_is_gpu: bool):
