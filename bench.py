@@ -5,17 +5,25 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the extraction hot path (XFextractor::operator(), reference
-src/XFextractor.cc:250-356) over one batch of B synthetic VGA frames per GPU, with the frames
-already resident in HBM and the 4096-row (keypoints, descriptors) records left in HBM; with
-N > 1 the step also all-gathers the records over RCCL (frame i -> GPU i mod N).
-`value` = frames/s over all GPUs.  The matching half of the metric (4096 x 4096 descriptor MNN
-match, pairs/s) is timed right after on descriptors of two extracted frames and reported in
-"match", with its own MFMA roofline line for k_mnn_gemm.  Rank 0 prints ONE JSON line.
+torch.distributed.run only LAUNCHES the ranks (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment); this
+script imports no torch: device memory, streams and the RCCL exchange all go through the C ABI of libxfeat_hip.so.
 
-The CPU baseline is the oracle (oracle/, a C restatement of the reference; "port") timed on
-the host cores on a bounded sample of the same frames; the first frame's GPU output is checked
-against it (parity verdict in the JSON).
+A "step" is one pass of the extraction hot path (XFextractor::operator(), reference src/XFextractor.cc:250-356) over
+one batch of B distinct synthetic VGA frames per GPU, with the frames already resident in HBM and the 4096-row
+(keypoints, descriptors) records left in HBM; with N > 1 the step also moves the records with RCCL (frame i -> GPU
+i mod N; xfh_allgather_records by default, --gather root|compact for the cheaper forms) on the ctx's
+communication stream, overlapped with the next step.  `value` = frames/s over all GPUs.  Rank 0 then reports, in the
+same JSON line:
+  roofline      dominant extraction kernel (3x3 64->64 at 1/8 resolution): algorithmic flops / average launch duration,
+                HIP events attached to every dispatch of the kernel inside the timed region
+  single_frame  one frame per call, device resident (latency path)
+  host_api      what the drop-in operator() really does: xfh_extract from host memory (H2D + kernels + record to host
+                inside the clock), synchronous latency and pipelined (2 frames in flight) throughput, nfeatures 4096 / 1000
+  match         4096 x 4096 MNN: whole call on raw descriptor rows (3 launches), on prepared images (2 launches), through
+                the host API, and the MFMA roofline of k_mnn_gemm_img
+  aux_kernels   k_dist_i32, k_best2_csr, k_distinctive_csr timings
+  cpu_baseline  the oracle (oracle/, a C restatement of the reference; "port") on the host cores: all cores and 1 thread
+  parity        GPU output of frame 0 / the match against the oracle, and a near-tie audit of the discrete decisions
 """
 from __future__ import annotations
 
@@ -33,13 +41,35 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, dense f32 MFMA
 NFEATURES = 4096
-KP_GAIN = 6.0                     # "dense" synthetic weights: > 4096 NMS candidates at VGA (BASELINE.md §4)
+KP_GAIN = 6.0                     # "dense" synthetic weights: > 4096 NMS candidates at VGA (BASELINE.md 4)
 DOMINANT_LAYERS = (7, 17)         # k_conv_mfma<64,64,3,1,4,2,1,16,PRO_BN,EPI_STATS,32>: block3.1, block_fusion.1
 
 
 def conv_flops(H, W):
     """algorithmic flops per frame of the 3x3 64->64 layer at 1/8 resolution"""
     return 2.0 * (H // 8) * (W // 8) * 64 * 64 * 9
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def usable_cores():
+    """hardware threads this process may really use: affinity mask, capped by the cgroup CPU quota"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
 
 
 def main():
@@ -51,147 +81,228 @@ def main():
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--streams", type=int, default=1, help="independent sub-batches in flight (one ctx + HIP stream each)")
-    ap.add_argument("--match-iters", type=int, default=200)
-    ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--match-iters", type=int, default=300)
+    ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the bounded all-core CPU-baseline sample (0 = skip)")
+    ap.add_argument("--gather", choices=["allgather", "root", "compact"], default="allgather")
+    ap.add_argument("--force-comm", action="store_true", help="run the RCCL exchange also with one rank")
+    ap.add_argument("--no-legs", action="store_true", help="timed region only (no host_api / match / aux / cpu legs)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0)); local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     N = max(world, 1)
-    torch = dist = None
-    use_dist = N > 1 or bool(os.environ.get("XFH_FORCE_DIST"))     # the env var exercises the RCCL path on one GPU
+    use_comm = N > 1 or args.force_comm
     saved_stdout = None
-    if use_dist:
-        # RCCL prints a version banner on stdout when the communicator is created: keep stdout clean
-        # for the single JSON line by pointing fd 1 at stderr until the result is printed
+    if use_comm:
+        # RCCL prints a version banner on stdout when the communicator is created: keep stdout clean for the single JSON
+        # line by pointing fd 1 at stderr until the result is printed
         sys.stdout.flush()
         saved_stdout = os.dup(1)
         os.dup2(2, 1)
-        # torch only for the process group / RCCL; it must be imported before the HIP library
-        # so that both share one HIP runtime
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
 
-    from xfeatslam_amd import capi, synth, weights as WT
+    from xfeatslam_amd import capi, dist as xd, synth, weights as WT
     from xfeatslam_amd.extractor import Context
     lib = capi.lib()
     if lib.xfh_device_count() <= 0:
         raise SystemExit("bench.py needs an MI355X: libxfeat_hip.so has no CPU fallback")
 
     B, H, W, K = args.batch, args.height, args.width, args.steps
+    dev = local_rank if N > 1 else 0
     blob = WT.pack_blob(WT.make_synthetic(1234, KP_GAIN))
     S = max(1, args.streams)
-    ctxs = [Context(nfeatures=NFEATURES, max_height=H, max_width=W, max_batch=B, device=local_rank if use_dist else 0) for _ in range(S)]
+    ctxs = [Context(nfeatures=NFEATURES, max_height=H, max_width=W, max_batch=B, device=dev) for _ in range(S)]
     for c_ in ctxs:
         c_.load_weights(blob)
     ctx = ctxs[0]
-    # frame i of the global batch goes to rank i mod N  (weak scaling: S*B frames per GPU per step)
-    base = synth.frames(min(B, 8), H, W, seed=42 + 100 * rank)
-    frames = np.concatenate([base] * ((B + len(base) - 1) // len(base)))[:B]
+    # frame i of the global batch goes to rank i mod N (weak scaling: S*B frames per GPU per step); every frame is distinct
+    frames = synth.frames(B, H, W, seed=42 + 1000 * rank)
     rec_bytes = ctx.rec_bytes
+    nf = NFEATURES
 
-    if use_dist:
-        # records of the S sub-batches are contiguous so that ONE all-gather moves them; two
-        # generations (ping-pong) let the collective of step i overlap the extraction of step i+1
-        d_in = torch.from_numpy(frames).cuda()
-        d_rec2 = [torch.empty(S * B * rec_bytes, dtype=torch.uint8, device="cuda") for _ in range(2)]
-        d_all2 = [torch.empty(N * S * B * rec_bytes, dtype=torch.uint8, device="cuda") for _ in range(2)]
-        in_ptr = d_in.data_ptr()
-        streams = [torch.cuda.Stream() for _ in range(S)]
-        comm = torch.cuda.Stream()
-        gathered = [None, None]                                # event: generation g has been all-gathered
-        for c_, st_ in zip(ctxs, streams):
-            capi.check(lib.xfh_set_stream(c_.h, C.c_void_p(st_.cuda_stream)), c_.h)
-        d_rec = d_rec2[0]
-        rec_ptr = d_rec.data_ptr()
-    else:
-        d_in = capi.DeviceBuffer(frames.nbytes).upload(frames)
-        d_recb = capi.DeviceBuffer(S * B * rec_bytes)
-        in_ptr, rec_ptr = d_in.ptr, d_recb.ptr
+    comm = None
+    if use_comm:
+        comm = xd.Comm(ctx, rank, N, os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29500")) + 17)
+    d_in = capi.DeviceBuffer(frames.nbytes).upload(frames)
+    d_rec = [capi.DeviceBuffer(S * B * rec_bytes) for _ in range(2 if use_comm else 1)]     # two generations under the exchange
+    d_all = None
+    if use_comm:
+        if args.gather == "allgather":
+            d_all = [capi.DeviceBuffer(N * S * B * rec_bytes) for _ in range(2)]
+        elif args.gather == "root":
+            d_all = [capi.DeviceBuffer(N * S * B * rec_bytes if rank == 0 else 16) for _ in range(2)]
+        else:
+            d_all = [capi.DeviceBuffer(N * int(lib.xfh_compact_bytes_max(nf, S * B)) if rank == 0 else 16) for _ in range(2)]
+    in_ptr, rec_ptr = d_in.ptr, d_rec[0].ptr
     step_no = [0]
 
     def step():
-        # S sub-batches of B frames, each on its own ctx/stream: the latency-bound tail kernels of
-        # one sub-batch (top-k, statistics, the 15x20 layers) overlap the convolutions of another
-        if use_dist:
-            g = step_no[0] & 1
-            base_ptr = d_rec2[g].data_ptr()
-            for k, (c_, st_) in enumerate(zip(ctxs, streams)):
-                if gathered[g] is not None:
-                    st_.wait_event(gathered[g])            # generation g was gathered two steps ago
-                capi.check(lib.xfh_extract_batch_device(c_.h, in_ptr, B, H, W, 0, 0, base_ptr + k * B * rec_bytes), c_.h)
-                comm.wait_stream(st_)
-            with torch.cuda.stream(comm):
-                dist.all_gather_into_tensor(d_all2[g], d_rec2[g])
-                gathered[g] = comm.record_event()
-            step_no[0] += 1
-        else:
-            for k, c_ in enumerate(ctxs):
-                capi.check(lib.xfh_extract_batch_device(c_.h, in_ptr, B, H, W, 0, 0, rec_ptr + k * B * rec_bytes), c_.h)
+        # S sub-batches of B frames, each on its own ctx / stream; the exchange of generation g runs on the ctx's
+        # communication stream while the next step extracts into the other generation
+        g = step_no[0] & 1 if use_comm else 0
+        if use_comm:
+            comm.fence(g)                                  # the collective that last read generation g has finished
+        for k, c_ in enumerate(ctxs):
+            capi.check(lib.xfh_extract_batch_device(c_.h, in_ptr, B, H, W, 0, 0, d_rec[g].ptr + k * B * rec_bytes), c_.h)
+        if use_comm:
+            for c_ in ctxs[1:]:
+                c_.synchronize()                           # only ctx 0's stream orders the collective
+            if args.gather == "allgather":
+                comm.allgather_records(d_rec[g].ptr, S * B, d_all[g].ptr, g)
+            elif args.gather == "root":
+                comm.gather_records_root(d_rec[g].ptr, S * B, d_all[g].ptr, 0, g)
+            else:
+                comm.gather_compact_root(d_rec[g].ptr, S * B, d_all[g].ptr, 0, g)
+        step_no[0] += 1
 
-    def sync():
-        if use_dist:
-            torch.cuda.synchronize()
-            dist.barrier()
-            torch.cuda.synchronize()
+    def sync(value=0.0):
+        """device idle on every rank, then a barrier (RCCL all-gather of one double); returns the max of `value`"""
         for c_ in ctxs:
             c_.synchronize()
+        if use_comm:
+            comm.synchronize()
+            return comm.barrier_max(value)
+        return value
 
     for _ in range(args.warmup):
         step()
     sync()
-    sync()
-    # roofline of the dominant kernel: dispatch-attached HIP events (hipExtLaunchKernelGGL) on every launch of
-    # that kernel.  With one sub-batch in flight (the default) they are taken INSIDE the timed region, on the
-    # stream the kernel runs on; rocprofv3 --kernel-trace of the same command reports the same average.
+    # roofline of the dominant kernel: dispatch-attached HIP events (hipExtLaunchKernelGGL) on every launch of that
+    # kernel.  With one sub-batch in flight (the default) they are taken INSIDE the timed region, on the stream the
+    # kernel runs on; rocprofv3 --kernel-trace of the same command reports the same average.
     layer_mask = sum(1 << l for l in DOMINANT_LAYERS)
     in_region = S == 1 and K * len(DOMINANT_LAYERS) <= 4096
     if in_region:
         ctx.timing_enable(capi.K["CONV_MFMA"], layer_mask)
+    sync()
     t0 = time.perf_counter()
     for _ in range(K):
         step()
-    sync()
-    elapsed = time.perf_counter() - t0
+    for c_ in ctxs:
+        c_.synchronize()
+    if use_comm:
+        comm.synchronize()
+    elapsed = sync(time.perf_counter() - t0)               # barrier; MAX over ranks
     if not in_region:
         # several sub-batches in flight share the CUs, so a launch's duration is not the kernel's own speed:
         # time the kernel in the same K steps once more on ONE stream
         ctx.timing_enable(capi.K["CONV_MFMA"], layer_mask)
-        for _ in range(K):
+        for _ in range(min(K, 2000)):
             capi.check(lib.xfh_extract_batch_device(ctx.h, in_ptr, B, H, W, 0, 0, rec_ptr), ctx.h)
         ctx.synchronize()
     n_conv, ms_conv = ctx.timing_read()
     ctx.timing_enable(0)
-    # configs[1] read literally: ONE frame per call (what a SLAM thread sees), device resident, back to back
+    frames_per_s = N * B * S * K / elapsed
+
+    if rank != 0:
+        sync()                                             # rank 0 runs its extra legs, then everybody leaves together
+        comm.close()
+        return
+
+    conv_us = ms_conv / max(n_conv, 1) * 1e3
+    conv_tf = conv_flops(H, W) * B / (conv_us * 1e-6) / 1e12 if n_conv else 0.0
+    out = {
+        "metric": "XFeat frames/s (VGA, 4096 kpts) + 4096x4096 desc-match pairs/s",
+        "value": frames_per_s, "unit": "frames/s", "n_gpus": N, "steps": K, "warmup": args.warmup,
+        "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"configs[1]: {H}x{W} u8 frames, XFeat extract, nfeatures {nf}, {B * S} distinct frames per GPU per step "
+                               f"({S} sub-batch(es) of {B} on separate HIP streams) (per-frame BatchNorm statistics), inputs and 4096-row records resident in HBM"
+                               + (f", RCCL {args.gather} of the records through the C ABI (xfh_comm_*), overlapped with the next step" if use_comm else ""),
+                   "frames_per_gpu_per_step": B * S, "sub_batches_in_flight": S, "height": H, "width": W, "nfeatures": nf,
+                   "weights": f"synthetic seed 1234, keypoint-logit gain {KP_GAIN}", "parallelism": f"frames x{N}"},
+    }
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")     # written by tools/summarize_profiles.py from --pmc passes
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath))
+        except Exception:
+            traffic = None
+    conv_traffic = None
+    if traffic and traffic.get("conv_bytes_per_launch"):
+        conv_traffic = traffic["conv_bytes_per_launch"] * (B / traffic["conv_batch"] if traffic.get("conv_batch") else 1.0)
+    out["roofline"] = {"kernel": "k_conv_mfma<64,64,3,1,4,2,1,16,1,0,32,1> (block3.1, block_fusion.1: 3x3 64->64 at 1/8 res)",
+                       "measured": "HIP events attached to every dispatch of the kernel inside the timed region" if in_region else "single-stream pass of the same steps",
+                       "bound": "mfma", "achieved": conv_tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": conv_tf / PEAK_F32_MFMA_TFLOPS,
+                       "traffic": conv_traffic, "avg_launch_us": conv_us, "launches": n_conv, "flops_per_launch": conv_flops(H, W) * B}
+
+    if not args.no_legs:
+        legs(out, args, lib, capi, synth, Context, ctx, blob, frames, d_in, d_rec[0], B, H, W, nf, rec_bytes, traffic, N)
+
+    if use_comm:
+        sync()
+        comm.close()
+    sys.stdout.flush()
+    if saved_stdout is not None:
+        os.dup2(saved_stdout, 1)
+    print(json.dumps(out), flush=True)
+
+
+def legs(out, args, lib, capi, synth, Context, ctx, blob, frames, d_in, d_recb, B, H, W, nf, rec_bytes, traffic, N):
+    in_ptr, rec_ptr = d_in.ptr, d_recb.ptr
+    # records of frames 0 and 1 on the ctx's own stream (the timed region may have left another generation here)
+    capi.check(lib.xfh_extract_batch_device(ctx.h, in_ptr, B, H, W, 0, 0, rec_ptr), ctx.h)
+    ctx.synchronize()
+
+    # ---- configs[1] read literally: ONE frame per call (what a SLAM thread sees), device resident, back to back -------
     for _ in range(10):
         capi.check(lib.xfh_extract_batch_device(ctx.h, in_ptr, 1, H, W, 0, 0, rec_ptr), ctx.h)
     ctx.synchronize()
     t1 = time.perf_counter()
-    n_single = 200
+    n_single = 300
     for _ in range(n_single):
         capi.check(lib.xfh_extract_batch_device(ctx.h, in_ptr, 1, H, W, 0, 0, rec_ptr), ctx.h)
     ctx.synchronize()
     single_dt = (time.perf_counter() - t1) / n_single
-    if use_dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    frames_per_s = N * B * S * K / elapsed
+    out["single_frame"] = {"ms_per_frame": single_dt * 1e3, "frames_per_s": 1.0 / single_dt,
+                           "note": "one 480x640 frame per xfh_extract_batch_device call, back to back on one stream (latency path of configs[1], device resident)"}
+    capi.check(lib.xfh_extract_batch_device(ctx.h, in_ptr, B, H, W, 0, 0, rec_ptr), ctx.h)   # restore the batch records
+    ctx.synchronize()
 
-    # ---- matching leg: 4096 x 4096 MNN on the descriptors of frame 0 vs frame 1 (device resident) --------
-    nf = NFEATURES
+    # ---- host API: the path the drop-in XFextractor::operator() takes (host image in, host keypoints / descriptors out)
+    host = {}
+    for nfh in (4096, 1000):
+        hc = Context(nfeatures=nfh, max_height=H, max_width=W, max_batch=1, device=ctx.device)
+        hc.load_weights(blob)
+        k = np.zeros(nfh, capi.KP_DTYPE); d = np.zeros((nfh, 64), np.float32); nv, mono = C.c_int(), C.c_int()
+        fr = [np.ascontiguousarray(frames[i % len(frames)]) for i in range(8)]
+
+        def blocking(i):
+            capi.check(lib.xfh_extract(hc.h, fr[i % 8].ctypes.data, H, W, W, 0, 0, k.ctypes.data, d.ctypes.data, C.byref(nv), C.byref(mono)), hc.h)
+        for i in range(10):
+            blocking(i)
+        t0 = time.perf_counter()
+        n_it = 200
+        for i in range(n_it):
+            blocking(i)
+        sync_dt = (time.perf_counter() - t0) / n_it
+        nvalid = nv.value
+        # pipelined: frame t+1 is submitted (H2D + kernels) before frame t is collected; XFH_MAX_INFLIGHT = 2
+        capi.check(lib.xfh_extract_submit(hc.h, fr[0].ctypes.data, H, W, W, 0, 0), hc.h)
+        t0 = time.perf_counter()
+        for i in range(n_it):
+            capi.check(lib.xfh_extract_submit(hc.h, fr[(i + 1) % 8].ctypes.data, H, W, W, 0, 0), hc.h)
+            capi.check(lib.xfh_extract_collect(hc.h, k.ctypes.data, d.ctypes.data, C.byref(nv), C.byref(mono)), hc.h)
+        pipe_dt = (time.perf_counter() - t0) / n_it
+        capi.check(lib.xfh_extract_collect(hc.h, k.ctypes.data, d.ctypes.data, C.byref(nv), C.byref(mono)), hc.h)
+        host[f"nfeatures_{nfh}"] = {"sync_ms_per_frame": sync_dt * 1e3, "sync_frames_per_s": 1.0 / sync_dt,
+                                    "pipelined_ms_per_frame": pipe_dt * 1e3, "pipelined_frames_per_s": 1.0 / pipe_dt, "n_valid": nvalid}
+        hc.close()
+    host["note"] = ("xfh_extract / xfh_extract_submit+collect on one ctx: pageable host image -> pinned -> H2D -> kernels -> record written "
+                    "to pinned host memory -> caller's buffers; everything inside the clock (SURVEY.md 8d 'host-visible')")
+    out["host_api"] = host
+    out["host_visible"] = {"value": host["nfeatures_4096"]["pipelined_frames_per_s"], "unit": "frames/s",
+                           "note": "single ctx, one frame per call, 2 frames in flight, host memory in and out (nfeatures 4096)"}
+
+    # ---- matching leg: 4096 x 4096 MNN on the descriptors of frame 0 vs frame 1 (device resident) ----------------------
     d1p = rec_ptr + ctx.desc_off
-    if use_dist:
-        capi.check(lib.xfh_set_stream(ctx.h, None), ctx.h)          # the matching leg runs on the ctx's own stream
     d2p = rec_ptr + (rec_bytes if B > 1 else 0) + ctx.desc_off
     mout = capi.DeviceBuffer(12 * nf + 64)
+    mo = (mout.ptr, mout.ptr + 4 * nf, mout.ptr + 8 * nf, mout.ptr + 12 * nf)
 
     def match():
-        capi.check(lib.xfh_match_mnn_device(ctx.h, d1p, nf, d2p, nf, -1.0, mout.ptr, mout.ptr + 4 * nf, mout.ptr + 8 * nf, mout.ptr + 12 * nf), ctx.h)
-    for _ in range(300):            # the clocks settle over a few hundred of these 40 us calls (first 200: ~6 % slower)
+        capi.check(lib.xfh_match_mnn_device(ctx.h, d1p, nf, d2p, nf, -1.0, *mo), ctx.h)
+    for _ in range(300):            # the clocks settle over a few hundred of these ~30 us calls
         match()
     ctx.synchronize()
     ctx.timing_enable(capi.K["MNN_GEMM"])
@@ -203,40 +314,105 @@ def main():
     n_gemm, ms_gemm = ctx.timing_read()
     ctx.timing_enable(0)
     n_matches = int(mout.download(np.int32, 1, 12 * nf)[0])
+    hm = (mout.download(np.int32, n_matches), mout.download(np.int32, n_matches, 4 * nf))
+    # prepared images (xfh_match_prepare_device once per frame, then two launches per pair)
+    img1 = capi.DeviceBuffer(int(lib.xfh_match_image_bytes(nf))); img2 = capi.DeviceBuffer(int(lib.xfh_match_image_bytes(nf)))
+    capi.check(lib.xfh_match_prepare_device(ctx.h, d1p, nf, img1.ptr), ctx.h)
+    capi.check(lib.xfh_match_prepare_device(ctx.h, d2p, nf, img2.ptr), ctx.h)
 
-    if rank != 0:
-        dist.barrier(); dist.destroy_process_group()
-        return
-
-    # ---- roofline lines ------------------------------------------------------------------------------
-    conv_us = ms_conv / max(n_conv, 1) * 1e3
-    conv_tf = conv_flops(H, W) * B / (conv_us * 1e-6) / 1e12 if n_conv else 0.0
+    def match_prepared():
+        capi.check(lib.xfh_match_mnn_prepared_device(ctx.h, img1.ptr, nf, img2.ptr, nf, -1.0, *mo), ctx.h)
+    for _ in range(100):
+        match_prepared()
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.match_iters):
+        match_prepared()
+    ctx.synchronize()
+    prep_dt = (time.perf_counter() - t0) / args.match_iters
+    n_matches_p = int(mout.download(np.int32, 1, 12 * nf)[0])
+    hp = (mout.download(np.int32, n_matches_p), mout.download(np.int32, n_matches_p, 4 * nf))
+    # host API
+    raw = d_recb.download(np.uint8, rec_bytes * min(B, 2))
+    recs = ctx.parse_records(raw, min(B, 2))
+    d1h, d2h = recs[0][1], recs[min(1, B - 1)][1]
+    for _ in range(5):
+        ctx.match_mnn(d1h, d2h)
+    t0 = time.perf_counter()
+    for _ in range(50):
+        ctx.match_mnn(d1h, d2h)
+    host_match_dt = (time.perf_counter() - t0) / 50
+    gemm_b2b = C.c_double(0.0)
+    capi.check(lib.xfh_bench_mnn_gemm(ctx.h, img1.ptr, nf, img2.ptr, nf, 300, C.byref(gemm_b2b)), ctx.h)
     gemm_us = ms_gemm / max(n_gemm, 1) * 1e3
     gemm_tf = 2.0 * nf * nf * 64 / (gemm_us * 1e-6) / 1e12 if n_gemm else 0.0
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")     # written by tools/collect_profiles.sh from --pmc passes
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath))
-        except Exception:
-            traffic = None
+    out["match"] = {"pairs_per_s": nf * nf / match_dt, "us_per_call": match_dt * 1e6, "n1": nf, "n2": nf, "n_matches": n_matches,
+                    "call": "xfh_match_mnn_device on raw descriptor rows: k_rownorm_img + k_mnn_gemm_img + k_mnn_post, back to back from a ctypes loop",
+                    "prepared": {"pairs_per_s": nf * nf / prep_dt, "us_per_call": prep_dt * 1e6,
+                                 "call": "xfh_match_mnn_prepared_device on two panel images (xfh_match_prepare_device once per frame): k_mnn_gemm_img + k_mnn_post",
+                                 "pairs_equal_raw": bool(np.array_equal(hm[0], hp[0]) and np.array_equal(hm[1], hp[1]))},
+                    "host_api_us_per_call": host_match_dt * 1e6,
+                    "roofline": {"kernel": "k_mnn_gemm_img", "bound": "mfma", "achieved": gemm_tf, "peak": PEAK_F32_MFMA_TFLOPS,
+                                 "unit": "TFLOP/s", "frac": gemm_tf / PEAK_F32_MFMA_TFLOPS,
+                                 "traffic": (traffic or {}).get("gemm_bytes_per_launch"), "avg_launch_us": gemm_us,
+                                 "launches": n_gemm, "flops_per_launch": 2.0 * nf * nf * 64,
+                                 "measured": "HIP events attached to every dispatch of the kernel inside the raw-call loop (the view rocprofv3 --kernel-trace gives; in a busy "
+                                             "stream these timestamps overlap the neighbouring kernels: their sum exceeds the wall time, DESIGN.md 5)",
+                                 "steady_state": {"wall_us_per_launch": gemm_b2b.value, "frac": 2.0 * nf * nf * 64 / (gemm_b2b.value * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                                                  "measured": "xfh_bench_mnn_gemm: 300 launches of the kernel alone back to back, wall time between two stream events / 300"}}}
 
-    # ---- CPU baseline + parity verdict (rank 0, N == 1 only) -------------------------------------------
-    cpu = None
-    parity = None
+    # ---- the other matcher kernels (no timing anywhere in round 1) ----------------------------------------------------
+    aux = {}
+    rng = np.random.RandomState(1)
+    for name, kid, fn in (
+        ("k_dist_i32 4096x4096 (64 MB table)", "DIST_I32", lambda: ctx.distance_i32(d1h, d2h)),
+        ("k_best2_csr 4096 queries x 64 candidates", "BEST2", None),
+        ("k_distinctive_csr 4096 groups x 16 rows", "DISTINCTIVE", None)):
+        if kid == "BEST2":
+            off = (np.arange(nf + 1) * 64).astype(np.int32); ind = rng.randint(0, nf, nf * 64).astype(np.int32)
+            fn = lambda: ctx.best2_csr(d1h, d2h, off, ind)
+        if kid == "DISTINCTIVE":
+            off2 = (np.arange(nf + 1) * 16).astype(np.int32); ind2 = rng.randint(0, nf, nf * 16).astype(np.int32)
+            fn = lambda: ctx.distinctive_csr(d1h, off2, ind2)
+        fn()
+        ctx.timing_enable(capi.K[kid])
+        for _ in range(5):
+            fn()
+        nl, ms = ctx.timing_read()
+        ctx.timing_enable(0)
+        aux[name] = {"kernel_us": ms / max(nl, 1) * 1e3, "launches": nl}
+    aux["k_dist_i32 4096x4096 (64 MB table)"]["hbm_write_GBps"] = nf * nf * 4 / (aux["k_dist_i32 4096x4096 (64 MB table)"]["kernel_us"] * 1e-6) / 1e9
+    out["aux_kernels"] = aux
+
+    # ---- CPU baseline + parity verdict (N == 1 only) ------------------------------------------------------------------
+    out["cpu_baseline"] = None
+    out["parity"] = None
     if N == 1 and args.cpu_frames > 0:
         from oracle import oracle as O
         orc = O.Oracle(blob)
-        nthr = min(O.get_threads(), os.cpu_count() or 1)
-        O.set_threads(nthr)
-        raw = d_rec[:rec_bytes * B].cpu().numpy() if use_dist else d_recb.download(np.uint8, rec_bytes * B)
-        recs = ctx.parse_records(raw, B)
-        orc.extract(frames[0], nf, (0, 0))                          # warm-up + parity reference
-        t0 = time.perf_counter()
-        for i in range(args.cpu_frames):
-            ok, od, onv, omono = orc.extract(frames[i % B], nf, (0, 0))
-        cpu_dt = (time.perf_counter() - t0) / args.cpu_frames
+        ncores = usable_cores()
+        cpu_legs = {}
+        # 1 thread, and the best of {all usable hardware threads, 32, 16}: the oracle's OpenMP loops stop scaling (and on an
+        # over-subscribed box collapse) well before a few hundred threads; every leg is bounded to a few seconds
+        for nthr in sorted({1, ncores, min(ncores, 32), min(ncores, 16)}):
+            O.set_threads(nthr)
+            t0 = time.perf_counter()
+            orc.extract(frames[0], nf, (0, 0))                          # warm-up, also sizes the leg
+            warm = time.perf_counter() - t0
+            nfr = max(1, min(args.cpu_frames if nthr > 1 else 2, int(6.0 / max(warm, 1e-3))))
+            t0 = time.perf_counter()
+            for i in range(nfr):
+                orc.extract(frames[i % B], nf, (0, 0))
+            fdt = (time.perf_counter() - t0) / nfr
+            t0 = time.perf_counter()
+            om = O.match_mnn(d1h, d2h)
+            mdt = time.perf_counter() - t0
+            cpu_legs[nthr] = (fdt, mdt, nfr)
+        best = min((k for k in cpu_legs if k > 1), key=lambda k: cpu_legs[k][0], default=1)
+        O.set_threads(best)
         ok, od, onv, omono = orc.extract(frames[0], nf, (0, 0))
+        cand = orc.tensor(O.T["CAND"]).reshape(-1, 3)
+        k1h = orc.tensor(O.T["K1H"])
         hk, hd, hnv, hmono, hnc = recs[0]
         vo, vh = ok["size"] > 0, hk["size"] > 0
         so = set(zip(ok["x"][vo].astype(int).tolist(), ok["y"][vo].astype(int).tolist()))
@@ -245,52 +421,31 @@ def main():
         ph = {(int(k["x"]), int(k["y"])): i for i, k in enumerate(hk) if k["size"] > 0}
         common = [k for k in po if k in ph]
         ddesc = max((float(np.abs(od[po[k]] - hd[ph[k]]).max()) for k in common), default=0.0)
-        d1h, d2h = recs[0][1], recs[min(1, B - 1)][1]
-        t0 = time.perf_counter()
-        om = O.match_mnn(d1h, d2h)
-        cpu_match_dt = time.perf_counter() - t0
-        hm = (mout.download(np.int32, n_matches), mout.download(np.int32, n_matches, 4 * nf))
-        parity = {"keypoint_sets_equal": so == sh, "n_valid": [int(onv), int(hnv)], "max_abs_desc_diff": ddesc,
-                  "match_pairs_equal": bool(np.array_equal(om[0], hm[0]) and np.array_equal(om[1], hm[1])),
-                  "n_candidates": int(hnc)}
-        cpu = {"value": 1.0 / cpu_dt, "unit": "frames/s", "cores": nthr, "kind": "port",
-               "sample": f"{args.cpu_frames} of the same {H}x{W} frames through oracle/xfeat_oracle.c (OpenMP, {nthr} threads); "
-                         f"4096x4096 MNN once: {nf * nf / cpu_match_dt:.3e} pairs/s",
-               "match_pairs_per_s": nf * nf / cpu_match_dt}
-
-    # PMC HBM bytes of the dominant kernel, scaled from the batch of the counter pass to this run's batch
-    conv_traffic = None
-    if traffic and traffic.get("conv_bytes_per_launch"):
-        conv_traffic = traffic["conv_bytes_per_launch"] * (B / traffic["conv_batch"] if traffic.get("conv_batch") else 1.0)
-    out = {
-        "metric": "XFeat frames/s (VGA, 4096 kpts) + 4096x4096 desc-match pairs/s",
-        "value": frames_per_s, "unit": "frames/s", "n_gpus": N, "steps": K, "warmup": args.warmup,
-        "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"configs[1]: {H}x{W} u8 frames, XFeat extract, nfeatures {nf}, {B * S} frames per GPU per step ({S} sub-batch(es) of {B} on separate HIP streams) "
-                               f"(per-frame BatchNorm statistics), inputs and 4096-row records resident in HBM"
-                               + (", RCCL all-gather of records" if use_dist else ""),
-                   "frames_per_gpu_per_step": B * S, "sub_batches_in_flight": S, "height": H, "width": W, "nfeatures": nf,
-                   "weights": f"synthetic seed 1234, keypoint-logit gain {KP_GAIN}", "parallelism": f"frames x{N}"},
-        "roofline": {"kernel": "k_conv_mfma<64,64,3,1,4,2,1,16,1,0,32,1> (block3.1, block_fusion.1: 3x3 64->64 at 1/8 res)", "measured": "HIP events attached to every dispatch of the kernel inside the timed region" if in_region else "single-stream pass of the same steps",
-                     "bound": "mfma", "achieved": conv_tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                     "frac": conv_tf / PEAK_F32_MFMA_TFLOPS, "traffic": conv_traffic,
-                     "avg_launch_us": conv_us, "launches": n_conv, "flops_per_launch": conv_flops(H, W) * B},
-        "single_frame": {"ms_per_frame": single_dt * 1e3, "frames_per_s": 1.0 / single_dt,
-                         "note": "one 480x640 frame per xfh_extract_batch_device call, back to back on one stream (latency path of configs[1])"},
-        "match": {"pairs_per_s": nf * nf / match_dt, "us_per_call": match_dt * 1e6, "n1": nf, "n2": nf, "n_matches": n_matches,
-                  "roofline": {"kernel": "k_mnn_gemm", "bound": "mfma", "achieved": gemm_tf, "peak": PEAK_F32_MFMA_TFLOPS,
-                               "unit": "TFLOP/s", "frac": gemm_tf / PEAK_F32_MFMA_TFLOPS,
-                               "traffic": (traffic or {}).get("gemm_bytes_per_launch"), "avg_launch_us": gemm_us,
-                               "launches": n_gemm, "flops_per_launch": 2.0 * nf * nf * 64}},
-        "cpu_baseline": cpu, "parity": parity,
-    }
-    sys.stdout.flush()
-    if saved_stdout is not None:
-        os.dup2(saved_stdout, 1)
-    print(json.dumps(out), flush=True)
-    if use_dist:
-        dist.barrier(); dist.destroy_process_group()
+        # near-tie audit: how many discrete decisions of this frame / match have a margin below 1e-6
+        sc = np.sort(cand[:, 2].astype(np.float64))[::-1]
+        top = sc[:min(len(sc), nf + 1)]
+        cos = d1h.astype(np.float32) @ d2h.astype(np.float32).T        # audit only: not the kernel's summation order
+        part = np.partition(cos, -2, axis=1)
+        audit = {"margin": 1e-6,
+                 "nms_threshold_pixels": int(np.count_nonzero(np.abs(k1h.astype(np.float64) - 0.05) < 1e-6)),
+                 "score_positive_cut": int(np.count_nonzero(np.abs(sc) < 1e-6)),
+                 "topk_cut_gap": float(top[nf - 1] - top[nf]) if len(top) > nf else None,
+                 "topk_adjacent_score_pairs": int(np.count_nonzero(np.abs(np.diff(top)) < 1e-6)),
+                 "mnn_rows_with_runner_up_gap": int(np.count_nonzero(part[:, -1] - part[:, -2] < 1e-6))}
+        out["parity"] = {"keypoint_sets_equal": so == sh, "n_valid": [int(onv), int(hnv)], "max_abs_desc_diff": ddesc,
+                         "match_pairs_equal": bool(np.array_equal(om[0], hm[0]) and np.array_equal(om[1], hm[1])),
+                         "match_pairs_equal_prepared": bool(np.array_equal(om[0], hp[0]) and np.array_equal(om[1], hp[1])),
+                         "n_candidates": int(hnc), "near_tie_audit": audit}
+        fdt, mdt, nfr = cpu_legs[best]
+        f1, m1, n1r = cpu_legs[1]
+        out["cpu_baseline"] = {"value": 1.0 / fdt, "unit": "frames/s", "cores": best, "kind": "port", "cpu_model": cpu_model(),
+                               "host_hardware_threads": os.cpu_count(), "usable_hardware_threads": ncores,
+                               "sample": f"{nfr} of the same {H}x{W} frames through oracle/xfeat_oracle.c (OpenMP, {best} threads = the fastest of the thread counts tried); "
+                                         f"4096x4096 MNN once: {nf * nf / mdt:.3e} pairs/s",
+                               "match_pairs_per_s": nf * nf / mdt,
+                               "one_thread": {"value": 1.0 / f1, "unit": "frames/s", "cores": 1, "match_pairs_per_s": nf * nf / m1,
+                                              "sample": f"{n1r} frames, 4096x4096 MNN once, 1 thread"},
+                               "legs": {str(k): {"frames_per_s": 1.0 / v[0], "match_pairs_per_s": nf * nf / v[1], "frames": v[2]} for k, v in sorted(cpu_legs.items())}}
 
 
 if __name__ == "__main__":

@@ -250,6 +250,9 @@ enum {
  * (0..22 in XFeatModel order) and bit 23 = block_fusion.2 */
 int xfh_timing_enable(xfh_ctx* ctx, int kernel_id, unsigned layer_mask);
 int xfh_timing_read(xfh_ctx* ctx, int* launches, double* total_ms);
+/* `iters` launches of the match GEMM alone, back to back, on two prepared images: wall time per launch between two stream
+ * events.  (Dispatch-attached timestamps of consecutive kernels in a busy stream overlap; this is the steady-state cost.) */
+int xfh_bench_mnn_gemm(xfh_ctx* ctx, const void* d_image1, int n1, const void* d_image2, int n2, int iters, double* us_per_launch);
 const char* xfh_kernel_name(int kernel_id);
 
 /* intermediate tensors of frame `frame` of the last extract call, copied to host as float

@@ -11,7 +11,7 @@
 #include <algorithm>
 
 const char* probe_gemm_name(int v);
-void probe_gemm(int v, hipStream_t s, hipEvent_t e0, hipEvent_t e1, const float* i1, int n1, const float* i2, int n2, u64* bR, u64* bC, u64* pairs);
+void probe_gemm(int v, hipStream_t s, hipEvent_t e0, hipEvent_t e1, const float* i1, int n1, const float* i2, int n2, u64* pR, size_t ldr, u64* pC, size_t ldc, u64* pairs);
 
 // reference: plain normalised rows, then per row of A the first index of the maximum dot product over B
 __global__ void k_ref_norm(const float* d, int n, float* o) {
@@ -23,6 +23,8 @@ __global__ void k_ref_norm(const float* d, int n, float* o) {
     const float nrm = fmaxf((float)sqrt(ss), 1e-12f);
     *(f32x4*)(o + (size_t)row * 64 + sub * 4) = f32x4{v.x / nrm, v.y / nrm, v.z / nrm, v.w / nrm};
 }
+__global__ void k_empty(int* p) { if (p && threadIdx.x == 12345) *p = 1; }
+__global__ void k_touch_lds(int* p) { __shared__ int big[30000]; big[threadIdx.x] = threadIdx.x; __syncthreads(); if (p && big[(threadIdx.x + 1) & 255] == -5) *p = 1; }
 __global__ void k_ref_best(const float* a, int na, const float* b, int nb, float* bv, int* bi) {
     const int row = blockIdx.x * 256 + threadIdx.x;
     if (row >= na) return;
@@ -78,7 +80,8 @@ int main(int argc, char** argv) {
         CK(hipMalloc(&img1, (size_t)P1 * MNN_PANEL_FLOATS * 4)); CK(hipMalloc(&img2, (size_t)P2 * MNN_PANEL_FLOATS * 4));
         CK(hipMalloc(&p1, h1.size() * 4)); CK(hipMalloc(&p2, h2.size() * 4));
         CK(hipMalloc(&rv1, n1 * 4)); CK(hipMalloc(&rv2, n2 * 4)); CK(hipMalloc(&ri1, n1 * 4)); CK(hipMalloc(&ri2, n2 * 4));
-        CK(hipMalloc(&bR, n1 * 8)); CK(hipMalloc(&bC, n2 * 8)); CK(hipMalloc(&pairs, n1 * 8));
+        const size_t ldr = (size_t)P1 * MNN_PANEL, ldc = (size_t)P2 * MNN_PANEL;
+        CK(hipMalloc(&bR, P2 * ldr * 8)); CK(hipMalloc(&bC, P1 * ldc * 8)); CK(hipMalloc(&pairs, n1 * 8));
         const int nmax = std::min(n1, n2);
         CK(hipMalloc(&idx1, nmax * 4)); CK(hipMalloc(&idx2, nmax * 4)); CK(hipMalloc(&dist, nmax * 4)); CK(hipMalloc(&nm, 4));
         { std::vector<u64> e(n1, MNN_PAIR_EMPTY); CK(hipMemcpy(pairs, e.data(), n1 * 8, hipMemcpyHostToDevice)); }
@@ -97,22 +100,23 @@ int main(int argc, char** argv) {
 
         auto rownorm = [&](hipEvent_t a, hipEvent_t b) {
             const dim3 g((P1 + P2) * 16);
-            if (a) hipExtLaunchKernelGGL(k_rownorm_img, g, dim3(256), 0, s, a, b, 0, (const float*)d1, n1, (const float*)d2, n2, P1, img1, img2, bR, bC);
-            else hipLaunchKernelGGL(k_rownorm_img, g, dim3(256), 0, s, (const float*)d1, n1, (const float*)d2, n2, P1, img1, img2, bR, bC);
+            if (a) hipExtLaunchKernelGGL(k_rownorm_img, g, dim3(256), 0, s, a, b, 0, (const float*)d1, n1, (const float*)d2, n2, P1, img1, img2);
+            else hipLaunchKernelGGL(k_rownorm_img, g, dim3(256), 0, s, (const float*)d1, n1, (const float*)d2, n2, P1, img1, img2);
         };
         auto post = [&](hipEvent_t a, hipEvent_t b) {
             const int nb = (n1 + 15) / 16, ncoll = mnn_ncoll(n1); const dim3 g(nb + ncoll);
-            if (a) hipExtLaunchKernelGGL(k_mnn_post<0>, g, dim3(256), MNN_POST_LDS, s, a, b, 0, (const float*)img1, n1, (const float*)img2, n2, (const u64*)bR, (const u64*)bC, -1.0f, pairs, nb, ncoll, 0, bR, bC, idx1, idx2, dist, nm, (long long*)nullptr);
-            else hipLaunchKernelGGL(k_mnn_post<0>, g, dim3(256), MNN_POST_LDS, s, (const float*)img1, n1, (const float*)img2, n2, (const u64*)bR, (const u64*)bC, -1.0f, pairs, nb, ncoll, 0, bR, bC, idx1, idx2, dist, nm, (long long*)nullptr);
+            if (a) hipExtLaunchKernelGGL(k_mnn_post<0>, g, dim3(256), MNN_POST_LDS, s, a, b, 0, (const float*)img1, n1, (const float*)img2, n2, (const u64*)bR, ldr, P2, (const u64*)bC, ldc, P1, -1.0f, pairs, nb, ncoll, idx1, idx2, dist, nm, (long long*)nullptr);
+            else hipLaunchKernelGGL(k_mnn_post<0>, g, dim3(256), MNN_POST_LDS, s, (const float*)img1, n1, (const float*)img2, n2, (const u64*)bR, ldr, P2, (const u64*)bC, ldc, P1, -1.0f, pairs, nb, ncoll, idx1, idx2, dist, nm, (long long*)nullptr);
         };
         for (int v = 0; v < NV; ++v) {
             rownorm(nullptr, nullptr);
-            probe_gemm(v, s, nullptr, nullptr, img1, n1, img2, n2, bR, bC, pairs);
+            probe_gemm(v, s, nullptr, nullptr, img1, n1, img2, n2, bR, ldr, bC, ldc, pairs);
             post(nullptr, nullptr);
             CK(hipStreamSynchronize(s));
             // level-1 keys
-            std::vector<u64> kR(n1), kC(n2);
-            CK(hipMemcpy(kR.data(), bR, n1 * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(kC.data(), bC, n2 * 8, hipMemcpyDeviceToHost));
+            std::vector<u64> kR(n1, 0), kC(n2, 0), pl(std::max(ldr, ldc));
+            for (int q = 0; q < P2; ++q) { CK(hipMemcpy(pl.data(), bR + q * ldr, n1 * 8, hipMemcpyDeviceToHost)); for (int i = 0; i < n1; ++i) kR[i] = std::max(kR[i], pl[i]); }
+            for (int q = 0; q < P1; ++q) { CK(hipMemcpy(pl.data(), bC + q * ldc, n2 * 8, hipMemcpyDeviceToHost)); for (int j = 0; j < n2; ++j) kC[j] = std::max(kC[j], pl[j]); }
             int badR = 0, badC = 0;
             for (int i = 0; i < n1; ++i) {
                 const float M = ord2f((unsigned)(kR[i] >> 32)); const int g = (int)(0xFFFFFFFFu - (unsigned)(kR[i] & 0xFFFFFFFFull));
@@ -155,8 +159,8 @@ int main(int argc, char** argv) {
                 long long* st; CK(hipMalloc(&st, 64 * 8));
                 for (int rep = 0; rep < 3; ++rep) {
                     CK(hipMemset(st, 0, 64 * 8));
-                    rownorm(nullptr, nullptr); probe_gemm(1, s, nullptr, nullptr, img1, n1, img2, n2, bR, bC, pairs);
-                    hipLaunchKernelGGL(k_mnn_post<1>, dim3((n1 + 15) / 16 + mnn_ncoll(n1)), dim3(256), MNN_POST_LDS, s, (const float*)img1, n1, (const float*)img2, n2, (const u64*)bR, (const u64*)bC, -1.0f, pairs, (n1 + 15) / 16, mnn_ncoll(n1), 0, bR, bC, idx1, idx2, dist, nm, st);
+                    rownorm(nullptr, nullptr); probe_gemm(1, s, nullptr, nullptr, img1, n1, img2, n2, bR, ldr, bC, ldc, pairs);
+                    hipLaunchKernelGGL(k_mnn_post<1>, dim3((n1 + 15) / 16 + mnn_ncoll(n1)), dim3(256), MNN_POST_LDS, s, (const float*)img1, n1, (const float*)img2, n2, (const u64*)bR, ldr, P2, (const u64*)bC, ldc, P1, -1.0f, pairs, (n1 + 15) / 16, mnn_ncoll(n1), idx1, idx2, dist, nm, st);
                     CK(hipStreamSynchronize(s));
                     long long h[64]; CK(hipMemcpy(h, st, 64 * 8, hipMemcpyDeviceToHost));
                     printf("  post stamps (us after block 0 start): block0 loads %.2f chain %.2f second %.2f stored %.2f | collector start %.2f", (h[1] - h[0]) / 100.0, (h[2] - h[0]) / 100.0, (h[3] - h[0]) / 100.0, (h[4] - h[0]) / 100.0, (h[16] - h[0]) / 100.0);
@@ -164,20 +168,57 @@ int main(int argc, char** argv) {
                 }
                 hipFree(st);
             }
+            {   // continuous streams (no host sync inside): duration of gemm(3) by dispatch events, with different neighbours
+                const int NREP = 200;
+                std::vector<hipEvent_t> ev(2 * NREP);
+                for (auto& e : ev) CK(hipEventCreate(&e));
+                auto seq = [&](const char* name, auto&& before, auto&& after) {
+                    for (int i = 0; i < 100; ++i) { before(); probe_gemm(3, s, nullptr, nullptr, img1, n1, img2, n2, bR, ldr, bC, ldc, pairs); after(); }
+                    for (int i = 0; i < NREP; ++i) { before(); probe_gemm(3, s, ev[2 * i], ev[2 * i + 1], img1, n1, img2, n2, bR, ldr, bC, ldc, pairs); after(); }
+                    CK(hipStreamSynchronize(s));
+                    double tot = 0;
+                    for (int i = 0; i < NREP; ++i) { float ms; CK(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1])); tot += ms; }
+                    printf("  continuous: gemm(3) with neighbours %-36s %.2f us\n", name, tot / NREP * 1e3);
+                };
+                auto none = [&]() {};
+                rownorm(nullptr, nullptr);
+                seq("none", none, none);
+                seq("k_empty (1 WG) before", [&]() { hipLaunchKernelGGL(k_empty, dim3(1), dim3(64), 0, s, (int*)nullptr); }, none);
+                seq("k_empty (256 WG) before", [&]() { hipLaunchKernelGGL(k_empty, dim3(256), dim3(256), 0, s, (int*)nullptr); }, none);
+                seq("k_touch_lds (256 WG) before", [&]() { hipLaunchKernelGGL(k_touch_lds, dim3(256), dim3(256), 0, s, (int*)nullptr); }, none);
+                seq("gemm(4) before", [&]() { probe_gemm(4, s, nullptr, nullptr, img1, n1, img2, n2, bR, ldr, bC, ldc, pairs); }, none);
+                seq("rownorm before", [&]() { rownorm(nullptr, nullptr); }, none);
+                seq("post before", [&]() { post(nullptr, nullptr); }, none);
+                seq("rownorm before, post after", [&]() { rownorm(nullptr, nullptr); }, [&]() { post(nullptr, nullptr); });
+                for (auto& e : ev) hipEventDestroy(e);
+            }
             time_kernel("k_rownorm_img", rownorm);
             time_kernel("k_mnn_post", post);
             for (int v = 0; v < NVT; ++v) {
                 rownorm(nullptr, nullptr);
                 char nmb[64]; snprintf(nmb, sizeof nmb, "gemm %s", probe_gemm_name(v));
-                const double us = time_kernel(nmb, [&](hipEvent_t a, hipEvent_t b) { probe_gemm(v, s, a, b, img1, n1, img2, n2, bR, bC, pairs); });
+                const double us = time_kernel(nmb, [&](hipEvent_t a, hipEvent_t b) { probe_gemm(v, s, a, b, img1, n1, img2, n2, bR, ldr, bC, ldc, pairs); });
                 printf("      -> %.1f TFLOP/s = %.1f %% of 157.3\n", 2.0 * n1 * n2 * 64 / (us * 1e-6) / 1e12, 2.0 * n1 * n2 * 64 / (us * 1e-6) / 157.3e12 * 100);
                 // whole call, back to back on the stream
-                for (int i = 0; i < 10; ++i) { rownorm(nullptr, nullptr); probe_gemm(v, s, nullptr, nullptr, img1, n1, img2, n2, bR, bC, pairs); post(nullptr, nullptr); }
+                for (int i = 0; i < 10; ++i) { rownorm(nullptr, nullptr); probe_gemm(v, s, nullptr, nullptr, img1, n1, img2, n2, bR, ldr, bC, ldc, pairs); post(nullptr, nullptr); }
                 CK(hipEventRecord(e0, s));
-                for (int i = 0; i < iters; ++i) { rownorm(nullptr, nullptr); probe_gemm(v, s, nullptr, nullptr, img1, n1, img2, n2, bR, bC, pairs); post(nullptr, nullptr); }
+                for (int i = 0; i < iters; ++i) { rownorm(nullptr, nullptr); probe_gemm(v, s, nullptr, nullptr, img1, n1, img2, n2, bR, ldr, bC, ldc, pairs); post(nullptr, nullptr); }
                 CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
                 float msg; CK(hipEventElapsedTime(&msg, e0, e1));
                 printf("      whole call (3 kernels, back to back): %.2f us\n", msg / iters * 1e3);
+                {   // the GEMM's own duration INSIDE the sequence (what bench.py's dispatch-attached timer sees)
+                    double tot = 0;
+                    for (int i = 0; i < 50; ++i) {
+                        rownorm(nullptr, nullptr); probe_gemm(v, s, e0, e1, img1, n1, img2, n2, bR, ldr, bC, ldc, pairs); post(nullptr, nullptr);
+                        CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms, e0, e1)); tot += ms;
+                    }
+                    double totp = 0;
+                    for (int i = 0; i < 50; ++i) {      // prepared style: images stay, only gemm + post
+                        probe_gemm(v, s, e0, e1, img1, n1, img2, n2, bR, ldr, bC, ldc, pairs); post(nullptr, nullptr);
+                        CK(hipEventSynchronize(e1)); float ms; CK(hipEventElapsedTime(&ms, e0, e1)); totp += ms;
+                    }
+                    printf("      gemm in sequence: after k_rownorm_img %.2f us | images resident (prepared) %.2f us\n", tot / 50 * 1e3, totp / 50 * 1e3);
+                }
             }
         }
         hipFree(d1); hipFree(d2); hipFree(img1); hipFree(img2); hipFree(p1); hipFree(p2); hipFree(rv1); hipFree(rv2); hipFree(ri1); hipFree(ri2);

@@ -93,6 +93,7 @@ SYMBOLS = [
     ("xfh_memcpy_d2h", _i, [_vp, _vp, _sz]),
     ("xfh_timing_enable", _i, [_vp, _i, C.c_uint]),
     ("xfh_timing_read", _i, [_vp, _pi, C.POINTER(C.c_double)]),
+    ("xfh_bench_mnn_gemm", _i, [_vp, _vp, _i, _vp, _i, _i, C.POINTER(C.c_double)]),
     ("xfh_kernel_name", C.c_char_p, [_i]),
     ("xfh_debug_tensor", _i, [_vp, _i, _i, _vp, _sz, C.POINTER(_sz)]),
 ]

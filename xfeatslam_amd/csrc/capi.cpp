@@ -140,8 +140,12 @@ int xfh_create(const xfh_config* cfg, xfh_ctx** out) {
         if (hipHostMalloc((void**)&c->s_hgray[k], (size_t)cfg->max_height * cfg->max_width, hipHostMallocDefault) != hipSuccess) return fail(XFH_ERR_OUT_OF_MEMORY);
         if (hipHostMalloc((void**)&c->s_hrec[k], rec, hipHostMallocDefault) != hipSuccess) return fail(XFH_ERR_OUT_OF_MEMORY);
     }
+    c->s_drec[0] = c->d_records;
+    for (int k = 1; k < xfh_ctx::SLOTS; ++k) A(c->s_drec[k], rec);
     for (int k = 0; k < xfh_ctx::SLOTS; ++k)
-        if (hipEventCreateWithFlags(&c->s_done[k], hipEventDisableTiming) != hipSuccess) return fail(XFH_ERR_HIP);
+        if (hipEventCreateWithFlags(&c->s_done[k], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->s_h2d[k], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->s_comp[k], hipEventDisableTiming) != hipSuccess) return fail(XFH_ERR_HIP);
+    if (hipStreamCreateWithFlags(&c->h2d_stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&c->d2h_stream, hipStreamNonBlocking) != hipSuccess) return fail(XFH_ERR_HIP);
 #undef A
     (void)rc;
     // matcher workspace for frame-against-frame calls and the pinned output mirror of xfh_match_mnn: no allocation on the call path
@@ -176,8 +180,10 @@ int xfh_destroy(xfh_ctx* c) {
     F(c->cand); F(c->cand_count); F(c->slot_src); F(c->sel_key); F(c->sel_n); F(c->d_records);
     if (c->h_records) hipHostFree(c->h_records);
     if (c->h_gray) hipHostFree(c->h_gray);
-    for (int k = 1; k < xfh_ctx::SLOTS; ++k) { F(c->s_dgray[k]); if (c->s_hgray[k]) hipHostFree(c->s_hgray[k]); if (c->s_hrec[k]) hipHostFree(c->s_hrec[k]); }
-    for (int k = 0; k < xfh_ctx::SLOTS; ++k) if (c->s_done[k]) hipEventDestroy(c->s_done[k]);
+    if (c->h2d_stream) { hipStreamSynchronize(c->h2d_stream); hipStreamDestroy(c->h2d_stream); }
+    if (c->d2h_stream) { hipStreamSynchronize(c->d2h_stream); hipStreamDestroy(c->d2h_stream); }
+    for (int k = 1; k < xfh_ctx::SLOTS; ++k) { F(c->s_dgray[k]); F(c->s_drec[k]); if (c->s_hgray[k]) hipHostFree(c->s_hgray[k]); if (c->s_hrec[k]) hipHostFree(c->s_hrec[k]); }
+    for (int k = 0; k < xfh_ctx::SLOTS; ++k) { if (c->s_done[k]) hipEventDestroy(c->s_done[k]); if (c->s_h2d[k]) hipEventDestroy(c->s_h2d[k]); if (c->s_comp[k]) hipEventDestroy(c->s_comp[k]); }
     MatchWs& w = c->mws;
     F(w.img1); F(w.keys); F(w.b2_buf); F(w.h_d1); F(w.o_buf); F(w.o_tab);
     if (w.h_out) hipHostFree(w.h_out);
@@ -369,9 +375,22 @@ int xfh_extract_submit(xfh_ctx* c, const uint8_t* gray, int H, int W, int stride
     uint8_t* hg = c->s_hgray[k];
     if (stride == W) memcpy(hg, gray, (size_t)H * W);
     else for (int y = 0; y < H; ++y) memcpy(hg + (size_t)y * W, gray + (size_t)y * stride, (size_t)W);
-    HIPCK(c, hipMemcpyAsync(c->s_dgray[k], hg, (size_t)H * W, hipMemcpyHostToDevice, c->stream));
-    HIPCK(c, run_extract(c, c->s_dgray[k], 1, H, W, lap0, lap1, c->s_hrec[k], false));
-    HIPCK(c, hipEventRecord(c->s_done[k], c->stream));
+    const bool zero_copy = c->s_count == 0;                 // nothing in flight: latency counts, see ctx.h
+    c->s_zero_copy[k] = zero_copy;
+    if (zero_copy) {
+        HIPCK(c, hipMemcpyAsync(c->s_dgray[k], hg, (size_t)H * W, hipMemcpyHostToDevice, c->stream));
+        HIPCK(c, run_extract(c, c->s_dgray[k], 1, H, W, lap0, lap1, c->s_hrec[k], false));
+        HIPCK(c, hipEventRecord(c->s_done[k], c->stream));
+    } else {
+        HIPCK(c, hipMemcpyAsync(c->s_dgray[k], hg, (size_t)H * W, hipMemcpyHostToDevice, c->h2d_stream));
+        HIPCK(c, hipEventRecord(c->s_h2d[k], c->h2d_stream));
+        HIPCK(c, hipStreamWaitEvent(c->stream, c->s_h2d[k], 0));
+        HIPCK(c, run_extract(c, c->s_dgray[k], 1, H, W, lap0, lap1, c->s_drec[k], false));
+        HIPCK(c, hipEventRecord(c->s_comp[k], c->stream));
+        HIPCK(c, hipStreamWaitEvent(c->d2h_stream, c->s_comp[k], 0));
+        HIPCK(c, hipMemcpyAsync(c->s_hrec[k], c->s_drec[k], xfh_record_bytes(c->cfg.nfeatures), hipMemcpyDeviceToHost, c->d2h_stream));
+        HIPCK(c, hipEventRecord(c->s_done[k], c->d2h_stream));
+    }
     ++c->s_count;
     return XFH_OK;
 }
@@ -638,6 +657,12 @@ int xfh_memcpy_h2d(void* d, const void* s, size_t n) { return hipMemcpy(d, s, n,
 int xfh_memcpy_d2h(void* d, const void* s, size_t n) { return hipMemcpy(d, s, n, hipMemcpyDeviceToHost) == hipSuccess ? XFH_OK : XFH_ERR_HIP; }
 
 // ------------------------------------------------------------------------- timing
+int xfh_bench_mnn_gemm(xfh_ctx* c, const void* image1, int n1, const void* image2, int n2, int iters, double* us_per_launch) {
+    if (!c || !image1 || !image2 || n1 < 1 || n2 < 1 || iters < 1 || !us_per_launch) return XFH_ERR_INVALID_ARG;
+    HIPCK(c, hipSetDevice(c->cfg.device));
+    HIPCK(c, bench_mnn_gemm(c, (const float*)image1, n1, (const float*)image2, n2, iters, us_per_launch));
+    return XFH_OK;
+}
 int xfh_timing_enable(xfh_ctx* c, int kernel_id, unsigned layer_mask) {
     if (!c || kernel_id < 0 || kernel_id >= XFH_K_COUNT) return XFH_ERR_INVALID_ARG;
     KTimer& t = c->timer;

@@ -96,8 +96,7 @@ struct KTimer {
 // ---- matcher workspace ----------------------------------------------------------------
 struct MatchWs {
     float* img1 = nullptr; float* img2 = nullptr; size_t cap_p1 = 0, cap_p2 = 0;   // panel images of the two sets (capacity in panels of 256 rows)
-    u64* keys = nullptr; u64* bestR = nullptr; u64* pairs = nullptr; u64* bestC = nullptr;   // one allocation: arg-max keys per d1 / d2 row, (column, value) pairs
-    bool keys_clean = true;                                            // bestR / bestC are all zero (allocation or a prepared-image call)
+    u64* keys = nullptr; u64* partR = nullptr; u64* partC = nullptr; u64* pairs = nullptr;   // one allocation: arg-max key planes (one per GEMM block column / row), (column, value) pairs
     float* h_d1 = nullptr; float* h_d2 = nullptr; size_t cap_in = 0;   // device staging of host inputs
     int* o_buf = nullptr; size_t cap_out = 0;                          // device outputs of the host call: n, idx1[nm], idx2[nm], dist[nm]
     int* h_out = nullptr; size_t cap_hout = 0;                         // pinned mirror of o_buf
@@ -111,9 +110,10 @@ hipError_t match_ws_reserve(xfh_ctx* c, int n1, int n2);
 hipError_t launch_mnn(xfh_ctx* c, const float* d1, int n1, const float* d2, int n2, float min_cossim,
                       int* idx1, int* idx2, float* dist, int* n_matches);
 hipError_t launch_match_prepare(xfh_ctx* c, const float* d, int n, float* img);
+hipError_t bench_mnn_gemm(xfh_ctx* c, const float* img1, int n1, const float* img2, int n2, int iters, double* us_per_launch);
 hipError_t launch_mnn_prepared(xfh_ctx* c, const float* img1, int n1, const float* img2, int n2, float min_cossim,
                                int* idx1, int* idx2, float* dist, int* n_matches);
-hipError_t launch_mnn_gemm(xfh_ctx* c, const float* img1, int n1, const float* img2, int n2, u64* bestR, u64* bestC, u64* pairs);   // kernels_mnn_gemm.hip
+hipError_t launch_mnn_gemm(xfh_ctx* c, const float* img1, int n1, const float* img2, int n2, u64* partR, size_t ldr, u64* partC, size_t ldc, u64* pairs);   // kernels_mnn_gemm.hip
 hipError_t launch_dist_i32(xfh_ctx* c, const float* d1, int n1, const float* d2, int n2, int32_t* out);
 hipError_t launch_distinctive(xfh_ctx* c, const float* table, const int* offsets, const int* indices, int n_groups, int max_group,
                               int* best_pos, int* best_median);

@@ -59,11 +59,16 @@ struct xfh_ctx {
     uint8_t* h_gray = nullptr;                  // pinned, [B] frames
 
     // xfh_extract_submit / _collect: a ring of XFH_SLOTS single-frame submissions.  Slot buffers: pinned image, device
-    // image, and a pinned record that the kernels write DIRECTLY (host memory is device visible: no D2H command, the
-    // stores cross PCIe while k_desc runs).  Slot 0 shares the batch buffers above.
+    // image, device record and pinned record.  With nothing else in flight (the blocking xfh_extract) the
+    // kernels write the pinned record DIRECTLY (host memory is device visible: no D2H command, the stores cross PCIe while
+    // k_desc runs: lowest latency); with a frame already in flight the three stages run on three streams (H2D | kernels |
+    // D2H) so that copies of one frame overlap the kernels of the other.  Slot 0 shares the batch buffers above.
     static const int SLOTS = 2;
     uint8_t* s_hgray[SLOTS] = {}; uint8_t* s_dgray[SLOTS] = {}; uint8_t* s_hrec[SLOTS] = {};
-    hipEvent_t s_done[SLOTS] = {};
+    uint8_t* s_drec[SLOTS] = {};                // device record of the slot (pipelined form: copied out on the D2H stream)
+    bool s_zero_copy[SLOTS] = {};               // the kernels of this submission wrote the pinned record directly
+    hipEvent_t s_done[SLOTS] = {}, s_h2d[SLOTS] = {}, s_comp[SLOTS] = {};
+    hipStream_t h2d_stream = nullptr, d2h_stream = nullptr;
     int s_head = 0, s_count = 0;                // oldest outstanding slot, number outstanding
 
     MatchWs mws;

@@ -201,24 +201,54 @@ hipError_t match_ws_reserve(xfh_ctx* c, int n1, int n2) {
         if (w.keys) { hipFree(w.keys); w.keys = nullptr; }
         w.cap_p1 = w.cap_p2 = 0;
         if ((e = hipMalloc((void**)&w.img1, (c1 + c2) * MNN_PANEL_FLOATS * sizeof(float))) != hipSuccess) return e;
-        const size_t nkeys = (2 * c1 + c2) * MNN_PANEL;          // bestR[c1 panels], pairs[c1 panels], bestC[c2 panels]
+        // partR: c2 planes of c1 panels of rows, partC: c1 planes of c2 panels, pairs: c1 panels
+        const size_t nkeys = (2 * c1 * c2 + c1) * MNN_PANEL;
         if ((e = hipMalloc((void**)&w.keys, nkeys * sizeof(u64))) != hipSuccess) return e;
-        if ((e = hipMemsetAsync(w.keys, 0, nkeys * sizeof(u64), c->stream)) != hipSuccess) return e;
-        w.cap_p1 = c1; w.cap_p2 = c2; w.keys_clean = true;
+        w.cap_p1 = c1; w.cap_p2 = c2;
     }
     w.img2 = w.img1 + w.cap_p1 * MNN_PANEL_FLOATS;
-    w.bestR = w.keys; w.pairs = w.keys + w.cap_p1 * MNN_PANEL; w.bestC = w.pairs + w.cap_p1 * MNN_PANEL;
+    w.partR = w.keys; w.partC = w.partR + w.cap_p1 * w.cap_p2 * MNN_PANEL; w.pairs = w.partC + w.cap_p1 * w.cap_p2 * MNN_PANEL;
     return hipSuccess;
 }
 
-static hipError_t launch_post(xfh_ctx* c, const float* img1, int n1, const float* img2, int n2, float min_cossim, int zero_keys,
-                              int* idx1, int* idx2, float* dist, int* n_matches) {
+// GEMM + post on two panel images: the keys of block (by, bx) go to plane bx of partR / plane by of partC
+static hipError_t launch_gemm_post(xfh_ctx* c, const float* img1, int n1, const float* img2, int n2, float min_cossim,
+                                   int* idx1, int* idx2, float* dist, int* n_matches) {
     MatchWs& w = c->mws;
+    hipError_t e;
+    const int P1 = (n1 + MNN_PANEL - 1) / MNN_PANEL, P2 = (n2 + MNN_PANEL - 1) / MNN_PANEL;
+    const size_t ldr = (size_t)P1 * MNN_PANEL, ldc = (size_t)P2 * MNN_PANEL;
+    if ((e = launch_mnn_gemm(c, img1, n1, img2, n2, w.partR, ldr, w.partC, ldc, w.pairs)) != hipSuccess) return e;
     XFH_SET_LDS_ATTR_ONCE(c, k_mnn_post<0>, MNN_POST_LDS);
     const int nb = (n1 + 15) / 16, ncoll = mnn_ncoll(n1);
-    hipLaunchKernelGGL(k_mnn_post<0>, dim3(nb + ncoll), dim3(256), MNN_POST_LDS, c->stream, img1, n1, img2, n2, (const u64*)w.bestR, (const u64*)w.bestC,
-                       min_cossim, w.pairs, nb, ncoll, zero_keys, w.bestR, w.bestC, idx1, idx2, dist, n_matches, (long long*)nullptr);
+    hipLaunchKernelGGL(k_mnn_post<0>, dim3(nb + ncoll), dim3(256), MNN_POST_LDS, c->stream, img1, n1, img2, n2, (const u64*)w.partR, ldr, P2,
+                       (const u64*)w.partC, ldc, P1, min_cossim, w.pairs, nb, ncoll, idx1, idx2, dist, n_matches, (long long*)nullptr);
     return hipGetLastError();
+}
+
+// measurement hook (xfh_bench_mnn_gemm): `iters` launches of k_mnn_gemm_img alone, back to back, on two prepared images;
+// returns the wall time per launch between two stream events.  In a busy stream the dispatch-attached timestamps of
+// consecutive kernels overlap (their sum exceeds the wall time, tools/probes/mnn_probe), so this is the kernel's
+// steady-state cost; xfh_timing_* reports the dispatch-attached view that rocprofv3 shows.
+hipError_t bench_mnn_gemm(xfh_ctx* c, const float* img1, int n1, const float* img2, int n2, int iters, double* us_per_launch) {
+    hipError_t e;
+    if ((e = match_ws_reserve(c, n1, n2)) != hipSuccess) return e;
+    MatchWs& w = c->mws;
+    const int P1 = (n1 + MNN_PANEL - 1) / MNN_PANEL, P2 = (n2 + MNN_PANEL - 1) / MNN_PANEL;
+    const size_t ldr = (size_t)P1 * MNN_PANEL, ldc = (size_t)P2 * MNN_PANEL;
+    hipEvent_t e0, e1;
+    if ((e = hipEventCreate(&e0)) != hipSuccess) return e;
+    if ((e = hipEventCreate(&e1)) != hipSuccess) { hipEventDestroy(e0); return e; }
+    for (int i = 0; i < 20 && e == hipSuccess; ++i) e = launch_mnn_gemm(c, img1, n1, img2, n2, w.partR, ldr, w.partC, ldc, w.pairs);
+    if (e == hipSuccess) e = hipEventRecord(e0, c->stream);
+    for (int i = 0; i < iters && e == hipSuccess; ++i) e = launch_mnn_gemm(c, img1, n1, img2, n2, w.partR, ldr, w.partC, ldc, w.pairs);
+    if (e == hipSuccess) e = hipEventRecord(e1, c->stream);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    *us_per_launch = (double)ms * 1e3 / (iters > 0 ? iters : 1);
+    return e;
 }
 
 // ORBmatcher::match on raw descriptor rows: normalise + images, GEMM, post (three launches)
@@ -229,35 +259,25 @@ hipError_t launch_mnn(xfh_ctx* c, const float* d1, int n1, const float* d2, int 
     if ((e = match_ws_reserve(c, n1, n2)) != hipSuccess) return e;
     MatchWs& w = c->mws;
     const int P1 = (n1 + MNN_PANEL - 1) / MNN_PANEL, P2 = (n2 + MNN_PANEL - 1) / MNN_PANEL;
-    hipLaunchKernelGGL(k_rownorm_img, dim3((P1 + P2) * 16), dim3(256), 0, c->stream, d1, n1, d2, n2, P1, w.img1, w.img2, w.bestR, w.bestC);
-    w.keys_clean = false;
-    if ((e = launch_mnn_gemm(c, w.img1, n1, w.img2, n2, w.bestR, w.bestC, w.pairs)) != hipSuccess) return e;
-    return launch_post(c, w.img1, n1, w.img2, n2, min_cossim, 0, idx1, idx2, dist, n_matches);
+    hipLaunchKernelGGL(k_rownorm_img, dim3((P1 + P2) * 16), dim3(256), 0, c->stream, d1, n1, d2, n2, P1, w.img1, w.img2);
+    return launch_gemm_post(c, w.img1, n1, w.img2, n2, min_cossim, idx1, idx2, dist, n_matches);
 }
 
 // one descriptor set -> its panel image (xfh_match_prepare_device): the per-frame half of launch_mnn
 hipError_t launch_match_prepare(xfh_ctx* c, const float* d, int n, float* img) {
     if (n <= 0) return hipSuccess;
     const int P = (n + MNN_PANEL - 1) / MNN_PANEL;
-    hipLaunchKernelGGL(k_rownorm_img, dim3(P * 16), dim3(256), 0, c->stream, d, n, (const float*)nullptr, 0, P, img, (float*)nullptr, (u64*)nullptr, (u64*)nullptr);
+    hipLaunchKernelGGL(k_rownorm_img, dim3(P * 16), dim3(256), 0, c->stream, d, n, (const float*)nullptr, 0, P, img, (float*)nullptr);
     return hipGetLastError();
 }
 
-// ORBmatcher::match on two prepared images: GEMM + post (two launches).  The keys are zero on entry (allocation, or the
-// previous prepared call) and the last collector of k_mnn_post zeroes them again.
+// ORBmatcher::match on two prepared images: GEMM + post (two launches)
 hipError_t launch_mnn_prepared(xfh_ctx* c, const float* img1, int n1, const float* img2, int n2, float min_cossim,
                                int* idx1, int* idx2, float* dist, int* n_matches) {
     hipError_t e;
     if (n1 <= 0 || n2 <= 0) return hipMemsetAsync(n_matches, 0, sizeof(int), c->stream);
     if ((e = match_ws_reserve(c, n1, n2)) != hipSuccess) return e;
-    MatchWs& w = c->mws;
-    if (!w.keys_clean) {           // a raw-descriptor call leaves its keys behind: clear them once when the call styles alternate
-        if ((e = hipMemsetAsync(w.keys, 0, (2 * w.cap_p1 + w.cap_p2) * MNN_PANEL * sizeof(u64), c->stream)) != hipSuccess) return e;
-    }
-    if ((e = launch_mnn_gemm(c, img1, n1, img2, n2, w.bestR, w.bestC, w.pairs)) != hipSuccess) return e;
-    e = launch_post(c, img1, n1, img2, n2, min_cossim, 1, idx1, idx2, dist, n_matches);
-    w.keys_clean = true;
-    return e;
+    return launch_gemm_post(c, img1, n1, img2, n2, min_cossim, idx1, idx2, dist, n_matches);
 }
 
 hipError_t launch_dist_i32(xfh_ctx* c, const float* d1, int n1, const float* d2, int n2, int32_t* out) {

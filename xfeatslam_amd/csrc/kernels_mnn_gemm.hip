@@ -6,8 +6,8 @@
 
 // measured on MI355X (tools/probes/mnn_probe, profiles/r02_mnn_probe.log): no wave priorities, arrival barrier + operand
 // reads of quarter kc+1 in the middle of the MFMAs of quarter kc, LDS-DMAs of quarter kc+2 issued before the wait for quarter kc+1
-hipError_t launch_mnn_gemm(xfh_ctx* c, const float* img1, int n1, const float* img2, int n2, u64* bestR, u64* bestC, u64* pairs) {
+hipError_t launch_mnn_gemm(xfh_ctx* c, const float* img1, int n1, const float* img2, int n2, u64* partR, size_t ldr, u64* partC, size_t ldc, u64* pairs) {
     const dim3 grid((n2 + MNN_PANEL - 1) / MNN_PANEL, (n1 + MNN_PANEL - 1) / MNN_PANEL);
-    launch_k(c, XFH_K_MNN_GEMM, -1, k_mnn_gemm_img<0, 1, 1>, grid, dim3(512), 0, img1, n1, img2, n2, bestR, bestC, pairs);
+    launch_k(c, XFH_K_MNN_GEMM, -1, k_mnn_gemm_img<0, 1, 1>, grid, dim3(512), 0, img1, n1, img2, n2, partR, ldr, partC, ldc, pairs);
     return hipGetLastError();
 }

@@ -24,13 +24,16 @@ __device__ __forceinline__ void mnn_dma1k(const float* gsrc_lane, float* lds_dst
 // per value and direction) over candidate groups that are fixed by the lane position:
 //     d1 row  -> best value over a group of 16 consecutive d2 rows   (key: value, d2 row / 16)
 //     d2 row  -> best value over a group of 16 consecutive d1 rows   (key: value, d1 row / 16)
-// merged across waves through LDS and across workgroups with 64-bit atomic max on (ordered(value) << 32 | ~group):
-// largest value, then lowest group = torch.max's "first index of the maximum" once k_mnn_post has named the first
-// member of the group that reaches the value (it recomputes the <= 16 dot products with the MFMA's own arithmetic).
+// as keys (ordered(value) << 32 | ~group), merged across waves through LDS and written to this block's plane:
+//     partR[blockIdx.x][d1 row]   (ldr = rows per plane),   partC[blockIdx.y][d2 row]   (ldc)
+// k_mnn_post takes the maximum over the planes: largest value, then lowest group = torch.max's "first index of the
+// maximum" once it has named the first member of the group that reaches the value (it recomputes the <= 16 dot
+// products with the MFMA's own arithmetic).  Every plane entry of a launched block is written (0 = no valid product),
+// so nothing has to be cleared between calls.
 template <int PRIO, int PIPE, int STG, int DBG = 0>      // DBG (probes only): 1 = no epilogue, 2 = no staging
 __global__ __launch_bounds__(512, 2)
 void k_mnn_gemm_img(const float* __restrict__ img1, int n1, const float* __restrict__ img2, int n2,
-                    u64* __restrict__ bestR, u64* __restrict__ bestC, u64* __restrict__ pairs) {
+                    u64* __restrict__ partR, size_t ldr, u64* __restrict__ partC, size_t ldc, u64* __restrict__ pairs) {
     __shared__ __attribute__((aligned(1024))) float smem[2 * MNN_PANEL_FLOATS];     // 128 KB: d1 image, d2 image
     const int t = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, i = lane & 31, h = lane >> 5;
@@ -136,7 +139,7 @@ void k_mnn_gemm_img(const float* __restrict__ img1, int n1, const float* __restr
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) sdbg += acc[rt][ct][0] + acc[rt][ct][7] + acc[rt][ct][15];
-        if (sdbg == 123.456f) bestR[t] = 1ull;
+        if (sdbg == 123.456f) partR[t] = 1ull;
         return;
     }
     // ---- epilogue.  acc[rt][ct][r] = < d1 row R0 + rt*16 + r , d2 row C0 + ct >
@@ -212,15 +215,15 @@ void k_mnn_gemm_img(const float* __restrict__ img1, int n1, const float* __restr
         sRow[wc * 256 + wr * 64 + lane] = (M > NEG) ? mnn_pack_key(M, grp) : 0ull;
     }
     __syncthreads();
+    // one key per row / column of this workgroup's block, written to the plane of this block (coalesced 2 KB each);
+    // k_mnn_post takes the maximum over the planes.  (64-bit atomic max straight into one bestR / bestC array was
+    // measured at ~15 ns per 1000 atomics: 131 K of them cost the kernel 2 us.)
     if (t < 256) {
-        // column t of the panel image order: position wc*128 + ct*32 + i  <->  d2 row col_base + wc*128 + i*4 + ct
-        const u64 k = mnn_umax64(mnn_umax64(sCol[t], sCol[256 + t]), mnn_umax64(sCol[512 + t], sCol[768 + t]));
-        const int col = col_base + (t & 128) + (t & 31) * 4 + ((t >> 5) & 3);
-        if (k) __hip_atomic_fetch_max(bestC + col, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // d2 row col_base + t  <->  position wc*128 + ct*32 + i  with  t = wc*128 + i*4 + ct
+        const int p = (t & 128) | ((t & 3) << 5) | ((t & 127) >> 2);
+        partC[(size_t)blockIdx.y * ldc + col_base + t] = mnn_umax64(mnn_umax64(sCol[p], sCol[256 + p]), mnn_umax64(sCol[512 + p], sCol[768 + p]));
     } else {
         const int r = t - 256;
-        const u64 k = mnn_umax64(sRow[r], sRow[256 + r]);
-        if (k) __hip_atomic_fetch_max(bestR + row_base + r, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        partR[(size_t)blockIdx.x * ldr + row_base + r] = mnn_umax64(sRow[r], sRow[256 + r]);
     }
 }
-

@@ -5,12 +5,11 @@
 
 // k_rownorm_img: F::normalize of both descriptor sets (ORBmatcher.cc:358-359: fp64 sum of squares, fp32
 // sqrt / max(.,1e-12) / divide) written as panel images; rows past the end of a set are written as zeros
-// (the GEMM masks their products).  Also resets the arg-max keys (bestR == nullptr: one set only, no keys -- the
-// prepare form).  16 lanes per row, 16 rows per block;
+// (the GEMM masks their products).  n2 == 0: one set only (the prepare form).  16 lanes per row, 16 rows per block;
 // blocks [0, P1*16) serve d1, the rest d2 (P = panels of the set).
 __global__ __launch_bounds__(256)
 void k_rownorm_img(const float* __restrict__ d1, int n1, const float* __restrict__ d2, int n2, int P1,
-                   float* __restrict__ img1, float* __restrict__ img2, u64* __restrict__ bestR, u64* __restrict__ bestC) {
+                   float* __restrict__ img1, float* __restrict__ img2) {
     const int t = threadIdx.x, sub = t & 15;
     int blk = blockIdx.x;
     const bool second = blk >= P1 * 16;
@@ -20,10 +19,7 @@ void k_rownorm_img(const float* __restrict__ d1, int n1, const float* __restrict
     const int n = second ? n2 : n1;
     float* img = second ? img2 : img1;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (row < n) {
-        v = *(const f32x4*)(d + (size_t)row * 64 + sub * 4);
-        if (sub == 0 && bestR) (second ? bestC : bestR)[row] = 0ull;
-    }
+    if (row < n) v = *(const f32x4*)(d + (size_t)row * 64 + sub * 4);
     double ss = (double)v.x * (double)v.x + (double)v.y * (double)v.y + (double)v.z * (double)v.z + (double)v.w * (double)v.w;
     ss += __shfl_xor(ss, 1); ss += __shfl_xor(ss, 2); ss += __shfl_xor(ss, 4); ss += __shfl_xor(ss, 8);
     const float nrm = fmaxf((float)sqrt(ss), 1e-12f);
@@ -49,9 +45,9 @@ __device__ __forceinline__ const float* mnn_row(const float* img, int row, int& 
 // k_mnn_post: second level of the arg-max, the mutual check (ORBmatcher.cc:367-372), the min_cossim gate (:361)
 // and the ordered output (:371-403) in one launch.  Blocks 0 .. gridDim.x-2: sixteen lanes per d1 row, sixteen rows
 // per workgroup (= one d1 row group of the bestC keys).
-//   bestR[row] = (M, gc): the row maximum M sits in d2 rows 16*gc .. 16*gc+15 -> lane c recomputes <row, 16*gc + c>;
+//   bestR[row] = max over the planes partR[.][row] = (M, gc): the row maximum M sits in d2 rows 16*gc .. 16*gc+15 -> lane c recomputes <row, 16*gc + c>;
 //   the first one equal to M is m12[row] (torch.max returns the first index of the maximum).
-//   bestC[col] = (Mc, gr): m21[col] is the first d1 row of 16*gr .. 16*gr+15 whose dot product equals Mc.  `row` is a
+//   bestC[col] = max over the planes partC[.][col] = (Mc, gr): m21[col] is the first d1 row of 16*gr .. 16*gr+15 whose dot product equals Mc.  `row` is a
 //   mutual match iff Mc == M, row lies in that group and no earlier row of the group reaches Mc -- lane c recomputes
 //   <16*gr + c, col> for the rows before `row` only; those rows are the workgroup's own 16 rows.
 // The kernel is bound by dependent memory round trips and by the number of cache-line requests, so all global reads
@@ -62,8 +58,7 @@ __device__ __forceinline__ const float* mnn_row(const float* img, int row, int& 
 // collectors (grid = nb + ncoll, nb = ceil(n1/16)): they poll the pairs (agent-scope atomic loads; MNN_PAIR_EMPTY = not
 // yet written; the data is its own flag, so no ticket and no fence) and write the matches in ascending idx1 with
 // dist = sqrt(2 (1 - cos)).  The writers never wait, so the collectors cannot dead-lock whatever the dispatch order
-// is; their spin is bounded.  mnn_ncoll(n1) = min(16, blocks of 256 rows).  zero_keys: the last collector clears
-// bestR / bestC afterwards (the prepared-image call style has no k_rownorm_img to do it).
+// is; their spin is bounded.  mnn_ncoll(n1) = min(16, blocks of 256 rows).
 #define MNN_PAIR_EMPTY 0xFFFFFFFE00000000ull
 #define MNN_SPIN_LIMIT (1 << 22)
 __host__ __device__ inline int mnn_ncoll(int n1) { const int nq = (n1 + 255) >> 8; return nq < 16 ? (nq < 1 ? 1 : nq) : 16; }
@@ -72,8 +67,8 @@ __host__ __device__ inline int mnn_ncoll(int n1) { const int nq = (n1 + 255) >> 
 template <int TS>            // TS (probes only): wall-clock stamps of block 0 / the collector into `stamps`
 __global__ __launch_bounds__(256)
 void k_mnn_post(const float* __restrict__ img1, int n1, const float* __restrict__ img2, int n2,
-                const u64* __restrict__ bestR, const u64* __restrict__ bestC, float min_cossim,
-                u64* __restrict__ pairs, int nb, int ncoll, int zero_keys, u64* __restrict__ zR, u64* __restrict__ zC, int* __restrict__ idx1, int* __restrict__ idx2, float* __restrict__ dist, int* __restrict__ n_matches,
+                const u64* __restrict__ partR, size_t ldr, int npr, const u64* __restrict__ partC, size_t ldc, int npc, float min_cossim,
+                u64* __restrict__ pairs, int nb, int ncoll, int* __restrict__ idx1, int* __restrict__ idx2, float* __restrict__ dist, int* __restrict__ n_matches,
                 long long* __restrict__ stamps) {
     extern __shared__ __attribute__((aligned(16))) float spost[];
     const int t = threadIdx.x;
@@ -84,7 +79,10 @@ void k_mnn_post(const float* __restrict__ img1, int n1, const float* __restrict_
         float* sB = spost + 16 * MNN_POST_LD;            // [16 row groups][16 candidates][68]
         const int c = t & 15, grp = t >> 4;
         const int row = blockIdx.x * 16 + grp;           // the image holds whole panels: rows up to the panel end are readable (zeros)
-        const u64 kr = (row < n1) ? bestR[row] : 0ull;
+        // bestR[row] = maximum over the npr planes the GEMM blocks of this d1 panel wrote: lane c takes planes c, c+16, ...
+        u64 kr = 0ull;
+        if (row < n1) for (int pl = c; pl < npr; pl += 16) kr = mnn_umax64(kr, partR[(size_t)pl * ldr + row]);
+        kr = mnn_umax64(kr, __shfl_xor(kr, 1)); kr = mnn_umax64(kr, __shfl_xor(kr, 2)); kr = mnn_umax64(kr, __shfl_xor(kr, 4)); kr = mnn_umax64(kr, __shfl_xor(kr, 8));
         {
             int sa;
             const float* ra = mnn_row(img1, row, sa);
@@ -94,7 +92,18 @@ void k_mnn_post(const float* __restrict__ img1, int n1, const float* __restrict_
         const int gc = (int)(0xFFFFFFFFu - (unsigned)(kr & 0xFFFFFFFFull));
         const int col = gc * MNN_CGROUP + c;
         const bool have = kr != 0ull && col < n2;
-        const u64 kcand = have ? bestC[col] : 0ull;
+        u64 kcand = 0ull;                                // bestC[col] = maximum over the npc planes
+        if (have) {
+            int pl = 0;
+            for (; pl + 8 <= npc; pl += 8) {              // eight independent loads in flight
+                u64 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = partC[(size_t)(pl + u) * ldc + col];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) kcand = mnn_umax64(kcand, v[u]);
+            }
+            for (; pl < npc; ++pl) kcand = mnn_umax64(kcand, partC[(size_t)pl * ldc + col]);
+        }
         if (kr != 0ull) {                                // candidate rows 16*gc .. 16*gc+15 (inside the panel image: readable)
             f32x4 pv[16];
 #pragma unroll
@@ -242,10 +251,6 @@ void k_mnn_post(const float* __restrict__ img1, int n1, const float* __restrict_
         }
         if (__syncthreads_or(timeout ? 1 : 0)) run = -1;   // a writer never showed up (cannot happen): report it instead of hanging
         if (t == 0) *n_matches = run;
-        if (zero_keys) {                                 // every row has been published: nobody reads the keys any more
-            for (int i = t; i < n1; i += 256) zR[i] = 0ull;
-            for (int i = t; i < n2; i += 256) zC[i] = 0ull;
-        }
     }
     MNN_STAMP(10);
 #undef MNN_STAMP

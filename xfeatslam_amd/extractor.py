@@ -29,6 +29,7 @@ class Context:
         h = C.c_void_p()
         check(lib().xfh_create(C.byref(cfg), C.byref(h)))
         self.h = h
+        self.device = device
         self.nfeatures = nfeatures
         self.max_batch = max_batch
         self.rec_bytes = int(lib().xfh_record_bytes(nfeatures))
