@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--gather", choices=["allgather", "root", "compact"], default="allgather")
     ap.add_argument("--force-comm", action="store_true", help="run the RCCL exchange also with one rank")
     ap.add_argument("--no-legs", action="store_true", help="timed region only (no host_api / match / aux / cpu legs)")
+    ap.add_argument("--serial-branch", action="store_true", help="XFH_FLAG_SERIAL_BRANCH: no overlapping kernels (for per-kernel profiles)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0)); local_rank = int(os.environ.get("LOCAL_RANK", 0))
@@ -110,7 +111,7 @@ def main():
     dev = local_rank if N > 1 else 0
     blob = WT.pack_blob(WT.make_synthetic(1234, KP_GAIN))
     S = max(1, args.streams)
-    ctxs = [Context(nfeatures=NFEATURES, max_height=H, max_width=W, max_batch=B, device=dev) for _ in range(S)]
+    ctxs = [Context(nfeatures=NFEATURES, max_height=H, max_width=W, max_batch=B, device=dev, flags=capi.FLAG_SERIAL_BRANCH if args.serial_branch else 0) for _ in range(S)]
     for c_ in ctxs:
         c_.load_weights(blob)
     ctx = ctxs[0]

@@ -73,6 +73,9 @@ typedef struct {
  * as upstream XFeat does.  The reference multiplies by a Long-typed factor, i.e. by 1 (XFextractor.cc:304-305,
  * SURVEY.md Q2): for inputs whose sides are not multiples of 32 its keypoints stay in the resized frame. */
 #define XFH_FLAG_RESCALE_KEYPOINTS 1
+/* XFH_FLAG_SERIAL_BRANCH: run the keypoint-head branch on the ctx stream instead of the ctx's second stream (same results;
+ * no two kernels overlap, so a profiler's per-launch durations are the kernels' own: profiles/r02_roofline_table.md). */
+#define XFH_FLAG_SERIAL_BRANCH 2
 
 /* fills the defaults: device 0, 480x640, nfeatures 4096, max_batch 1, threshold 0.05 */
 void xfh_config_default(xfh_config* cfg);
@@ -258,8 +261,8 @@ const char* xfh_kernel_name(int kernel_id);
 /* intermediate tensors of frame `frame` of the last extract call, copied to host as float
  * (ids match oracle/xfeat_oracle.h; image-like tensors are NHWC).  count_out = floats. */
 enum {
-    XFH_T_X = 0, XFH_T_XSTAT = 1, XFH_T_SKIP_POOL = 2, XFH_T_XUNFOLD = 3, XFH_T_B2IN = 4,
-    XFH_T_FUSE_IN = 5, XFH_T_FEATS = 6, XFH_T_M1N = 7, XFH_T_H1 = 8, XFH_T_K1H = 9,
+    XFH_T_X = 0, XFH_T_XSTAT = 1, XFH_T_SKIP_POOL = 2, XFH_T_XUNFOLD = 3,           /* 4, 5, 7 (x1 + skip, fusion input, normalised features) */
+    XFH_T_FEATS = 6, XFH_T_H1 = 8, XFH_T_K1H = 9,                                   /* are never materialised on the GPU: fused into consumers */
     XFH_T_RAW0 = 16, XFH_T_STAT0 = 48, XFH_T_SEL = 80
 };
 int xfh_debug_tensor(xfh_ctx* ctx, int id, int frame, float* out, size_t capacity, size_t* count_out);

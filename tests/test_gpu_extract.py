@@ -67,9 +67,17 @@ def test_stage_tensors_match_oracle(gpu_lib, oracle_mod, weights_std):
     _, blob = weights_std
     img = synth.image(160, 224, 9)
     orc = oracle_mod.Oracle(blob); orc.extract(img, 512, (0, 0))
-    ctx = _ctx(512, 160, 224); ctx.load_weights(blob); ctx.extract_batch(img[None])
+    ctx = _ctx(512, 160, 224, B=12); ctx.load_weights(blob)
     T, OT = capi.T, oracle_mod.T
-    for nm in ["X", "XSTAT", "SKIP_POOL", "XUNFOLD", "B2IN", "FUSE_IN", "FEATS", "M1N"]:
+    # B = 12: statistics finalised by k_bn_finalize, persistent short-K kernels; then B = 1 (everything folded by the consumers)
+    ctx.extract_batch(np.stack([img] * 12))
+    big = {i: (ctx.debug_tensor(T["RAW0"] + i, 11), ctx.debug_tensor(T["STAT0"] + i, 11)) for i in range(23)}
+    ctx.extract_batch(img[None])
+    for i in range(23):
+        assert np.array_equal(big[i][0], ctx.debug_tensor(T["RAW0"] + i)) and np.array_equal(big[i][1], ctx.debug_tensor(T["STAT0"] + i)), f"regimes differ at layer {i}"
+    # x1 + skip1(x), the fusion input and the normalised features are never materialised on the GPU (they are computed while the
+    # consuming kernels stage their inputs); raw maps 4 (block2.0) and 16 (block_fusion.0) and the descriptors cover them
+    for nm in ["X", "XSTAT", "SKIP_POOL", "XUNFOLD", "FEATS"]:
         assert np.array_equal(ctx.debug_tensor(T[nm]), orc.tensor(OT[nm])), nm
     for i in range(23):
         a, b = ctx.debug_tensor(T["RAW0"] + i), orc.tensor(OT["RAW0"] + i)

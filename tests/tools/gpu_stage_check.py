@@ -124,11 +124,8 @@ def extract_checks(H, W, gain, nf=4096, lap=(0, 0), seed=42):
     for i in range(23):
         cmp("raw " + LAYER_NAMES[i], ctx.debug_tensor(capi.T["RAW0"] + i), orc.tensor(O.T["RAW0"] + i))
         cmp("st  " + LAYER_NAMES[i], ctx.debug_tensor(capi.T["STAT0"] + i), orc.tensor(O.T["STAT0"] + i))
-        if i == 3: cmp("B2IN", ctx.debug_tensor(capi.T["B2IN"]), orc.tensor(O.T["B2IN"]))
-        if i == 15: cmp("FUSE_IN", ctx.debug_tensor(capi.T["FUSE_IN"]), orc.tensor(O.T["FUSE_IN"]))
         if i == 17:
             cmp("FEATS", ctx.debug_tensor(capi.T["FEATS"]), orc.tensor(O.T["FEATS"]))
-            cmp("M1N", ctx.debug_tensor(capi.T["M1N"]), orc.tensor(O.T["M1N"]))
     cmp("H1", ctx.debug_tensor(capi.T["H1"]), orc.tensor(O.T["H1"]))
     cmp("K1H", ctx.debug_tensor(capi.T["K1H"]), orc.tensor(O.T["K1H"]))
     hs = ctx.debug_tensor(capi.T["SEL"]).reshape(-1, 3); os_ = orc.tensor(O.T["SEL"]).reshape(-1, 3)

@@ -80,6 +80,28 @@ __device__ __forceinline__ void bn_fold(const double* __restrict__ p, int npart,
     __syncthreads();
 }
 
+// statistics of a producer layer as a consumer sees them: either finalised (stat: [B][2*C] mean, rstd) or, for small
+// batches, still as fp64 partials that every workgroup of the consumer folds itself (bn_fold; the same order, hence the
+// same bits as k_bn_finalize) -- workgroup 0 of each frame publishes the result to stat_out for the debug API and for
+// consumers that do not fold
+struct StatSrc {
+    const float* stat;
+    const double* part; size_t part_stride; int npart; double count; float* stat_out;
+};
+
+// statistics of frame b into LDS (2*C floats): folded here from the partials, or copied.  `red`: >= 512 doubles of LDS
+// scratch (only touched when folding).  Ends with a barrier.
+__device__ __forceinline__ void stage_stat(const StatSrc& st, int b, int C, bool publish, float* s_stat, double* red, int t, int nthr) {
+    if (st.part) {
+        bn_fold(st.part + (size_t)b * st.part_stride, st.npart, C, st.count, s_stat, red, t, nthr);
+        if (publish) for (int q = t; q < 2 * C; q += nthr) st.stat_out[(size_t)b * 2 * C + q] = s_stat[q];
+    } else {
+        const float* g = st.stat + (size_t)b * 2 * C;
+        for (int q = t; q < 2 * C; q += nthr) s_stat[q] = g[q];
+        __syncthreads();
+    }
+}
+
 // per-frame output record header (include/xfeat_hip.h, xfh_record_bytes)
 struct RecordHeader { int32_t n_valid, mono_index, n_candidates, reserved; };
 

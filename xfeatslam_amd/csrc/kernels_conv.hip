@@ -24,7 +24,7 @@
 
 struct ConvArgs {
     const float* in;        // raw input slab (or plain input)
-    const float* in_stat;   // [B][2*CIN] mean, rstd of the producer (PRO_BN) / [B][2] (PRO_IN)
+    StatSrc st;             // statistics of `in` (PRO_BN / PRO_B2IN), InstanceNorm statistics of the image (PRO_IN: st.stat = [B][2])
     size_t in_stride;       // floats per frame
     int Hin, Win;
     const float* w;         // packed weights
@@ -35,13 +35,56 @@ struct ConvArgs {
     double* part;           // [B][npart][COUT][2]
     size_t part_stride;     // doubles per frame
     int tiles_x;
-    // consumer-side statistics fold (small batches, k_conv_mfma PRO_BN): when in_part != nullptr every workgroup folds the
-    // producer's partials itself (bn_fold) instead of reading in_stat, and tile 0 publishes them to in_stat_out
-    const double* in_part; size_t in_part_stride; int in_npart; double in_count; float* in_stat_out;
+    // PRO_B2IN (block2.0: input = relu(bn(block1.3)) + skip1(x), XFeat.cc:153): pooled image and the 1x1 skip convolution
+    const float* pool; size_t pool_stride; const float* skip_w; const float* skip_b;
+    // PRO_FUSE (block_fusion.0: input = x3 + up2(x4) + up4(x5), XFeat.cc:159-166): `in` / st are block3.2 (x3)
+    const float* r4; size_t s4; int H4, W4; StatSrc st4;      // block4.2
+    const float* r5; size_t s5; int H5, W5; StatSrc st5;      // block5.3
 };
 
-enum { PRO_PLAIN = 0, PRO_BN = 1, PRO_IN = 2 };
+// PRO_PLAIN: input used as is; PRO_BN: relu((x - mean) * rstd) of the producer; PRO_IN: InstanceNorm of the image;
+// PRO_B2IN / PRO_FUSE: the two element-wise glue steps of the backbone computed while staging (no intermediate tensor)
+enum { PRO_PLAIN = 0, PRO_BN = 1, PRO_IN = 2, PRO_B2IN = 3, PRO_FUSE = 4 };
 enum { EPI_STATS = 0, EPI_BIAS = 1 };
+
+// ATen upsample_bilinear2d (align_corners=false) source index / weights; see oracle lin_coeff
+__device__ __forceinline__ void lin_coeff_c(int in, int out, int d, int& i0, int& i1, float& l0, float& l1) {
+    const float scale = (float)in / (float)out;
+    float src = fmaf(scale, (float)d + 0.5f, -0.5f);
+    if (src < 0.f) src = 0.f;
+    int a = (int)src;
+    if (a > in - 1) a = in - 1;
+    float lam = src - (float)a;
+    lam = fminf(fmaxf(lam, 0.f), 1.f);
+    i0 = a; i1 = a + ((a < in - 1) ? 1 : 0);
+    l1 = lam; l0 = 1.f - lam;
+}
+// 8 channels (group g) of relu(bn(raw)) at one pixel; st: LDS mean[64], rstd[64]
+__device__ __forceinline__ void ld_act8(const float* __restrict__ raw, const float* st, size_t pix, int g, f32x4& v0, f32x4& v1) {
+    const float* p = raw + pix * 64 + g * 8;
+    v0 = *(const f32x4*)p; v1 = *(const f32x4*)(p + 4);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        v0[q] = fmaxf((v0[q] - st[g * 8 + q]) * st[64 + g * 8 + q], 0.f);
+        v1[q] = fmaxf((v1[q] - st[g * 8 + 4 + q]) * st[64 + g * 8 + 4 + q], 0.f);
+    }
+}
+// bilinear sample (ATen arithmetic: fma(w0, v0, w1*v1) per axis) of relu(bn(raw)) for 8 channels
+__device__ __forceinline__ void up_bilinear8(const float* __restrict__ raw, const float* st, int Hi, int Wi, int Ho, int Wo, int y, int x, int g, f32x4& o0, f32x4& o1) {
+    int y0, y1, x0, x1; float hy0, hy1, wx0, wx1;
+    lin_coeff_c(Hi, Ho, y, y0, y1, hy0, hy1);
+    lin_coeff_c(Wi, Wo, x, x0, x1, wx0, wx1);
+    f32x4 a0, a1, b0, b1, c0, c1, d0, d1;
+    ld_act8(raw, st, (size_t)y0 * Wi + x0, g, a0, a1); ld_act8(raw, st, (size_t)y0 * Wi + x1, g, b0, b1);
+    ld_act8(raw, st, (size_t)y1 * Wi + x0, g, c0, c1); ld_act8(raw, st, (size_t)y1 * Wi + x1, g, d0, d1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float t0 = fmaf(wx0, a0[j], wx1 * b0[j]), u0 = fmaf(wx0, c0[j], wx1 * d0[j]);
+        o0[j] = fmaf(hy0, t0, hy1 * u0);
+        const float t1 = fmaf(wx0, a1[j], wx1 * b1[j]), u1 = fmaf(wx0, c1[j], wx1 * d1[j]);
+        o1[j] = fmaf(hy0, t1, hy1 * u1);
+    }
+}
 
 // ------------------------------------------------------------------------------------
 // statistics finalisation: grid = B, block = 256.  thread (c, j): channel c, slice j.
@@ -55,18 +98,23 @@ void k_bn_finalize(const double* __restrict__ part, size_t part_stride, int npar
 
 // ------------------------------------------------------------------------------------
 // direct convolution 3x3 for block1.  16x16 output pixels per workgroup.
-template <int CIN, int COUT, int ST, int PRO>
+// FOLD (small batches, PRO_BN): the workgroup folds the producer's statistic partials itself (LDS); otherwise the
+// finalised statistics come through the scalar cache -- staging them through LDS first would put a second dependent
+// memory round trip into every workgroup's latency chain, which is what bounds these kernels (measured 3.5x slower).
+template <int CIN, int COUT, int ST, int PRO, bool FOLD>
 __global__ __launch_bounds__(256)
 void k_conv_direct(ConvArgs a) {
     constexpr int TI = 15 * ST + 3;
     constexpr int SL = 256 / COUT;
     __shared__ __attribute__((aligned(16))) float s_in[TI * TI * CIN];
     __shared__ __attribute__((aligned(16))) float s_out[256 * (COUT + 1)];
-    __shared__ double s_red[SL * COUT * 2];
+    __shared__ double s_red[(SL * COUT * 2 > 512) ? SL * COUT * 2 : 512];
     const int t = threadIdx.x, b = blockIdx.z;
     const int tile = blockIdx.x, tx0 = (tile % a.tiles_x) * 16, ty0 = (tile / a.tiles_x) * 16;
     const float* in = a.in + (size_t)b * a.in_stride;
-    const float* st = a.in_stat + (size_t)b * 2 * (PRO == PRO_IN ? 1 : CIN);
+    __shared__ float s_stat[FOLD ? 2 * CIN : 1];
+    if constexpr (FOLD) stage_stat(a.st, b, CIN, tile == 0, s_stat, s_red, t, 256);                // s_red is free until the epilogue
+    const float* st = a.st.stat + (size_t)b * 2 * (PRO == PRO_IN ? 1 : CIN);                      // wave-uniform: scalar loads
 
     // stage the activated input tile, zero outside the image (Conv2d zero padding)
     constexpr int VEC = (CIN >= 4) ? 4 : 1;
@@ -82,7 +130,7 @@ void k_conv_direct(ConvArgs a) {
                 v = *(const f32x4*)(in + ((size_t)gy * a.Win + gx) * CIN + g * 4);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float m = st[g * 4 + q], r = st[CIN + g * 4 + q];
+                    const float m = FOLD ? s_stat[g * 4 + q] : st[g * 4 + q], r = FOLD ? s_stat[CIN + g * 4 + q] : st[CIN + g * 4 + q];
                     v[q] = fmaxf((v[q] - m) * r, 0.f);
                 }
             }
@@ -183,7 +231,7 @@ void k_conv_mfma(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_in = smem;
     float* s_w = smem + IN_FLOATS;               // two buffers of W_FLOATS
-    float* s_stat = s_w + NWBUF * W_FLOATS;      // 2*CIN floats (PRO_BN)
+    float* s_stat = s_w + NWBUF * W_FLOATS;      // 2*CIN floats (PRO_BN), 4*CIN (PRO_B2IN: + skip weights / bias), 3*128 (PRO_FUSE)
 
     const int t = threadIdx.x, b = blockIdx.z;
     const int tile = blockIdx.x, tx0 = (tile % a.tiles_x) * TW, ty0 = (tile / a.tiles_x) * TH;
@@ -196,15 +244,15 @@ void k_conv_mfma(ConvArgs a) {
         const int f = t + q * NTHR;
         if (f < WCH / 4) wreg[q] = *(const f32x4*)(a.w + (size_t)f * 4);
     }
-    if constexpr (PRO == PRO_BN) {
-        if (a.in_part) {            // consumer-side fold of the producer's statistics (small batches); s_in is still free
-            bn_fold(a.in_part + (size_t)b * a.in_part_stride, a.in_npart, CIN, a.in_count, s_stat, (double*)s_in, t, NTHR);
-            if (tile == 0) for (int q = t; q < 2 * CIN; q += NTHR) a.in_stat_out[(size_t)b * 2 * CIN + q] = s_stat[q];
-        } else {
-            const float* st = a.in_stat + (size_t)b * 2 * CIN;
-            for (int q = t; q < 2 * CIN; q += NTHR) s_stat[q] = st[q];
-            __syncthreads();
-        }
+    // producer statistics -> LDS (folded here for small batches; s_in is still free and serves as fp64 scratch)
+    if constexpr (PRO == PRO_BN || PRO == PRO_B2IN || PRO == PRO_FUSE) stage_stat(a.st, b, CIN, tile == 0, s_stat, (double*)s_in, t, NTHR);
+    if constexpr (PRO == PRO_B2IN) {
+        for (int q = t; q < CIN; q += NTHR) { s_stat[2 * CIN + q] = a.skip_w[q]; s_stat[3 * CIN + q] = a.skip_b[q]; }
+        __syncthreads();
+    }
+    if constexpr (PRO == PRO_FUSE) {
+        stage_stat(a.st4, b, 64, tile == 0, s_stat + 128, (double*)s_in, t, NTHR);
+        stage_stat(a.st5, b, 64, tile == 0, s_stat + 256, (double*)s_in, t, NTHR);
     }
     // ---- stage the activated input tile (zero padding outside the image) ----------------
     for (int item = t; item < TIH * TIW * G; item += NTHR) {
@@ -216,12 +264,27 @@ void k_conv_mfma(ConvArgs a) {
             const float* p = in + ((size_t)gy * a.Win + gx) * CIN + g * 8;
             v0 = *(const f32x4*)p;
             v1 = *(const f32x4*)(p + 4);
-            if constexpr (PRO == PRO_BN) {
+            if constexpr (PRO == PRO_BN || PRO == PRO_B2IN || PRO == PRO_FUSE) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     v0[q] = fmaxf((v0[q] - s_stat[g * 8 + q]) * s_stat[CIN + g * 8 + q], 0.f);
                     v1[q] = fmaxf((v1[q] - s_stat[g * 8 + 4 + q]) * s_stat[CIN + g * 8 + 4 + q], 0.f);
                 }
+            }
+            if constexpr (PRO == PRO_B2IN) {            // x1 + skip1(x): AvgPool4 of the normalised image, 1x1 conv with bias (XFeat.cc:36-39,153)
+                const float pl = a.pool[(size_t)b * a.pool_stride + (size_t)gy * a.Win + gx];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    v0[q] = v0[q] + (pl * s_stat[2 * CIN + g * 8 + q] + s_stat[3 * CIN + g * 8 + q]);
+                    v1[q] = v1[q] + (pl * s_stat[2 * CIN + g * 8 + 4 + q] + s_stat[3 * CIN + g * 8 + 4 + q]);
+                }
+            }
+            if constexpr (PRO == PRO_FUSE) {            // x3 + up2(x4) + up4(x5) with ATen's bilinear arithmetic (XFeat.cc:159-166)
+                f32x4 u0, u1, w0, w1;
+                up_bilinear8(a.r4 + (size_t)b * a.s4, s_stat + 128, a.H4, a.W4, a.Hin, a.Win, gy, gx, g, u0, u1);
+                up_bilinear8(a.r5 + (size_t)b * a.s5, s_stat + 256, a.H5, a.W5, a.Hin, a.Win, gy, gx, g, w0, w1);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { v0[q] = (v0[q] + u0[q]) + w0[q]; v1[q] = (v1[q] + u1[q]) + w1[q]; }
             }
         }
         // k permutation inside each group of 8: position 4*(k&1) + (k>>1)
@@ -383,6 +446,7 @@ void k_conv_mfma_p(ConvArgs a, int ntile, int total) {
     const int ly = (wm * WH + pr) * ST, lx = pc * ST;
 
     f32x4 v0[NIT], v1[NIT];
+    float pl[NIT];                                // PRO_B2IN: pooled image value of the item's pixel
     unsigned inside = 0u;
     auto load_tile = [&](int tile) {              // global -> registers (raw values), remembers which items lie inside the image
         const int b = tile / ntile, tl = tile - b * ntile;
@@ -399,28 +463,34 @@ void k_conv_mfma_p(ConvArgs a, int ntile, int total) {
             if (t < NE && item < NITEM && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win) {
                 const float* p = in + ((size_t)gy * a.Win + gx) * CIN + g * 8;
                 v0[k] = *(const f32x4*)p; v1[k] = *(const f32x4*)(p + 4);
+                if constexpr (PRO == PRO_B2IN) pl[k] = a.pool[(size_t)b * a.pool_stride + (size_t)gy * a.Win + gx];
                 inside |= 1u << k;
             }
         }
     };
     auto store_tile = [&](int tile) {             // registers -> activated, k-permuted LDS tile
-        f32x4 m0, m1, r0, r1;
-        if constexpr (PRO == PRO_BN) {
+        f32x4 m0, m1, r0, r1, w0, w1, c0, c1;
+        if constexpr (PRO == PRO_BN || PRO == PRO_B2IN) {
             const int b = tile / ntile;
-            const float* st = a.in_stat + (size_t)b * 2 * CIN + g * 8;
+            const float* st = a.st.stat + (size_t)b * 2 * CIN + g * 8;      // large batches: always finalised statistics
             m0 = *(const f32x4*)st; m1 = *(const f32x4*)(st + 4); r0 = *(const f32x4*)(st + CIN); r1 = *(const f32x4*)(st + CIN + 4);
+        }
+        if constexpr (PRO == PRO_B2IN) {
+            w0 = *(const f32x4*)(a.skip_w + g * 8); w1 = *(const f32x4*)(a.skip_w + g * 8 + 4);
+            c0 = *(const f32x4*)(a.skip_b + g * 8); c1 = *(const f32x4*)(a.skip_b + g * 8 + 4);
         }
 #pragma unroll
         for (int k = 0; k < NIT; ++k) {
             const int item = t + k * NE;
             if (t < NE && item < NITEM) {
                 f32x4 x0 = v0[k], x1 = v1[k];
-                if constexpr (PRO == PRO_BN) {
+                if constexpr (PRO == PRO_BN || PRO == PRO_B2IN) {
                     if (inside & (1u << k)) {
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             x0[q] = fmaxf((x0[q] - m0[q]) * r0[q], 0.f);
                             x1[q] = fmaxf((x1[q] - m1[q]) * r1[q], 0.f);
+                            if constexpr (PRO == PRO_B2IN) { x0[q] = x0[q] + (pl[k] * w0[q] + c0[q]); x1[q] = x1[q] + (pl[k] * w1[q] + c1[q]); }
                         }
                     }
                 }
@@ -525,7 +595,8 @@ static hipError_t conv_mfma_launch(xfh_ctx* c, const ConvArgs& a, int B, int* np
     constexpr int TIH = (TH - 1) * ST + KS, TIW = (TW - 1) * ST + KS;
     constexpr int CB = CIN > CBMAX ? CBMAX : CIN;
     constexpr int NWBUF = (KS * KS * (CIN / CB) / TPC) > 1 ? 2 : 1;
-    constexpr size_t LDS = sizeof(float) * ((size_t)TIH * TIW * (CIN + 4) + NWBUF * (size_t)COUTP * (TPC * CB + 4) + 2 * CIN);
+    constexpr int STATF = PRO == PRO_FUSE ? 384 : (PRO == PRO_B2IN ? 4 * CIN : 2 * CIN);
+    constexpr size_t LDS = sizeof(float) * ((size_t)TIH * TIW * (CIN + 4) + NWBUF * (size_t)COUTP * (TPC * CB + 4) + STATF);
     static_assert(LDS <= 160 * 1024, "LDS budget");
     static_assert(sizeof(double) * WM * COUTP * 2 <= LDS, "stat scratch");
     static_assert(sizeof(double) * 512 <= sizeof(float) * (size_t)TIH * TIW * (CIN + 4), "bn_fold scratch in the input tile");
@@ -560,12 +631,17 @@ static hipError_t conv_mfma_p_launch(xfh_ctx* c, const ConvArgs& a, int B, int* 
     return hipGetLastError();
 }
 
-// persistent kernels for the short-K layers of large batches; XFH_PERSIST=0 falls back to k_conv_mfma
-static bool persistent(int B) {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("XFH_PERSIST"); v = e ? atoi(e) : 1; }
-    return v != 0 && B > 8;
-}
+// Batch regimes (tests/test_gpu_extract.py::test_batch_is_per_frame checks that they agree bit for bit):
+//   B > 8 : persistent kernels for the short-K layers (k_conv_mfma_p), k_bn_finalize after every layer;
+//   B <= 8: a dependent launch costs ~5 us on this GPU whatever it does, so EVERY consumer folds the statistics of its
+//           producer itself (bn_fold in each workgroup: same order, same bits, ~2 us of latency instead of a launch) and
+//           k_bn_finalize is never launched -- at large batches the per-workgroup re-read of the partials would cost
+//           more than the launch;
+//   B == 1: additionally 2x16-pixel tiles with three taps per weight chunk for the 3x3 64->64 layers (40 workgroups of
+//           the 8x16 form cannot fill 256 CUs, and at one wave per SIMD the K loop otherwise waits on each weight chunk).
+static bool persistent(int B) { return B > 8; }
+bool consumer_fold(int B) { return B <= 8; }
+static bool small_batch(int B) { return B == 1; }
 
 template <int CIN, int COUT, int ST, int PRO>
 static hipError_t conv_direct_launch(xfh_ctx* c, const ConvArgs& a, int B, int* npart_out, int layer) {
@@ -573,38 +649,12 @@ static hipError_t conv_direct_launch(xfh_ctx* c, const ConvArgs& a, int B, int* 
     aa.tiles_x = (a.Wout + 15) / 16;
     const int ntile = aa.tiles_x * ((a.Hout + 15) / 16);
     if (npart_out) *npart_out = ntile;
-    launch_k(c, XFH_K_CONV_DIRECT, layer, k_conv_direct<CIN, COUT, ST, PRO>, dim3(ntile, 1, B), dim3(256), 0, aa);
+    if (PRO == PRO_BN && a.st.part) launch_k(c, XFH_K_CONV_DIRECT, layer, k_conv_direct<CIN, COUT, ST, PRO, PRO == PRO_BN>, dim3(ntile, 1, B), dim3(256), 0, aa);
+    else launch_k(c, XFH_K_CONV_DIRECT, layer, k_conv_direct<CIN, COUT, ST, PRO, false>, dim3(ntile, 1, B), dim3(256), 0, aa);
     return hipGetLastError();
 }
 
 // number of statistic partials a layer produces per frame (needed to size buffers up front)
-// tile configuration of the 3x3 64->64 layers at 1/8 resolution (see launch_basic_layer)
-// single-frame tile configurations (latency path; measured 0.492 -> 0.477 ms at B = 1, slower from B = 2 on).
-// XFH_SMALL_BATCH=0/1 forces it
-static bool small_batch(int B) {
-    static int v = -2;
-    if (v == -2) { const char* e = getenv("XFH_SMALL_BATCH"); v = e ? atoi(e) : -1; }
-    return v < 0 ? B == 1 : v != 0;
-}
-static int conv_cfg() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("XFH_CONV_CFG"); v = e ? atoi(e) : 1; }
-    return v;
-}
-
-// Small batches: a dependent launch costs ~5 us on this GPU whatever it does, so the statistics of a layer
-// whose consumer is a convolution are folded by every workgroup of that consumer (same bn_fold, same bits;
-// ~2 us of latency instead of a launch) and published by its tile 0.  Large batches keep k_bn_finalize:
-// there the per-workgroup re-read of the partials would cost more than the launch.  XFH_CONSUMER_FOLD=0/1 forces it.
-bool consumer_fold(int B) {
-    static int v = -2;
-    if (v == -2) { const char* e = getenv("XFH_CONSUMER_FOLD"); v = e ? atoi(e) : -1; }
-    return v < 0 ? B <= 8 : v != 0;
-}
-// layers whose (only or first) consumer is a PRO_BN k_conv_mfma: all but block1.0/1.1 (-> k_conv_direct, which reads the
-// statistics through the scalar cache), block1.3 (-> k_b2in), block5.3 (-> k_fuse_in), heatmap_head.1 / keypoint_head.2 (-> heads)
-static bool folds_in_consumer(int li) { return li >= 2 && li != 3 && li != 15 && li != 19 && li != 22; }
-
 int conv_layer_npart(int li, int Hout, int Wout) {
     auto cdiv = [](int a, int b) { return (a + b - 1) / b; };
     if (li < 3) return cdiv(Wout, 16) * cdiv(Hout, 16);
@@ -616,73 +666,79 @@ int conv_layer_npart(int li, int Hout, int Wout) {
     }
 }
 
-// BasicLayer li: conv + statistics partials + finalize.  `in`/`in_stat`: producer tensors.
-hipError_t launch_basic_layer(xfh_ctx* c, int li, const float* in, size_t in_stride, const float* in_stat,
-                              int pro, int Hin, int Win, int B) {
+// statistics of layer j as its consumer gets them in a batch of B frames
+StatSrc stat_src(xfh_ctx* c, int j, int B) {
+    StatSrc s{};
+    s.stat = c->stat[j];
+    if (c->cfg.bn_mode != XFH_BN_RUNNING_STATS && consumer_fold(B)) {
+        s.part = c->part[j]; s.part_stride = c->part_stride[j]; s.npart = c->npart[j];
+        s.count = (double)c->lh[j] * (double)c->lw[j]; s.stat_out = c->stat[j];
+    }
+    return s;
+}
+
+// BasicLayer li: conv + statistics partials (+ finalize for large batches).  `in`: producer tensor; src >= 0: the
+// BasicLayer whose BatchNorm + ReLU is applied while staging (PRO_BN / PRO_B2IN / PRO_FUSE), src == -1: plain input,
+// src == -2: InstanceNorm of the image (block1.0).
+hipError_t launch_basic_layer(xfh_ctx* c, int li, const float* in, size_t in_stride, int src, int pro, int Hin, int Win, int B) {
     const LayerSpec& L = XFH_LAYERS[li];
     const int pad = L.ks / 2;
     const int Hout = (Hin + 2 * pad - L.ks) / L.stride + 1, Wout = (Win + 2 * pad - L.ks) / L.stride + 1;
     c->lh[li] = Hout; c->lw[li] = Wout;
     ConvArgs a{};
-    a.in = in; a.in_stat = in_stat; a.in_stride = in_stride; a.Hin = Hin; a.Win = Win;
+    a.in = in; a.in_stride = in_stride; a.Hin = Hin; a.Win = Win;
+    if (src >= 0) a.st = stat_src(c, src, B);
+    else if (src == -2) a.st.stat = c->xstat;
     a.w = (li < 3) ? c->w.direct[li] : c->w.mfma[li];
     a.bias = nullptr;
     a.out = c->raw[li]; a.out_stride = c->raw_stride[li]; a.Hout = Hout; a.Wout = Wout;
     a.part = c->part[li]; a.part_stride = c->part_stride[li];
     const bool running = c->cfg.bn_mode == XFH_BN_RUNNING_STATS;
-    if (pro == PRO_BN && !running && consumer_fold(B)) {
-        for (int j = 0; j < XFH_NUM_LAYERS; ++j)
-            if (in_stat == c->stat[j] && folds_in_consumer(j)) {
-                a.in_part = c->part[j]; a.in_part_stride = c->part_stride[j]; a.in_npart = c->npart[j];
-                a.in_count = (double)c->lh[j] * (double)c->lw[j]; a.in_stat_out = c->stat[j];
-            }
+    if (pro == PRO_B2IN) {
+        const size_t xs = (size_t)c->Hmax * c->Wmax;
+        a.pool = c->skip_pool; a.pool_stride = xs / 16; a.skip_w = c->w.skip_w; a.skip_b = c->w.skip_b;
+    }
+    if (pro == PRO_FUSE) {
+        a.r4 = c->raw[11]; a.s4 = c->raw_stride[11]; a.H4 = c->lh[11]; a.W4 = c->lw[11]; a.st4 = stat_src(c, 11, B);
+        a.r5 = c->raw[15]; a.s5 = c->raw_stride[15]; a.H5 = c->lh[15]; a.W5 = c->lw[15]; a.st5 = stat_src(c, 15, B);
     }
     int np = 0;
     hipError_t e = hipSuccess;
-    const bool bn = (pro == PRO_BN);
     switch (li) {
         case 0: e = conv_direct_launch<1, 4, 1, PRO_IN>(c, a, B, &np, li); break;
         case 1: e = conv_direct_launch<4, 8, 2, PRO_BN>(c, a, B, &np, li); break;
         case 2: e = conv_direct_launch<8, 8, 1, PRO_BN>(c, a, B, &np, li); break;
         case 3:
-            if (persistent(B)) { a.w = c->w.alt[li]; e = conv_mfma_p_launch<8, 24, 3, 2, 4, 1, 1, 16, PRO_BN, EPI_STATS>(c, a, B, &np, li); break; }
             // all nine taps of the weights in one LDS chunk (no barrier inside the K = 72 loop): 49.5 -> 46.2 us at B = 32;
-                    // the same form measured slower for the 24 -> 24 layers (95 vs 91 us).  XFH_CONV_CFG=0: one tap per chunk
-            if (conv_cfg()) { a.w = c->w.alt[li]; e = conv_mfma_launch<8, 24, 3, 2, 4, 1, 1, 16, PRO_BN, EPI_STATS, 64, 9>(c, a, B, &np, li); }
-            else e = conv_mfma_launch<8, 24, 3, 2, 4, 1, 1, 16, PRO_BN, EPI_STATS>(c, a, B, &np, li);
+            // the same form measured slower for the 24 -> 24 layers (95 vs 91 us)
+            a.w = c->w.alt[li];
+            if (persistent(B)) e = conv_mfma_p_launch<8, 24, 3, 2, 4, 1, 1, 16, PRO_BN, EPI_STATS>(c, a, B, &np, li);
+            else e = conv_mfma_launch<8, 24, 3, 2, 4, 1, 1, 16, PRO_BN, EPI_STATS, 64, 9>(c, a, B, &np, li);
             break;
-        case 4:                                                                                                 // input = b2in
-            if (persistent(B)) { a.w = c->w.alt[li]; e = conv_mfma_p_launch<24, 24, 3, 1, 4, 1, 1, 16, PRO_PLAIN, EPI_STATS>(c, a, B, &np, li); }
-            else e = conv_mfma_launch<24, 24, 3, 1, 4, 1, 1, 16, PRO_PLAIN, EPI_STATS>(c, a, B, &np, li);
+        case 4:                                                                                                 // input = relu(bn(block1.3)) + skip1(x), computed while staging
+            if (persistent(B)) { a.w = c->w.alt[li]; e = conv_mfma_p_launch<24, 24, 3, 1, 4, 1, 1, 16, PRO_B2IN, EPI_STATS>(c, a, B, &np, li); }
+            else e = conv_mfma_launch<24, 24, 3, 1, 4, 1, 1, 16, PRO_B2IN, EPI_STATS>(c, a, B, &np, li);
             break;
         case 5:
             if (persistent(B)) { a.w = c->w.alt[li]; e = conv_mfma_p_launch<24, 24, 3, 1, 4, 1, 1, 16, PRO_BN, EPI_STATS>(c, a, B, &np, li); }
             else e = conv_mfma_launch<24, 24, 3, 1, 4, 1, 1, 16, PRO_BN, EPI_STATS>(c, a, B, &np, li);
             break;
         case 6: e = conv_mfma_launch<24, 64, 3, 2, 4, 1, 2, 16, PRO_BN, EPI_STATS>(c, a, B, &np, li); break;
-        case 7: case 17: case 16: {
-            // the dominant 3x3 64->64 instance: 8x16 pixels x 64 channels per workgroup, 8 waves (4 x 2),
-            // 32-channel weight chunks (67 KB LDS -> 2 workgroups per CU); measured 70 us vs 77 us for the
-            // 4-wave / 64-channel-chunk form at B = 16 (profiles/r01_conv_cfg.log).  XFH_CONV_CFG=0 selects the latter.
-            // Single frame (40 workgroups cannot fill 256 CUs, and with one wave per SIMD the K loop waits on each of the
-            // 18 weight chunks): 2x16 pixels per workgroup, 2 waves, three taps per chunk (6 chunks).
-            const int cfg = conv_cfg();
+        case 7: case 17: case 16:
+            // the dominant 3x3 64->64 instance: 8x16 pixels x 64 channels per workgroup, 8 waves (4 x 2), 32-channel weight
+            // chunks (67 KB LDS -> 2 workgroups per CU); measured 70 us vs 77 us for the 4-wave / 64-channel-chunk form at
+            // B = 16 (profiles/r01_conv_cfg.log).  Single frame: 2x16 pixels per workgroup, 2 waves, three taps per chunk.
+            // block_fusion.0 (16) builds its input x3 + up2(x4) + up4(x5) while staging.
             if (small_batch(B)) {
                 a.w = c->w.alt2[li];
-                if (li == 16) e = conv_mfma_launch<64, 64, 3, 1, 1, 2, 1, 16, PRO_PLAIN, EPI_STATS, 64, 3>(c, a, B, &np, li);
+                if (li == 16) e = conv_mfma_launch<64, 64, 3, 1, 1, 2, 1, 16, PRO_FUSE, EPI_STATS, 64, 3>(c, a, B, &np, li);
                 else e = conv_mfma_launch<64, 64, 3, 1, 1, 2, 1, 16, PRO_BN, EPI_STATS, 64, 3>(c, a, B, &np, li);
-                break;
-            }
-            if (cfg != 0) a.w = c->w.alt[li];
-            if (li == 16) {                                                                                     // input = fuse_in
-                if (cfg != 0) e = conv_mfma_launch<64, 64, 3, 1, 4, 2, 1, 16, PRO_PLAIN, EPI_STATS, 32>(c, a, B, &np, li);
-                else e = conv_mfma_launch<64, 64, 3, 1, 4, 1, 2, 16, PRO_PLAIN, EPI_STATS>(c, a, B, &np, li);
             } else {
-                if (cfg != 0) e = conv_mfma_launch<64, 64, 3, 1, 4, 2, 1, 16, PRO_BN, EPI_STATS, 32>(c, a, B, &np, li);
-                else e = conv_mfma_launch<64, 64, 3, 1, 4, 1, 2, 16, PRO_BN, EPI_STATS>(c, a, B, &np, li);
+                a.w = c->w.alt[li];
+                if (li == 16) e = conv_mfma_launch<64, 64, 3, 1, 4, 2, 1, 16, PRO_FUSE, EPI_STATS, 32>(c, a, B, &np, li);
+                else e = conv_mfma_launch<64, 64, 3, 1, 4, 2, 1, 16, PRO_BN, EPI_STATS, 32>(c, a, B, &np, li);
             }
             break;
-        }
         case 8:
             if (persistent(B)) e = conv_mfma_p_launch<64, 64, 1, 1, 4, 1, 2, 16, PRO_BN, EPI_STATS>(c, a, B, &np, li);
             else e = conv_mfma_launch<64, 64, 1, 1, 4, 1, 2, 16, PRO_BN, EPI_STATS>(c, a, B, &np, li);
@@ -693,8 +749,8 @@ hipError_t launch_basic_layer(xfh_ctx* c, int li, const float* in, size_t in_str
             else e = conv_mfma_launch<64, 64, 3, 1, 2, 2, 1, 8, PRO_BN, EPI_STATS>(c, a, B, &np, li);
             break;
         case 12: e = conv_mfma_launch<64, 128, 3, 2, 1, 4, 1, 8, PRO_BN, EPI_STATS>(c, a, B, &np, li); break;
-        case 13: case 14:       // 32-channel weight chunks: 69 KB LDS -> 2 workgroups per CU, 58 -> 50 us at B = 32; XFH_CONV_CFG=0: 64-channel chunks
-            if (conv_cfg() && !small_batch(B)) { a.w = c->w.alt[li]; e = conv_mfma_launch<128, 128, 3, 1, 1, 4, 1, 8, PRO_BN, EPI_STATS, 32>(c, a, B, &np, li); }
+        case 13: case 14:       // 32-channel weight chunks: 69 KB LDS -> 2 workgroups per CU, 58 -> 50 us at B = 32
+            if (!small_batch(B)) { a.w = c->w.alt[li]; e = conv_mfma_launch<128, 128, 3, 1, 1, 4, 1, 8, PRO_BN, EPI_STATS, 32>(c, a, B, &np, li); }
             else e = conv_mfma_launch<128, 128, 3, 1, 1, 4, 1, 8, PRO_BN, EPI_STATS>(c, a, B, &np, li);
             break;
         case 15: e = conv_mfma_launch<128, 64, 1, 1, 1, 2, 1, 8, PRO_BN, EPI_STATS>(c, a, B, &np, li); break;
@@ -708,11 +764,9 @@ hipError_t launch_basic_layer(xfh_ctx* c, int li, const float* in, size_t in_str
             break;
         default: return hipErrorInvalidValue;
     }
-    (void)bn;
     if (e != hipSuccess) return e;
     c->npart[li] = np;
-    if (running) return hipGetLastError();                                       // statistics come from the weight file
-    if (consumer_fold(B) && folds_in_consumer(li)) return hipGetLastError();     // the consuming convolution folds the partials itself
+    if (running || consumer_fold(B)) return hipGetLastError();     // statistics from the weight file / folded by the consumers
     hipLaunchKernelGGL(k_bn_finalize, dim3(B), dim3(256), 0, c->stream, (const double*)c->part[li], c->part_stride[li], np,
                        L.cout, (double)Hout * (double)Wout, c->stat[li]);
     return hipGetLastError();
@@ -721,14 +775,10 @@ hipError_t launch_basic_layer(xfh_ctx* c, int li, const float* in, size_t in_str
 // block_fusion.2: Conv2d(64,64,1) with bias, no BN (src/XFeat.cc:75) -> feats
 hipError_t launch_fusion_out(xfh_ctx* c, int Hh, int Wh, int B) {
     ConvArgs a{};
-    a.in = c->raw[17]; a.in_stat = c->stat[17]; a.in_stride = c->raw_stride[17]; a.Hin = Hh; a.Win = Wh;
+    a.in = c->raw[17]; a.st = stat_src(c, 17, B); a.in_stride = c->raw_stride[17]; a.Hin = Hh; a.Win = Wh;
     a.w = c->w.fus2; a.bias = c->w.fus2_bias;
     a.out = c->feats; a.out_stride = c->raw_stride[17]; a.Hout = Hh; a.Wout = Wh;
     a.part = nullptr; a.part_stride = 0;
-    if (c->cfg.bn_mode != XFH_BN_RUNNING_STATS && consumer_fold(B)) {
-        a.in_part = c->part[17]; a.in_part_stride = c->part_stride[17]; a.in_npart = c->npart[17];
-        a.in_count = (double)Hh * (double)Wh; a.in_stat_out = c->stat[17];
-    }
     if (persistent(B)) return conv_mfma_p_launch<64, 64, 1, 1, 4, 1, 2, 16, PRO_BN, EPI_BIAS>(c, a, B, nullptr, 23);
     return conv_mfma_launch<64, 64, 1, 1, 4, 1, 2, 16, PRO_BN, EPI_BIAS>(c, a, B, nullptr, 23);
 }

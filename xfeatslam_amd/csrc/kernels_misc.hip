@@ -2,14 +2,14 @@
 // (reference src/XFextractor.cc:250-356) on gfx950:
 //   k_preproc      parseInput + preprocessTensor (:161-202) and InstanceNorm partial sums
 //   k_norm_aux     InstanceNorm apply, unfold2d(x,8) (XFeat.cc:124-133), AvgPool4 of skip1 (:36-39)
-//   k_b2in         x1 + skip1(x)                       (XFeat.cc:153)
-//   k_fuse_in      x3 + up(x4) + up(x5)                (XFeat.cc:159-166)
-//   k_feats_norm   F::normalize(M1, dim=1)             (XFextractor.cc:273)
+//   (x1 + skip1(x), XFeat.cc:153, and x3 + up(x4) + up(x5), :159-166, are computed by the consuming convolutions while
+//    they stage their input: kernels_conv.hip PRO_B2IN / PRO_FUSE; F::normalize(M1, dim=1), XFextractor.cc:273, is
+//    applied per bilinear tap inside k_desc)
 //   k_heads_heat   heatmap_head.2 + sigmoid; k_heads_kp: keypoint_head.3 + softmax + depth-to-space
 //                  (XFeat.cc:81-82,89; XFextractor.cc:204-217)
 //   k_nms_score    5x5 NMS, threshold, nearest*bilinear score (XFextractor.cc:219-248, 280-282)
 //   k_select       top-k by (score desc, index asc), validity, lapping placement (:285-295, 310-343)
-//   k_desc         bilinear descriptor sampling + L2 normalise + record packing (:298-301, 323-343)
+//   k_desc         F::normalize of the sampled feature pixels (:273), bilinear descriptor sampling + L2 normalise + record packing (:298-301, 323-343)
 // Compiled with -ffp-contract=off: every fused multiply-add below is written as fmaf().
 #include "ctx.h"
 #include <stdlib.h>
@@ -85,15 +85,20 @@ void k_preproc(const uint8_t* __restrict__ gray, size_t gray_stride, int H0, int
 }
 
 // ---- k_norm_aux: one thread per 4x4 pixel block -------------------------------------------
+// xs: InstanceNorm statistics of the image; for small batches every workgroup folds k_preproc's partials itself
+// (workgroup 0 publishes them for block1.0), which saves the finalize launch
 __global__ __launch_bounds__(256)
-void k_norm_aux(const float* __restrict__ X, size_t x_stride, const float* __restrict__ xstat, int H, int W,
+void k_norm_aux(const float* __restrict__ X, size_t x_stride, StatSrc xs, int H, int W,
                 float* __restrict__ xunfold, size_t xu_stride, float* __restrict__ pool, size_t pool_stride) {
+    __shared__ double red[512];
+    __shared__ float s_stat[2];
     const int b = blockIdx.z;
+    stage_stat(xs, b, 1, blockIdx.x == 0, s_stat, red, threadIdx.x, 256);
     const int q = blockIdx.x * 256 + threadIdx.x;
     const int w4 = W / 4, h4 = H / 4;
     if (q >= w4 * h4) return;
     const int by = q / w4, bx = q % w4;
-    const float m = xstat[b * 2], r = xstat[b * 2 + 1];
+    const float m = s_stat[0], r = s_stat[1];
     const float* x = X + (size_t)b * x_stride;
     float* xu = xunfold + (size_t)b * xu_stride;
     float s = 0.f;
@@ -109,78 +114,12 @@ void k_norm_aux(const float* __restrict__ X, size_t x_stride, const float* __res
     pool[(size_t)b * pool_stride + q] = s / 16.0f;
 }
 
-// ---- k_b2in: relu(bn(raw3)) + (pool * w + b), one thread per (pixel, 4 channels) ------------
-__global__ __launch_bounds__(256)
-void k_b2in(const float* __restrict__ raw3, size_t raw_stride, const float* __restrict__ stat3,
-            const float* __restrict__ pool, size_t pool_stride, const float* __restrict__ sw, const float* __restrict__ sb,
-            int npix, float* __restrict__ out, size_t out_stride) {
-    const int b = blockIdx.z;
-    const int q = blockIdx.x * 256 + threadIdx.x;
-    if (q >= npix * 6) return;
-    const int pix = q / 6, g = q % 6;
-    const float* st = stat3 + (size_t)b * 48;
-    f32x4 v = *(const f32x4*)(raw3 + (size_t)b * raw_stride + (size_t)pix * 24 + g * 4);
-    const float p = pool[(size_t)b * pool_stride + pix];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int c = g * 4 + j;
-        const float a = fmaxf((v[j] - st[c]) * st[24 + c], 0.f);
-        v[j] = a + (p * sw[c] + sb[c]);
-    }
-    *(f32x4*)(out + (size_t)b * out_stride + (size_t)pix * 24 + g * 4) = v;
-}
-
-// ---- k_fuse_in: x3 + up2(x4) + up4(x5), one thread per (pixel, 4 channels) ------------------
+// relu(bn(raw)) of 4 channels (group g) at one pixel; st: mean[C], rstd[C]
 __device__ __forceinline__ f32x4 ld_act4(const float* raw, const float* st, int C, size_t pix, int g) {
     f32x4 v = *(const f32x4*)(raw + pix * C + g * 4);
 #pragma unroll
     for (int j = 0; j < 4; ++j) v[j] = fmaxf((v[j] - st[g * 4 + j]) * st[C + g * 4 + j], 0.f);
     return v;
-}
-__device__ __forceinline__ f32x4 up_bilinear4(const float* raw, const float* st, int Hi, int Wi, int Ho, int Wo,
-                                               int y, int x, int g) {
-    int y0, y1, x0, x1; float hy0, hy1, wx0, wx1;
-    lin_coeff(Hi, Ho, y, y0, y1, hy0, hy1);
-    lin_coeff(Wi, Wo, x, x0, x1, wx0, wx1);
-    const f32x4 p00 = ld_act4(raw, st, 64, (size_t)y0 * Wi + x0, g), p01 = ld_act4(raw, st, 64, (size_t)y0 * Wi + x1, g);
-    const f32x4 p10 = ld_act4(raw, st, 64, (size_t)y1 * Wi + x0, g), p11 = ld_act4(raw, st, 64, (size_t)y1 * Wi + x1, g);
-    f32x4 o;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float top = fmaf(wx0, p00[j], wx1 * p01[j]), bot = fmaf(wx0, p10[j], wx1 * p11[j]);
-        o[j] = fmaf(hy0, top, hy1 * bot);
-    }
-    return o;
-}
-__global__ __launch_bounds__(256)
-void k_fuse_in(const float* __restrict__ r3, size_t s3, const float* __restrict__ st3,
-               const float* __restrict__ r4, size_t s4, const float* __restrict__ st4, int H4, int W4,
-               const float* __restrict__ r5, size_t s5, const float* __restrict__ st5, int H5, int W5,
-               int Hh, int Wh, float* __restrict__ out, size_t so) {
-    const int b = blockIdx.z;
-    const int q = blockIdx.x * 256 + threadIdx.x;
-    if (q >= Hh * Wh * 16) return;
-    const int pix = q >> 4, g = q & 15;
-    const int y = pix / Wh, x = pix % Wh;
-    const f32x4 a = ld_act4(r3 + (size_t)b * s3, st3 + (size_t)b * 128, 64, (size_t)pix, g);
-    const f32x4 u4 = up_bilinear4(r4 + (size_t)b * s4, st4 + (size_t)b * 128, H4, W4, Hh, Wh, y, x, g);
-    const f32x4 u5 = up_bilinear4(r5 + (size_t)b * s5, st5 + (size_t)b * 128, H5, W5, Hh, Wh, y, x, g);
-    f32x4 o;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = (a[j] + u4[j]) + u5[j];
-    *(f32x4*)(out + (size_t)b * so + (size_t)pix * 64 + g * 4) = o;
-}
-
-// ---- k_feats_norm: one wave per 1/8-res pixel, lane = channel -------------------------------
-__global__ __launch_bounds__(256)
-void k_feats_norm(const float* __restrict__ feats, size_t stride, int npix, float* __restrict__ out) {
-    const int b = blockIdx.z;
-    const int pix = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (pix >= npix) return;
-    const float v = feats[(size_t)b * stride + (size_t)pix * 64 + lane];
-    const double ss = wave_sum((double)v * (double)v);
-    const float nrm = fmaxf((float)sqrt(ss), 1e-12f);
-    out[(size_t)b * stride + (size_t)pix * 64 + lane] = v / nrm;
 }
 
 // ---- k_heads_heat / k_heads_kp: 128 pixels per workgroup, one pixel per lane -----------------------------
@@ -188,14 +127,15 @@ void k_feats_norm(const float* __restrict__ feats, size_t stride, int npix, floa
 #define HF_LD 129
 // heatmap head: 64 -> 1, sigmoid (XFeat.cc:81-82)
 __global__ __launch_bounds__(HF_PX)
-void k_heads_heat(const float* __restrict__ rawH, const float* __restrict__ statH,     // heatmap_head.1
+void k_heads_heat(const float* __restrict__ rawH, StatSrc sH,     // heatmap_head.1
                   size_t raw_stride, const float* __restrict__ wh, const float* __restrict__ bh,
                   int npix, float* __restrict__ H1, size_t h1_stride) {
     __shared__ float sA[64 * HF_LD];
+    __shared__ float st[128];
     const int t = threadIdx.x, b = blockIdx.z;
     const int p0 = blockIdx.x * HF_PX;
     const int pix = p0 + t;
-    const float* st = statH + (size_t)b * 128;
+    stage_stat(sH, b, 64, blockIdx.x == 0, st, (double*)sA, t, HF_PX);
     for (int item = t; item < HF_PX * 16; item += HF_PX) {
         const int lp = item >> 4, g = item & 15;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -214,14 +154,15 @@ void k_heads_heat(const float* __restrict__ rawH, const float* __restrict__ stat
 // Runs on the ctx's second stream together with keypoint_head.0-2: the whole branch only depends on the
 // normalised image, not on the backbone.
 __global__ __launch_bounds__(HF_PX)
-void k_heads_kp(const float* __restrict__ rawK, const float* __restrict__ statK,      // keypoint_head.2
+void k_heads_kp(const float* __restrict__ rawK, StatSrc sK,      // keypoint_head.2
                 size_t raw_stride, const float* __restrict__ wk /* [64][68] */, const float* __restrict__ bk /* [65] */,
                 int Hh, int Wh, float* __restrict__ K1h, size_t k1h_stride) {
     __shared__ float sA[64 * HF_LD];
+    __shared__ float st[128];
     const int t = threadIdx.x, b = blockIdx.z;
     const int npix = Hh * Wh, p0 = blockIdx.x * HF_PX;
     const int pix = p0 + t;
-    const float* st = statK + (size_t)b * 128;
+    stage_stat(sK, b, 64, blockIdx.x == 0, st, (double*)sA, t, HF_PX);
     for (int item = t; item < HF_PX * 16; item += HF_PX) {
         const int lp = item >> 4, g = item & 15;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -612,7 +553,7 @@ void k_select(const u64* __restrict__ cand, size_t cand_cap, const int* __restri
 
 // ---- k_desc: one wave per output slot, lane = descriptor channel ---------------------------------
 __global__ __launch_bounds__(256)
-void k_desc(const float* __restrict__ m1n, size_t m_stride, const int* __restrict__ slot_src, const u64* __restrict__ sel_key,
+void k_desc(const float* __restrict__ feats, size_t m_stride, const int* __restrict__ slot_src, const u64* __restrict__ sel_key,
             int H, int W, int nfeatures, float rw, float rh, uint8_t* __restrict__ records, size_t rec_bytes, size_t kps_off, size_t desc_off, int write_padding) {
     const int b = blockIdx.z;
     const int slot = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -640,11 +581,22 @@ void k_desc(const float* __restrict__ m1n, size_t m_stride, const int* __restric
     const float nw = e * so, ne = w * so, sw = e * n, se = w * n;
     const int x0 = (int)xw, y0 = (int)yn, x1 = x0 + 1, y1 = y0 + 1;
     const bool vx0 = x0 >= 0 && x0 < Wh, vx1 = x1 >= 0 && x1 < Wh, vy0 = y0 >= 0 && y0 < Hh, vy1 = y1 >= 0 && y1 < Hh;
-    const float* m = m1n + (size_t)b * m_stride;
-    const float a = (vx0 && vy0) ? m[((size_t)y0 * Wh + x0) * 64 + lane] : 0.f;
-    const float bb = (vx1 && vy0) ? m[((size_t)y0 * Wh + x1) * 64 + lane] : 0.f;
-    const float d = (vx0 && vy1) ? m[((size_t)y1 * Wh + x0) * 64 + lane] : 0.f;
-    const float g = (vx1 && vy1) ? m[((size_t)y1 * Wh + x1) * 64 + lane] : 0.f;
+    // F::normalize(M1, dim=1) (XFextractor.cc:273) of the four feature pixels the sample touches: fp64 sum of squares over
+    // the 64 channels (lane = channel), fp32 sqrt / max(., 1e-12) / divide -- the same values a normalised copy would hold.
+    // The four sums are reduced together: a reduce-scatter over lane bits 5 and 4 leaves tap (lane >> 4) in each 16-lane
+    // group, four butterfly steps finish it (7 fp64 exchanges instead of 24), and the four norms are broadcast back.
+    const float* m = feats + (size_t)b * m_stride;
+    const float r0 = (vx0 && vy0) ? m[((size_t)y0 * Wh + x0) * 64 + lane] : 0.f, r1 = (vx1 && vy0) ? m[((size_t)y0 * Wh + x1) * 64 + lane] : 0.f;
+    const float r2 = (vx0 && vy1) ? m[((size_t)y1 * Wh + x0) * 64 + lane] : 0.f, r3 = (vx1 && vy1) ? m[((size_t)y1 * Wh + x1) * 64 + lane] : 0.f;
+    const double s0 = (double)r0 * (double)r0, s1 = (double)r1 * (double)r1, s2 = (double)r2 * (double)r2, s3 = (double)r3 * (double)r3;
+    const bool hi = lane & 32, b4 = lane & 16;
+    double kA = hi ? s2 : s0, kB = hi ? s3 : s1;
+    kA += __shfl_xor(hi ? s0 : s2, 32); kB += __shfl_xor(hi ? s1 : s3, 32);
+    double sst = b4 ? kB : kA;
+    sst += __shfl_xor(b4 ? kA : kB, 16);
+    sst += __shfl_xor(sst, 8); sst += __shfl_xor(sst, 4); sst += __shfl_xor(sst, 2); sst += __shfl_xor(sst, 1);
+    const float nrm_t = fmaxf((float)sqrt(sst), 1e-12f);          // of tap lane >> 4
+    const float a = r0 / __shfl(nrm_t, 0), bb = r1 / __shfl(nrm_t, 16), d = r2 / __shfl(nrm_t, 32), g = r3 / __shfl(nrm_t, 48);
     const float v = ((a * nw + bb * ne) + d * sw) + g * se;
     const double ss = wave_sum((double)v * (double)v);
     const float nrm = fmaxf((float)sqrt(ss), 1e-12f);
@@ -660,13 +612,14 @@ void k_desc(const float* __restrict__ m1n, size_t m_stride, const int* __restric
 
 // ---------------------------------------------------------------------------------------------
 // pipeline
-hipError_t launch_basic_layer(xfh_ctx* c, int li, const float* in, size_t in_stride, const float* in_stat,
-                              int pro, int Hin, int Win, int B);
+hipError_t launch_basic_layer(xfh_ctx* c, int li, const float* in, size_t in_stride, int src, int pro, int Hin, int Win, int B);
 hipError_t launch_fusion_out(xfh_ctx* c, int Hh, int Wh, int B);
 hipError_t launch_finalize_image(xfh_ctx* c, int B, int npart, double count);
+StatSrc stat_src(xfh_ctx* c, int j, int B);
+bool consumer_fold(int B);
 
 #define CK(x) do { hipError_t _e = (x); if (_e != hipSuccess) return _e; } while (0)
-enum { PRO_PLAIN = 0, PRO_BN = 1, PRO_IN = 2 };
+enum { PRO_PLAIN = 0, PRO_BN = 1, PRO_IN = 2, PRO_B2IN = 3, PRO_FUSE = 4 };
 
 hipError_t run_extract(xfh_ctx* c, const uint8_t* d_gray, int B, int H0, int W0, int lap0, int lap1, uint8_t* d_records, bool write_padding) {
     const int H = (H0 / 32) * 32, W = (W0 / 32) * 32;
@@ -683,74 +636,72 @@ hipError_t run_extract(xfh_ctx* c, const uint8_t* d_gray, int B, int H0, int W0,
     const int npre = (H * W + 1023) / 1024;
     launch_k(c, XFH_K_PREPROC, -1, k_preproc, dim3(npre, 1, B), dim3(256), 0, d_gray, (size_t)H0 * W0, H0, W0, H, W, c->X, xs, c->pre_part, c->pre_npart, c->cand_count);
     CK(hipGetLastError());
-    CK(launch_finalize_image(c, B, npre, (double)H * (double)W));
-    hipLaunchKernelGGL(k_norm_aux, dim3((h4 * w4 + 255) / 256, 1, B), dim3(256), 0, s, c->X, xs, c->xstat, H, W,
-                       c->xunfold, xs, c->skip_pool, xs / 16);
+    StatSrc xsrc{};
+    xsrc.stat = c->xstat;
+    if (consumer_fold(B)) { xsrc.part = c->pre_part; xsrc.part_stride = (size_t)c->pre_npart * 2; xsrc.npart = npre; xsrc.count = (double)H * (double)W; xsrc.stat_out = c->xstat; }
+    else CK(launch_finalize_image(c, B, npre, (double)H * (double)W));
+    hipLaunchKernelGGL(k_norm_aux, dim3((h4 * w4 + 255) / 256, 1, B), dim3(256), 0, s, c->X, xs, xsrc, H, W, c->xunfold, xs, c->skip_pool, xs / 16);
     CK(hipGetLastError());
-    bool use_aux = true;
     // keypoint branch (keypoint_head.0-3 on unfold2d(x), softmax, depth-to-space) on the second stream: it only needs
     // the normalised image, so it runs beside the backbone (memory-bound 1x1 layers next to MFMA-bound 3x3 layers)
     {
-        static int two = -1;
-        if (two < 0) { const char* e = getenv("XFH_AUX_STREAM"); two = e ? atoi(e) : 1; }
-        use_aux = two != 0;
-        if (use_aux) {
-            CK(hipEventRecord(c->ev_fork, s));
-            CK(hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
-            c->stream = c->aux_stream;
-        }
-        hipError_t e = launch_basic_layer(c, 20, c->xunfold, xs, nullptr, PRO_PLAIN, h8, w8, B);
-        if (e == hipSuccess) e = launch_basic_layer(c, 21, c->raw[20], c->raw_stride[20], c->stat[20], PRO_BN, h8, w8, B);
-        if (e == hipSuccess) e = launch_basic_layer(c, 22, c->raw[21], c->raw_stride[21], c->stat[21], PRO_BN, h8, w8, B);
+        const bool two = !(c->cfg.flags & XFH_FLAG_SERIAL_BRANCH);
+        hipStream_t branch = two ? c->aux_stream : s;
+        hipError_t e = hipEventRecord(c->ev_fork, s);
+        if (e == hipSuccess) e = hipStreamWaitEvent(branch, c->ev_fork, 0);
+        CK(e);
+        c->stream = branch;
+        e = launch_basic_layer(c, 20, c->xunfold, xs, -1, PRO_PLAIN, h8, w8, B);
+        if (e == hipSuccess) e = launch_basic_layer(c, 21, c->raw[20], c->raw_stride[20], 20, PRO_BN, h8, w8, B);
+        if (e == hipSuccess) e = launch_basic_layer(c, 22, c->raw[21], c->raw_stride[21], 21, PRO_BN, h8, w8, B);
         if (e == hipSuccess) {
             launch_k(c, XFH_K_HEADS, -1, k_heads_kp, dim3((h8 * w8 + HF_PX - 1) / HF_PX, 1, B), dim3(HF_PX), 0,
-                     (const float*)c->raw[22], (const float*)c->stat[22], c->raw_stride[22], (const float*)c->w.kp3_w, (const float*)c->w.kp3_b, h8, w8, c->K1h, xs);
+                     (const float*)c->raw[22], stat_src(c, 22, B), c->raw_stride[22], (const float*)c->w.kp3_w, (const float*)c->w.kp3_b, h8, w8, c->K1h, xs);
             e = hipGetLastError();
         }
         c->stream = s;
-        CK(e);
-        if (use_aux) CK(hipEventRecord(c->ev_join, c->aux_stream));
+        // the fork is always joined, also on an error path: the main stream must not run ahead of (or be destroyed before) the branch
+        const hipError_t e2 = hipEventRecord(c->ev_join, branch);
+        if (e != hipSuccess || e2 != hipSuccess) { hipStreamSynchronize(branch); return e != hipSuccess ? e : e2; }
     }
+    // backbone + heatmap head on the main stream; whatever happens, the branch is joined afterwards (K1h is needed by the NMS,
+    // and the main stream must never run ahead of, or be destroyed before, the second stream)
+    auto backbone = [&]() -> hipError_t {
     // block1
-    CK(launch_basic_layer(c, 0, c->X, xs, c->xstat, PRO_IN, H, W, B));
-    CK(launch_basic_layer(c, 1, c->raw[0], c->raw_stride[0], c->stat[0], PRO_BN, c->lh[0], c->lw[0], B));
-    CK(launch_basic_layer(c, 2, c->raw[1], c->raw_stride[1], c->stat[1], PRO_BN, c->lh[1], c->lw[1], B));
-    CK(launch_basic_layer(c, 3, c->raw[2], c->raw_stride[2], c->stat[2], PRO_BN, c->lh[2], c->lw[2], B));
-    // x1 + skip1(x)
-    hipLaunchKernelGGL(k_b2in, dim3((h4 * w4 * 6 + 255) / 256, 1, B), dim3(256), 0, s, c->raw[3], c->raw_stride[3], c->stat[3],
-                       c->skip_pool, xs / 16, c->w.skip_w, c->w.skip_b, h4 * w4, c->b2in, c->raw_stride[3]);
-    CK(hipGetLastError());
-    // block2, block3
-    CK(launch_basic_layer(c, 4, c->b2in, c->raw_stride[3], nullptr, PRO_PLAIN, h4, w4, B));
-    CK(launch_basic_layer(c, 5, c->raw[4], c->raw_stride[4], c->stat[4], PRO_BN, h4, w4, B));
-    CK(launch_basic_layer(c, 6, c->raw[5], c->raw_stride[5], c->stat[5], PRO_BN, h4, w4, B));
-    CK(launch_basic_layer(c, 7, c->raw[6], c->raw_stride[6], c->stat[6], PRO_BN, h8, w8, B));
-    CK(launch_basic_layer(c, 8, c->raw[7], c->raw_stride[7], c->stat[7], PRO_BN, h8, w8, B));
+    CK(launch_basic_layer(c, 0, c->X, xs, -2, PRO_IN, H, W, B));
+    CK(launch_basic_layer(c, 1, c->raw[0], c->raw_stride[0], 0, PRO_BN, c->lh[0], c->lw[0], B));
+    CK(launch_basic_layer(c, 2, c->raw[1], c->raw_stride[1], 1, PRO_BN, c->lh[1], c->lw[1], B));
+    CK(launch_basic_layer(c, 3, c->raw[2], c->raw_stride[2], 2, PRO_BN, c->lh[2], c->lw[2], B));
+    // block2 (block2.0 adds skip1(x) to x1 while staging), block3
+    CK(launch_basic_layer(c, 4, c->raw[3], c->raw_stride[3], 3, PRO_B2IN, h4, w4, B));
+    CK(launch_basic_layer(c, 5, c->raw[4], c->raw_stride[4], 4, PRO_BN, h4, w4, B));
+    CK(launch_basic_layer(c, 6, c->raw[5], c->raw_stride[5], 5, PRO_BN, h4, w4, B));
+    CK(launch_basic_layer(c, 7, c->raw[6], c->raw_stride[6], 6, PRO_BN, h8, w8, B));
+    CK(launch_basic_layer(c, 8, c->raw[7], c->raw_stride[7], 7, PRO_BN, h8, w8, B));
     // block4, block5
-    CK(launch_basic_layer(c, 9, c->raw[8], c->raw_stride[8], c->stat[8], PRO_BN, h8, w8, B));
-    CK(launch_basic_layer(c, 10, c->raw[9], c->raw_stride[9], c->stat[9], PRO_BN, c->lh[9], c->lw[9], B));
-    CK(launch_basic_layer(c, 11, c->raw[10], c->raw_stride[10], c->stat[10], PRO_BN, c->lh[10], c->lw[10], B));
-    CK(launch_basic_layer(c, 12, c->raw[11], c->raw_stride[11], c->stat[11], PRO_BN, c->lh[11], c->lw[11], B));
-    CK(launch_basic_layer(c, 13, c->raw[12], c->raw_stride[12], c->stat[12], PRO_BN, c->lh[12], c->lw[12], B));
-    CK(launch_basic_layer(c, 14, c->raw[13], c->raw_stride[13], c->stat[13], PRO_BN, c->lh[13], c->lw[13], B));
-    CK(launch_basic_layer(c, 15, c->raw[14], c->raw_stride[14], c->stat[14], PRO_BN, c->lh[14], c->lw[14], B));
-    // pyramid fusion input
-    hipLaunchKernelGGL(k_fuse_in, dim3((h8 * w8 * 16 + 255) / 256, 1, B), dim3(256), 0, s,
-                       c->raw[8], c->raw_stride[8], c->stat[8], c->raw[11], c->raw_stride[11], c->stat[11], c->lh[11], c->lw[11],
-                       c->raw[15], c->raw_stride[15], c->stat[15], c->lh[15], c->lw[15], h8, w8, c->fuse_in, c->raw_stride[8]);
-    CK(hipGetLastError());
-    CK(launch_basic_layer(c, 16, c->fuse_in, c->raw_stride[8], nullptr, PRO_PLAIN, h8, w8, B));
-    CK(launch_basic_layer(c, 17, c->raw[16], c->raw_stride[16], c->stat[16], PRO_BN, h8, w8, B));
+    CK(launch_basic_layer(c, 9, c->raw[8], c->raw_stride[8], 8, PRO_BN, h8, w8, B));
+    CK(launch_basic_layer(c, 10, c->raw[9], c->raw_stride[9], 9, PRO_BN, c->lh[9], c->lw[9], B));
+    CK(launch_basic_layer(c, 11, c->raw[10], c->raw_stride[10], 10, PRO_BN, c->lh[10], c->lw[10], B));
+    CK(launch_basic_layer(c, 12, c->raw[11], c->raw_stride[11], 11, PRO_BN, c->lh[11], c->lw[11], B));
+    CK(launch_basic_layer(c, 13, c->raw[12], c->raw_stride[12], 12, PRO_BN, c->lh[12], c->lw[12], B));
+    CK(launch_basic_layer(c, 14, c->raw[13], c->raw_stride[13], 13, PRO_BN, c->lh[13], c->lw[13], B));
+    CK(launch_basic_layer(c, 15, c->raw[14], c->raw_stride[14], 14, PRO_BN, c->lh[14], c->lw[14], B));
+    // pyramid fusion: block_fusion.0 builds x3 + up2(x4) + up4(x5) while staging
+    CK(launch_basic_layer(c, 16, c->raw[8], c->raw_stride[8], 8, PRO_FUSE, h8, w8, B));
+    CK(launch_basic_layer(c, 17, c->raw[16], c->raw_stride[16], 16, PRO_BN, h8, w8, B));
     CK(launch_fusion_out(c, h8, w8, B));
-    hipLaunchKernelGGL(k_feats_norm, dim3((h8 * w8 + 3) / 4, 1, B), dim3(256), 0, s, c->feats, c->raw_stride[17], h8 * w8, c->m1n);
-    CK(hipGetLastError());
     // heatmap head
-    CK(launch_basic_layer(c, 18, c->feats, c->raw_stride[17], nullptr, PRO_PLAIN, h8, w8, B));
-    CK(launch_basic_layer(c, 19, c->raw[18], c->raw_stride[18], c->stat[18], PRO_BN, h8, w8, B));
+    CK(launch_basic_layer(c, 18, c->feats, c->raw_stride[17], -1, PRO_PLAIN, h8, w8, B));
+    CK(launch_basic_layer(c, 19, c->raw[18], c->raw_stride[18], 18, PRO_BN, h8, w8, B));
     hipLaunchKernelGGL(k_heads_heat, dim3((h8 * w8 + HF_PX - 1) / HF_PX, 1, B), dim3(HF_PX), 0, s,
-                       (const float*)c->raw[19], (const float*)c->stat[19], c->raw_stride[19], (const float*)c->w.heat2_w, (const float*)c->w.heat2_b, h8 * w8, c->H1, xs / 64);
-    CK(hipGetLastError());
-    if (use_aux) CK(hipStreamWaitEvent(s, c->ev_join, 0));          // K1h of the keypoint branch
+                       (const float*)c->raw[19], stat_src(c, 19, B), c->raw_stride[19], (const float*)c->w.heat2_w, (const float*)c->w.heat2_b, h8 * w8, c->H1, xs / 64);
+    return hipGetLastError();
+    };
+    {
+        const hipError_t eb = backbone();
+        const hipError_t ej = hipStreamWaitEvent(s, c->ev_join, 0);          // K1h of the keypoint branch
+        CK(eb); CK(ej);
+    }
     // NMS + score, top-k + placement, descriptors
     launch_k(c, XFH_K_NMS, -1, k_nms_score, dim3(((W + NMS_TW - 1) / NMS_TW) * ((H + NMS_TH - 1) / NMS_TH), 1, B), dim3(256), 0, c->K1h, xs, c->H1, xs / 64,
                        H, W, c->cfg.nms_threshold, c->cand, c->cand_cap, c->cand_count);
@@ -765,7 +716,7 @@ hipError_t run_extract(xfh_ctx* c, const uint8_t* d_gray, int B, int H0, int W0,
                  lap0, lap1, rw, c->slot_src, c->sel_key, c->sel_n, d_records, rec);
     }
     CK(hipGetLastError());
-    launch_k(c, XFH_K_DESC, -1, k_desc, dim3((nf + 3) / 4, 1, B), dim3(256), 0, c->m1n, c->raw_stride[17], c->slot_src, c->sel_key, H, W, nf, rw, rh,
+    launch_k(c, XFH_K_DESC, -1, k_desc, dim3((nf + 3) / 4, 1, B), dim3(256), 0, c->feats, c->raw_stride[17], c->slot_src, c->sel_key, H, W, nf, rw, rh,
                        d_records, rec, xfh_record_kps_offset(), xfh_record_desc_offset(nf), write_padding ? 1 : 0);
     return hipGetLastError();
 }
