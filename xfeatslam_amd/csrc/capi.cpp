@@ -137,12 +137,8 @@ int xfh_create(const xfh_config* cfg, xfh_ctx** out) {
         if (hipHostMalloc((void**)&c->s_hgray[k], (size_t)cfg->max_height * cfg->max_width, hipHostMallocDefault) != hipSuccess) return fail(XFH_ERR_OUT_OF_MEMORY);
         if (hipHostMalloc((void**)&c->s_hrec[k], rec, hipHostMallocDefault) != hipSuccess) return fail(XFH_ERR_OUT_OF_MEMORY);
     }
-    c->s_drec[0] = c->d_records;
-    for (int k = 1; k < xfh_ctx::SLOTS; ++k) A(c->s_drec[k], rec);
     for (int k = 0; k < xfh_ctx::SLOTS; ++k)
-        if (hipEventCreateWithFlags(&c->s_done[k], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->s_h2d[k], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&c->s_comp[k], hipEventDisableTiming) != hipSuccess) return fail(XFH_ERR_HIP);
-    if (hipStreamCreateWithFlags(&c->h2d_stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&c->d2h_stream, hipStreamNonBlocking) != hipSuccess) return fail(XFH_ERR_HIP);
+        if (hipEventCreateWithFlags(&c->s_done[k], hipEventDisableTiming) != hipSuccess) return fail(XFH_ERR_HIP);
 #undef A
     (void)rc;
     // matcher workspace for frame-against-frame calls and the pinned output mirror of xfh_match_mnn: no allocation on the call path
@@ -164,23 +160,25 @@ int xfh_create(const xfh_config* cfg, xfh_ctx** out) {
 int xfh_destroy(xfh_ctx* c) {
     if (!c) return XFH_OK;
     hipSetDevice(c->cfg.device);
+    if (c->twin) { xfh_destroy(c->twin); c->twin = nullptr; }
     xfh_comm_destroy(c);
     if (c->stream && c->stream != c->own_stream) hipStreamSynchronize(c->stream);     // work queued on a caller's stream
     if (c->own_stream) hipStreamSynchronize(c->own_stream);
     if (c->aux_stream) hipStreamSynchronize(c->aux_stream);
     auto F = [](void* p) { if (p) hipFree(p); };
     F(c->d_gray); F(c->X); F(c->pre_part); F(c->xstat);
-    for (int i = 0; i < XFH_NUM_LAYERS; ++i) { F(c->raw[i]); F(c->part[i]); F(c->stat[i]); F(c->w.mfma[i]); F(c->w.alt[i]); F(c->w.alt2[i]); }
-    for (int i = 0; i < 3; ++i) F(c->w.direct[i]);
-    F(c->w.fus2); F(c->w.fus2_bias); F(c->w.skip_w); F(c->w.skip_b); F(c->w.heat2_w); F(c->w.heat2_b); F(c->w.kp3_w); F(c->w.kp3_b);
+    for (int i = 0; i < XFH_NUM_LAYERS; ++i) { F(c->raw[i]); F(c->part[i]); F(c->stat[i]); }
+    if (!c->is_twin) {                                   // a twin borrows the weights of its parent
+        for (int i = 0; i < XFH_NUM_LAYERS; ++i) { F(c->w.mfma[i]); F(c->w.alt[i]); F(c->w.alt2[i]); }
+        for (int i = 0; i < 3; ++i) F(c->w.direct[i]);
+        F(c->w.fus2); F(c->w.fus2_bias); F(c->w.skip_w); F(c->w.skip_b); F(c->w.heat2_w); F(c->w.heat2_b); F(c->w.kp3_w); F(c->w.kp3_b);
+    }
     F(c->skip_pool); F(c->xunfold); F(c->feats); F(c->H1); F(c->K1h);
     F(c->cand); F(c->cand_count); F(c->slot_src); F(c->sel_key); F(c->sel_n); F(c->d_records);
     if (c->h_records) hipHostFree(c->h_records);
     if (c->h_gray) hipHostFree(c->h_gray);
-    if (c->h2d_stream) { hipStreamSynchronize(c->h2d_stream); hipStreamDestroy(c->h2d_stream); }
-    if (c->d2h_stream) { hipStreamSynchronize(c->d2h_stream); hipStreamDestroy(c->d2h_stream); }
-    for (int k = 1; k < xfh_ctx::SLOTS; ++k) { F(c->s_dgray[k]); F(c->s_drec[k]); if (c->s_hgray[k]) hipHostFree(c->s_hgray[k]); if (c->s_hrec[k]) hipHostFree(c->s_hrec[k]); }
-    for (int k = 0; k < xfh_ctx::SLOTS; ++k) { if (c->s_done[k]) hipEventDestroy(c->s_done[k]); if (c->s_h2d[k]) hipEventDestroy(c->s_h2d[k]); if (c->s_comp[k]) hipEventDestroy(c->s_comp[k]); }
+    for (int k = 1; k < xfh_ctx::SLOTS; ++k) { F(c->s_dgray[k]); if (c->s_hgray[k]) hipHostFree(c->s_hgray[k]); if (c->s_hrec[k]) hipHostFree(c->s_hrec[k]); }
+    for (int k = 0; k < xfh_ctx::SLOTS; ++k) if (c->s_done[k]) hipEventDestroy(c->s_done[k]);
     MatchWs& w = c->mws;
     F(w.img1); F(w.keys); F(w.b2_buf); F(w.h_d1); F(w.o_buf); F(w.o_tab);
     if (w.h_out) hipHostFree(w.h_out);
@@ -242,6 +240,8 @@ static std::vector<float> pack_mfma(const float* w, int cout, int cin, int ks, i
         }
     return o;
 }
+
+static void twin_share_weights(xfh_ctx* c);
 
 int xfh_load_weights(xfh_ctx* c, const void* blob, size_t nbytes) {
     if (!c || !blob) return XFH_ERR_INVALID_ARG;
@@ -307,6 +307,7 @@ int xfh_load_weights(xfh_ctx* c, const void* blob, size_t nbytes) {
     if (!blob_find(blob, nbytes, "keypoint_head.3.bias", &e) || e.dims[0] != 65) return XFH_ERR_BAD_WEIGHTS;
     if ((rc = upload(c, &c->w.kp3_b, std::vector<float>(e.p, e.p + 65))) != XFH_OK) return rc;
     c->w.loaded = true;
+    if (c->twin) { HIPCK(c, hipStreamSynchronize(c->twin->stream)); twin_share_weights(c); }
     return XFH_OK;
 }
 
@@ -357,6 +358,27 @@ int xfh_extract_batch(xfh_ctx* c, const uint8_t* gray, int B, int H, int W, int 
     return XFH_OK;
 }
 
+// second single-frame ctx of the submission ring (ctx.h): same configuration with max_batch 1, the parent's weights
+static void twin_share_weights(xfh_ctx* c) {
+    xfh_ctx* t = c->twin;
+    t->w = c->w;
+    if (c->cfg.bn_mode == XFH_BN_RUNNING_STATS && c->w.loaded)
+        for (int i = 0; i < XFH_NUM_LAYERS; ++i)
+            hipMemcpy(t->stat[i], c->stat[i], sizeof(float) * 2 * XFH_LAYERS[i].cout, hipMemcpyDeviceToDevice);
+}
+static int twin_ready(xfh_ctx* c) {
+    if (c->twin) return XFH_OK;
+    xfh_config cfg = c->cfg;
+    cfg.max_batch = 1;
+    xfh_ctx* t = nullptr;
+    const int rc = xfh_create(&cfg, &t);
+    if (rc != XFH_OK) return rc;
+    t->is_twin = true;
+    c->twin = t;
+    twin_share_weights(c);
+    return XFH_OK;
+}
+
 // xfh_extract = submit + collect.  The split form lets the caller overlap its own work (the other camera of a stereo
 // rig on a second ctx, tracking of the previous frame, or simply the next frame: up to XFH_SLOTS submissions may be
 // outstanding, collected in order) with the GPU.  The record is written by the kernels straight into
@@ -372,22 +394,15 @@ int xfh_extract_submit(xfh_ctx* c, const uint8_t* gray, int H, int W, int stride
     uint8_t* hg = c->s_hgray[k];
     if (stride == W) memcpy(hg, gray, (size_t)H * W);
     else for (int y = 0; y < H; ++y) memcpy(hg + (size_t)y * W, gray + (size_t)y * stride, (size_t)W);
-    const bool zero_copy = c->s_count == 0;                 // nothing in flight: latency counts, see ctx.h
-    c->s_zero_copy[k] = zero_copy;
-    if (zero_copy) {
-        HIPCK(c, hipMemcpyAsync(c->s_dgray[k], hg, (size_t)H * W, hipMemcpyHostToDevice, c->stream));
-        HIPCK(c, run_extract(c, c->s_dgray[k], 1, H, W, lap0, lap1, c->s_hrec[k], false));
-        HIPCK(c, hipEventRecord(c->s_done[k], c->stream));
-    } else {
-        HIPCK(c, hipMemcpyAsync(c->s_dgray[k], hg, (size_t)H * W, hipMemcpyHostToDevice, c->h2d_stream));
-        HIPCK(c, hipEventRecord(c->s_h2d[k], c->h2d_stream));
-        HIPCK(c, hipStreamWaitEvent(c->stream, c->s_h2d[k], 0));
-        HIPCK(c, run_extract(c, c->s_dgray[k], 1, H, W, lap0, lap1, c->s_drec[k], false));
-        HIPCK(c, hipEventRecord(c->s_comp[k], c->stream));
-        HIPCK(c, hipStreamWaitEvent(c->d2h_stream, c->s_comp[k], 0));
-        HIPCK(c, hipMemcpyAsync(c->s_hrec[k], c->s_drec[k], xfh_record_bytes(c->cfg.nfeatures), hipMemcpyDeviceToHost, c->d2h_stream));
-        HIPCK(c, hipEventRecord(c->s_done[k], c->d2h_stream));
+    xfh_ctx* run = c;
+    if (k != 0) {                                            // slot 1 executes on the twin, beside slot 0
+        rc = twin_ready(c);
+        if (rc != XFH_OK) return rc;
+        run = c->twin;
     }
+    HIPCK(c, hipMemcpyAsync(c->s_dgray[k], hg, (size_t)H * W, hipMemcpyHostToDevice, run->stream));
+    HIPCK(c, run_extract(run, c->s_dgray[k], 1, H, W, lap0, lap1, c->s_hrec[k], false));
+    HIPCK(c, hipEventRecord(c->s_done[k], run->stream));
     ++c->s_count;
     return XFH_OK;
 }
@@ -639,6 +654,7 @@ int xfh_distinctive_csr(xfh_ctx* c, const float* table, int n_rows, const int* o
 int xfh_synchronize(xfh_ctx* c) {
     if (!c) return XFH_ERR_INVALID_ARG;
     HIPCK(c, hipStreamSynchronize(c->stream));
+    if (c->twin) HIPCK(c, hipStreamSynchronize(c->twin->stream));
     return XFH_OK;
 }
 int xfh_set_stream(xfh_ctx* c, void* s) {

@@ -2,6 +2,7 @@
 #pragma once
 #include "common.h"
 #include <hip/hip_ext.h>
+#include <atomic>
 #include <string>
 
 // packed device weights
@@ -57,17 +58,16 @@ struct xfh_ctx {
     uint8_t* h_records = nullptr;               // pinned mirror, [B][record_bytes]
     uint8_t* h_gray = nullptr;                  // pinned, [B] frames
 
-    // xfh_extract_submit / _collect: a ring of XFH_SLOTS single-frame submissions.  Slot buffers: pinned image, device
-    // image, device record and pinned record.  With nothing else in flight (the blocking xfh_extract) the
-    // kernels write the pinned record DIRECTLY (host memory is device visible: no D2H command, the stores cross PCIe while
-    // k_desc runs: lowest latency); with a frame already in flight the three stages run on three streams (H2D | kernels |
-    // D2H) so that copies of one frame overlap the kernels of the other.  Slot 0 shares the batch buffers above.
+    // xfh_extract_submit / _collect: a ring of SLOTS single-frame submissions, collected in order.  Slot buffers: pinned
+    // image, device image, and a pinned record that the kernels write DIRECTLY (host memory is device visible: no D2H
+    // command, the stores cross PCIe while k_desc runs).  Slot 0 runs on this ctx; slot 1 runs on `twin`, a second
+    // single-frame ctx (own activations, own streams, shared weights; created at the first overlapping submit), so two
+    // frames in flight really execute side by side -- one frame's 40-workgroup kernels leave most of the 256 CUs idle.
     static const int SLOTS = 2;
     uint8_t* s_hgray[SLOTS] = {}; uint8_t* s_dgray[SLOTS] = {}; uint8_t* s_hrec[SLOTS] = {};
-    uint8_t* s_drec[SLOTS] = {};                // device record of the slot (pipelined form: copied out on the D2H stream)
-    bool s_zero_copy[SLOTS] = {};               // the kernels of this submission wrote the pinned record directly
-    hipEvent_t s_done[SLOTS] = {}, s_h2d[SLOTS] = {}, s_comp[SLOTS] = {};
-    hipStream_t h2d_stream = nullptr, d2h_stream = nullptr;
+    hipEvent_t s_done[SLOTS] = {};
+    xfh_ctx* twin = nullptr;
+    bool is_twin = false;                       // a twin does not own its weights
     int s_head = 0, s_count = 0;                // oldest outstanding slot, number outstanding
 
     MatchWs mws;
@@ -91,12 +91,12 @@ inline void launch_k(xfh_ctx* c, int kernel_id, int layer, K kern, dim3 grid, di
 // (one 64-bit mask per call site; device ids < 64)
 #define XFH_SET_LDS_ATTR_ONCE(c, kern, bytes)                                                                   \
     do {                                                                                                       \
-        static unsigned long long done_mask_ = 0ull;                                                           \
+        static std::atomic<unsigned long long> done_mask_{0ull};   /* several ctx may be driven from several threads */ \
         const unsigned long long bit_ = 1ull << ((c)->cfg.device & 63);                                        \
-        if (!(done_mask_ & bit_)) {                                                                            \
+        if (!(done_mask_.load(std::memory_order_acquire) & bit_)) {                                            \
             hipError_t e_ = hipFuncSetAttribute((const void*)(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
             if (e_ != hipSuccess) return e_;                                                                   \
-            done_mask_ |= bit_;                                                                                \
+            done_mask_.fetch_or(bit_, std::memory_order_release);                                              \
         }                                                                                                      \
     } while (0)
 

@@ -497,11 +497,13 @@ void k_select(const u64* __restrict__ cand, size_t cand_cap, const int* __restri
         place_sorted<4>(key, t, b, N, W, nfeatures, lap0, lap1, rw, slot_src, sel_key, sel_n, records, rec_bytes, n_cand, wsumF, wsumB);
         return;
     }
-    // ---- more than 4096 candidates: radix select down to N, then the 4-per-thread sort -----------
+    // ---- more than 4096 candidates: radix select (8-bit digits from the top) until the keys at or below the current prefix
+    // fit the 4-per-thread sort (<= 4096), which then orders them exactly and the first N are taken.  Typically two
+    // passes: the keys that share the top 16 bits of the N-th score are few.
     int shift = 64;
     u64 prefix = 0;
     {
-        int need = N;
+        int need = N;                                    // keys still to take among those that match the prefix
         for (int pass = 0; pass < 8; ++pass) {
             const int sh = 56 - 8 * pass;
             for (int e = t; e < 256; e += 1024) hist[e] = 0;
@@ -523,7 +525,8 @@ void k_select(const u64* __restrict__ cand, size_t cand_cap, const int* __restri
                     if (cum + h0 < need) { cum += h0; dg = lane * 4 + 1; hv = h1;
                         if (cum + h1 < need) { cum += h1; dg = lane * 4 + 2; hv = h2;
                             if (cum + h2 < need) { cum += h2; dg = lane * 4 + 3; hv = h3; } } }
-                    s_digit = dg; s_need = need - cum; s_done = (hv == need - cum) ? 1 : 0;
+                    // keys strictly better than the new prefix: (N - need) + cum; with the hv keys that share it they must fit the sort
+                    s_digit = dg; s_need = need - cum; s_done = ((N - need) + cum + hv <= SEL_FAST_MAX) ? 1 : 0;
                 }
             }
             __syncthreads();
