@@ -61,6 +61,43 @@ def test_extract_matches_golden(gpu_lib, name):
     assert np.abs(desc[ridx] - g["desc_rows"]).max() < DESC_TOL
 
 
+def test_config3_batch8_720p_device_resident(gpu_lib, oracle_mod):
+    """BASELINE.json configs[3], the per-GPU side: a batch of 8 frames of 1280x720 (resized to 1280x704 inside)
+    through xfh_extract_batch_device with frames and records resident in HBM.  Frame 0 is the committed golden
+    (extract_720p.npz); every frame is compared with the oracle; statistics are per frame (the batch holds the golden frame
+    twice, at positions 0 and 5, and a constant frame)."""
+    g = np.load(os.path.join(GOLDEN, "extract_720p.npz"))
+    H, W, nf = int(g["H"]), int(g["W"]), int(g["nfeatures"])
+    lap = tuple(int(v) for v in g["lap"])
+    blob = WT.pack_blob(WT.make_synthetic(1234, float(g["gain"])))
+    fr = np.stack([synth.image(H, W, int(g["seed"]) + (0 if i in (0, 5) else i)) for i in range(8)])
+    fr[6] = 77
+    L = capi.lib()
+    ctx = _ctx(nf, H, W, B=8); ctx.load_weights(blob)
+    d_in = capi.DeviceBuffer(fr.nbytes).upload(fr)
+    d_rec = capi.DeviceBuffer(8 * ctx.rec_bytes)
+    capi.check(L.xfh_extract_batch_device(ctx.h, d_in.ptr, 8, H, W, lap[0], lap[1], d_rec.ptr), ctx.h)
+    ctx.synchronize()
+    recs = ctx.parse_records(d_rec.download(np.uint8, 8 * ctx.rec_bytes), 8)
+    ctx.close()
+    kps, desc, nv, mono, nc = recs[0]
+    assert (nv, mono, nc) == (int(g["n_valid"]), int(g["mono_index"]), int(g["n_candidates"]))
+    assert kp_set(kps) == set(map(tuple, g["xy"].tolist()))
+    pos = {(int(k["x"]), int(k["y"])): i for i, k in enumerate(kps) if k["size"] > 0}
+    ridx = np.array([pos[tuple(p)] for p in g["desc_rows_xy"].tolist()])
+    assert np.abs(desc[ridx] - g["desc_rows"]).max() < DESC_TOL
+    for a, b in zip(recs[0], recs[5]):
+        assert np.array_equal(a, b)                                   # same frame, same record, wherever it sits in the batch
+    assert recs[6][2] == 0 and not recs[6][1].any()                   # constant frame: no keypoints, zero descriptors
+    orc = oracle_mod.Oracle(blob)
+    for b in (1, 2, 3, 4, 7):
+        ok, od, onv, omono = orc.extract(fr[b], nf, lap)
+        hk, hd, hnv, hmono, _ = recs[b]
+        assert (hnv, hmono) == (onv, omono) and kp_set(hk) == kp_set(ok), b
+        dd, ds, n = joined_desc_diff(hk, hd, ok, od)
+        assert n == onv and dd < DESC_TOL and ds < 1e-6, b
+
+
 def test_stage_tensors_match_oracle(gpu_lib, oracle_mod, weights_std):
     """every intermediate of the forward pass; convolutions and statistics are the same fp32/fp64
     expression on both sides (one fma chain in (ky,kx,ci) order) -> expected bit exact"""

@@ -119,9 +119,20 @@ def test_mnn_ties_across_candidate_groups(mctx, oracle_mod, n1, n2):
 
 
 def test_distance_i32_exact(mctx, oracle_mod):
-    for n1, n2, z in [(512, 384, 0), (70, 33, 3), (1, 1, 0), (64, 65, 0)]:
+    """k_dist_mfma: MFMA bulk (|a|^2 + |b|^2 - 2ab) + exact recomputation wherever the value is within the error bound of an
+    integer; the checker is the oracle's sequential fp32-difference / fp64-accumulate expression.  Zero rows (distance exactly
+    512 against unit rows), duplicates (distance 0), unnormalised and tiny-magnitude rows all stress the fix-up path."""
+    for n1, n2, z in [(512, 384, 0), (70, 33, 3), (1, 1, 0), (64, 65, 0), (4096, 4096, 100), (129, 1000, 5)]:
         d1, d2 = synth.descriptor_sets(n1, n2, noise=0.3, zero_rows=z)
+        if n2 > 10:
+            d2[3] = d1[0]; d2[7] = d2[2]
         assert np.array_equal(mctx.distance_i32(d1, d2), oracle_mod.distance_i32(d1, d2))       # integer: bit exact
+    d1, d2 = synth.descriptor_sets(300, 260, noise=0.5)
+    s1 = (np.arange(300, dtype=np.float32) % 7 + 0.25)[:, None]; s2 = (np.arange(260, dtype=np.float32) % 5 * 0.5 + 1e-3)[:, None]
+    assert np.array_equal(mctx.distance_i32(d1 * s1, d2 * s2), oracle_mod.distance_i32(d1 * s1, d2 * s2))
+    q = (np.round(d1 * 64) / 64).astype(np.float32); r = (np.round(d2 * 64) / 64).astype(np.float32)       # many exactly representable distances
+    assert np.array_equal(mctx.distance_i32(q, r), oracle_mod.distance_i32(q, r))
+    d1, d2 = synth.descriptor_sets(n1, n2, noise=0.3, zero_rows=z)
     # consistency with the scalar host metric that ORBmatcher::DescriptorDistance replaces
     L = capi.lib()
     t = mctx.distance_i32(d1, d2)

@@ -7,7 +7,7 @@
 //                   unit kernels_mnn_gemm.hip).
 //   k_mnn_post    : second level (names the member of the winning group by recomputing its 16 dot products
 //                   bit-identically), mutual check (:372), min_cossim gate, ordered compaction and distances (:371-403).
-//   k_dist_i32    : dense (int)(512 * ||a-b||^2), ORBmatcher::DescriptorDistance (:2246-2247).
+//   k_dist_mfma   : dense (int)(512 * ||a-b||^2), ORBmatcher::DescriptorDistance (:2246-2247): MFMA bulk + exact fix-up.
 //   k_best2_csr   : best / second-best distance over candidate lists (the SearchBy* inner loop, :75-119).
 //   k_distinctive_csr : MapPoint::ComputeDistinctiveDescriptors (src/MapPoint.cc:329-403), one wave per map point.
 //
@@ -21,49 +21,114 @@
 #include <utility>
 #include <stdlib.h>
 
-// dense integer metric: fp32 difference, fp64 square-accumulate, fp32 * 512, truncate
-__global__ __launch_bounds__(256)
-void k_dist_i32(const float* __restrict__ d1, int n1, const float* __restrict__ d2, int n2, int32_t* __restrict__ out) {
-    __shared__ float sa[64 * 65];
-    __shared__ float sb[64 * 65];
-    const int t = threadIdx.x;
-    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
-    for (int e = t; e < 64 * 64; e += 256) {
-        const int r = e >> 6, k = e & 63;
-        sa[r * 65 + k] = (r0 + r < n1) ? d1[(size_t)(r0 + r) * 64 + k] : 0.f;
-        sb[r * 65 + k] = (c0 + r < n2) ? d2[(size_t)(c0 + r) * 64 + k] : 0.f;
+// ---- k_dist_mfma: dense table of ORBmatcher::DescriptorDistance (ORBmatcher.cc:2246-2247) -----------------------
+//     out[i][j] = (int)(float(sum_k double(a_k - b_k)^2) * 512)          (cv::norm NORM_L2SQR: fp32 difference, fp64 accumulate)
+// The table is HBM-write bound (n1 * n2 * 4 bytes), the exact expression is fp64 VALU work 10x above that bound.  So the
+// bulk goes through the matrix cores: d^2 = |a|^2 + |b|^2 - 2 <a, b> with the norms in fp64 and the dot product from
+// v_mfma_f32_32x32x2_f32, combined in fp64.  That value v = 512 d^2 differs from the exact 512 * float(s) by at most
+//     E = 512 * (64 * 2^-24 * (|a|^2 + |b|^2)          fp32 fma chain of the dot product (gamma_64 |a||b| <= gamma_64 (|a|^2+|b|^2)/2, times 2)
+//              + 2^-22 * d^2)                           fp32 rounding of each difference (2^-23 relative on the sum) and of float(s) (2^-24)
+// so wherever v is further than E from an integer, floor(v) IS the reference's integer.  The other entries (about 1 % for
+// unit descriptors; all entries that are exact integers, e.g. against zero-padded rows) are marked in an LDS bitmap and
+// recomputed with the exact expression from the tiles that are still in LDS.  Identical integers by construction; the
+// C oracle (sequential fp64) is the checker in tests/test_gpu_match.py::test_distance_i32_exact.
+#define DT 128          // tile edge
+#define DLDK 68         // padded LDS row (floats)
+__global__ __launch_bounds__(256, 2)
+void k_dist_mfma(const float* __restrict__ d1, int n1, const float* __restrict__ d2, int n2, int32_t* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) float sA[DT * DLDK];
+    __shared__ __attribute__((aligned(16))) float sB[DT * DLDK];
+    __shared__ double sNa[DT], sNb[DT];
+    __shared__ unsigned sMask[DT * 4];                    // [row][4 words]: entries to recompute exactly
+    const int t = threadIdx.x, sub = t & 15, r0 = t >> 4;
+    const int row_base = blockIdx.y * DT, col_base = blockIdx.x * DT;
+    for (int e = t; e < DT * 4; e += 256) sMask[e] = 0u;
+    // staging: 16 lanes per row; k permutation inside each group of 8 (element e at 4*(e&1) + (e>>1)) by one pair exchange
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+        const float* d = side ? d2 : d1;
+        const int n = side ? n2 : n1, base = side ? col_base : row_base;
+        float* sT = side ? sB : sA;
+        double* sN = side ? sNb : sNa;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int rl = p * 16 + r0, row = base + rl;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (row < n) v = *(const f32x4*)(d + (size_t)row * 64 + sub * 4);
+            double ss = (double)v.x * (double)v.x + (double)v.y * (double)v.y + (double)v.z * (double)v.z + (double)v.w * (double)v.w;
+            ss += __shfl_xor(ss, 1); ss += __shfl_xor(ss, 2); ss += __shfl_xor(ss, 4); ss += __shfl_xor(ss, 8);
+            if (sub == 0) sN[rl] = ss;
+            const bool odd = sub & 1;
+            const float sx = odd ? v.x : v.y, sy = odd ? v.z : v.w;
+            const float rx = __shfl_xor(sx, 1), ry = __shfl_xor(sy, 1);
+            const f32x4 o = odd ? f32x4{rx, ry, v.y, v.w} : f32x4{v.x, v.z, rx, ry};
+            *(f32x4*)(sT + rl * DLDK + (sub >> 1) * 8 + (odd ? 4 : 0)) = o;
+        }
     }
     __syncthreads();
-    const int tx = t & 15, ty = t >> 4;       // 16 x 16 threads, 4 x 4 outputs each
-    double acc[4][4];
+    const int wave = t >> 6, lane = t & 63, i = lane & 31, h = lane >> 5;
+    const int wr = wave >> 1, wc = wave & 1;
+    const float* pa = sA + (wr * 64 + i) * DLDK + 4 * h;
+    const float* pb = sB + (wc * 64 + i) * DLDK + 4 * h;
+    const f32x16 Z16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f32x16 acc[2][2];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int g = 0; g < 8; ++g) {
+        const f32x4 a0 = *(const f32x4*)(pa + g * 8), a1 = *(const f32x4*)(pa + 32 * DLDK + g * 8);
+        const f32x4 b0 = *(const f32x4*)(pb + g * 8), b1 = *(const f32x4*)(pb + 32 * DLDK + g * 8);
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
-    for (int k = 0; k < 64; ++k) {
-        float av[4], bv[4];
+        for (int j = 0; j < 4; ++j) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[j], (g | j) ? acc[0][0] : Z16, 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b1[j], (g | j) ? acc[0][1] : Z16, 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b0[j], (g | j) ? acc[1][0] : Z16, 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1[j], (g | j) ? acc[1][1] : Z16, 0, 0, 0);
+        }
+    }
+    // acc[rt][ct][r] = < row wr*64 + rt*32 + (r&3) + 8*(r>>2) + 4*h , column wc*64 + ct*32 + i >
 #pragma unroll
-        for (int a = 0; a < 4; ++a) av[a] = sa[(ty + 16 * a) * 65 + k];
+    for (int ct = 0; ct < 2; ++ct) {
+        const int cl = wc * 64 + ct * 32 + i, col = col_base + cl;
+        const double nb = sNb[cl];
 #pragma unroll
-        for (int b = 0; b < 4; ++b) bv[b] = sb[(tx + 16 * b) * 65 + k];
+        for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const double df = (double)(av[a] - bv[b]);
-                acc[a][b] = fma(df, df, acc[a][b]);
+            for (int r = 0; r < 16; ++r) {
+                const int rl = wr * 64 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, row = row_base + rl;
+                const double na = sNa[rl];
+                const double d2v = na + nb - 2.0 * (double)acc[rt][ct][r];
+                const double v = 512.0 * d2v;
+                const double E = 512.0 * (3.814697265625e-6 * (na + nb) + 2.384185791015625e-7 * fabs(d2v));
+                const double fl = floor(v), fr = v - fl;
+                const bool safe = (fr > E) && (fr < 1.0 - E) && (v < 2.0e9);      // NaN / huge values fail every test: exact path
+                if (row < n1 && col < n2) {
+                    if (safe) out[(size_t)row * n2 + col] = (int32_t)fl;
+                    else atomicOr(&sMask[rl * 4 + (cl >> 5)], 1u << (cl & 31));
+                }
             }
     }
+    __syncthreads();
+    // exact expression for the marked entries, from the tiles in LDS: element k = 8g + 2j + hh sits at 8g + 4hh + j
+    for (int w = t; w < DT * 4; w += 256) {
+        unsigned m = sMask[w];
+        const int rl = w >> 2;
+        const float* ra = sA + rl * DLDK;
+        while (m) {
+            const int bit = __builtin_ctz(m); m &= m - 1;
+            const int cl = (w & 3) * 32 + bit;
+            const float* rb = sB + cl * DLDK;
+            double s = 0.0;
+            for (int g = 0; g < 8; ++g)
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+                for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int r = r0 + ty + 16 * a, c = c0 + tx + 16 * b;
-            if (r < n1 && c < n2) {
-                const float nd = (float)acc[a][b];
-                out[(size_t)r * n2 + c] = (int)(nd * 512.0f);
-            }
+                    for (int hh = 0; hh < 2; ++hh) {
+                        const double df = (double)(ra[g * 8 + 4 * hh + j] - rb[g * 8 + 4 * hh + j]);
+                        s = fma(df, df, s);
+                    }
+            const float nd = (float)s;
+            out[(size_t)(row_base + rl) * n2 + col_base + cl] = (int)(nd * 512.0f);
         }
+    }
 }
 
 // ---- k_best2_csr: best / second-best integer distance over per-query candidate lists -----------
@@ -282,6 +347,6 @@ hipError_t launch_mnn_prepared(xfh_ctx* c, const float* img1, int n1, const floa
 
 hipError_t launch_dist_i32(xfh_ctx* c, const float* d1, int n1, const float* d2, int n2, int32_t* out) {
     if (n1 <= 0 || n2 <= 0) return hipSuccess;
-    launch_k(c, XFH_K_DIST_I32, -1, k_dist_i32, dim3((n2 + 63) / 64, (n1 + 63) / 64), dim3(256), 0, d1, n1, d2, n2, out);
+    launch_k(c, XFH_K_DIST_I32, -1, k_dist_mfma, dim3((n2 + DT - 1) / DT, (n1 + DT - 1) / DT), dim3(256), 0, d1, n1, d2, n2, out);
     return hipGetLastError();
 }
