@@ -104,3 +104,41 @@ def test_convert_weights_tool(tmp_path):
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert (tmp_path / "o.xfhw").read_bytes() == WT.pack_blob(w)
+
+
+def test_png_reader_and_gray_conversion(tmp_path):
+    """include/xfeat/image_io.h (replay harness input): every PNG filter type, gray / gray+alpha / RGB / RGBA, several IDAT chunks,
+    and the reference's colour conversion (imread BGR order + Camera.RGB flag, OpenCV fixed point); cross-checked with PIL's
+    decoder when it is installed"""
+    import subprocess
+    from pngutil import opencv_gray, write_png
+    exe = str(tmp_path / "image_io_test")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "image_io_test.cpp"), "-lz", "-o", exe])
+    rng = np.random.RandomState(4)
+    smooth = (np.add.outer(np.arange(37), np.arange(53)) * 3 % 256).astype(np.uint8)
+    cases = [("g", smooth), ("ga", np.stack([smooth, 255 - smooth], -1)), ("rgb", rng.randint(0, 256, (37, 53, 3)).astype(np.uint8)),
+             ("rgba", np.stack([smooth, smooth[::-1], rng.randint(0, 256, smooth.shape).astype(np.uint8), smooth], -1))]
+    for name, img in cases:
+        for filt in ([0], [1], [2], [3], [4], [0, 1, 2, 3, 4]):
+            path = str(tmp_path / f"{name}_{len(filt)}_{filt[0]}.png")
+            write_png(path, img, filt)
+            try:
+                from PIL import Image
+                assert np.array_equal(np.asarray(Image.open(path)).reshape(img.shape), img)          # the writer itself is a valid encoder
+            except ImportError:
+                pass
+            for flag in (0, 1):
+                out = str(tmp_path / "o.bin")
+                subprocess.check_call([exe, path, str(flag), out])
+                raw = open(out, "rb").read()
+                hdr, data = raw.split(b"\n", 1)
+                assert tuple(map(int, hdr.split())) == (37, 53, 1 if img.ndim == 2 else img.shape[2])
+                assert np.array_equal(np.frombuffer(data, np.uint8).reshape(37, 53), opencv_gray(img, flag)), (name, filt, flag)
+    # PGM path and a truncated PNG
+    with open(tmp_path / "a.pgm", "wb") as f:
+        f.write(b"P5\n# c\n53 37\n255\n" + smooth.tobytes())
+    subprocess.check_call([exe, str(tmp_path / "a.pgm"), "1", str(tmp_path / "o.bin")])
+    assert open(tmp_path / "o.bin", "rb").read().split(b"\n", 1)[1] == smooth.tobytes()
+    bad = open(tmp_path / "rgb_1_0.png", "rb").read()[:200]
+    open(tmp_path / "bad.png", "wb").write(bad)
+    assert subprocess.call([exe, str(tmp_path / "bad.png"), "1", str(tmp_path / "o.bin")]) == 1

@@ -41,11 +41,74 @@ def test_cpp_dropin_end_to_end(gpu_lib, oracle_mod, tmp_path):
     assert np.array_equal(a[0], m["q"]) and np.array_equal(a[1], m["t"])
 
 
+def _read_dump(path, n_frames):
+    raw = open(path, "rb").read()
+    o = 0
+    frames = []
+    for _ in range(n_frames):
+        nv, nk = np.frombuffer(raw, "<i4", 2, o); o += 8
+        kp = np.frombuffer(raw, "<f4", 3 * nk, o).reshape(nk, 3); o += 12 * nk
+        nm = int(np.frombuffer(raw, "<i4", 1, o)[0]); o += 4
+        m = np.frombuffer(raw, np.dtype([("q", "<i4"), ("t", "<i4"), ("d", "<f4")]), nm, o); o += 12 * nm
+        frames.append((int(nv), kp, m))
+    assert o == len(raw)
+    return frames
+
+
+def test_frontend_replay_matches_oracle(gpu_lib, oracle_mod, tmp_path):
+    """examples/frontend_replay.cpp (shaped after the reference's examples/RGB-D/rgbd_tum.cc:75-143) on a TUM-style association
+    list of RGB PNG frames: per frame XFextractor::operator(), per frame pair ORBmatcher::match against the previous frame.
+    The dumped keypoints and per-pair match lists must equal what the oracle computes from the same files (gray conversion as
+    the reference does with Camera.RGB = 1), pair by pair; the inlier statistic of the drifting sequence must see the drift."""
+    from pngutil import opencv_gray, write_png
+    exe = str(tmp_path / "frontend_replay")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "frontend_replay.cpp"),
+                           "-L" + os.path.join(ROOT, "xfeatslam_amd"), "-lxfeat_hip", "-lz", "-Wl,-rpath," + os.path.join(ROOT, "xfeatslam_amd"),
+                           "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    blob = WT.pack_blob(WT.make_synthetic(1234, 6.0))
+    (tmp_path / "w.xfhw").write_bytes(blob)
+    os.makedirs(tmp_path / "rgb")
+    nf, H, W, n = 300, 96, 160, 5
+    base = synth.image(H, W + 8 * n, 31)
+    lines, grays = [], []
+    for i in range(n):
+        g = base[:, 8 * i:8 * i + W]                                   # the scene drifts 8 px per frame (one cell of the 1/8-resolution
+                                                                       # maps: with synthetic weights the descriptors only repeat under such shifts)
+        rgb = np.stack([g, np.roll(g, 1, 0), 255 - g], -1).astype(np.uint8)
+        write_png(str(tmp_path / "rgb" / f"{i}.png"), rgb, [0, 1, 2, 3, 4])
+        grays.append(np.ascontiguousarray(opencv_gray(rgb, 1)))
+        lines.append(f"{i}.0 rgb/{i}.png {i}.0 depth/{i}.png")
+    (tmp_path / "assoc.txt").write_text("\n".join(lines) + "\n")
+    dump = str(tmp_path / "dump.bin")
+    r = subprocess.run([exe, str(tmp_path / "w.xfhw"), str(tmp_path / "assoc.txt"), str(tmp_path), "--dump", dump], capture_output=True, text=True,
+                       env=dict(os.environ, XFH_NFEATURES=str(nf)))
+    assert r.returncode == 0, r.stderr
+    assert "median front-end time" in r.stdout and "inliers/frame pair" in r.stdout
+    frames = _read_dump(dump, n)
+    orc = oracle_mod.Oracle(blob)
+    prev = None
+    for i in range(n):
+        ok, od, onv, _ = orc.extract(grays[i], nf, (0, 0))
+        nv, kp, m = frames[i]
+        assert nv == onv and np.array_equal(kp[:, 0], ok["x"]) and np.array_equal(kp[:, 1], ok["y"]) and np.array_equal(kp[:, 2], ok["size"]), i
+        if prev is not None:
+            a = oracle_mod.match_mnn(prev[1], od)                      # the reference matches the padded descriptor blocks (SURVEY Q11)
+            assert np.array_equal(a[0], m["q"]) and np.array_equal(a[1], m["t"]) and np.array_equal(a[2], m["d"], equal_nan=True), i
+            # drift: most matches between real keypoints move by (-8, 0)
+            real = (prev[0]["size"][m["q"]] > 0) & (ok["size"][m["t"]] > 0)
+            dx = ok["x"][m["t"]][real] - prev[0]["x"][m["q"]][real]
+            assert real.sum() > 20 and np.median(dx) == -8.0
+        else:
+            assert len(m) == 0
+        prev = (ok, od)
+    assert "median displacement (-8.0, 0.0)" in r.stdout
+
+
 def test_frontend_replay_example(gpu_lib, tmp_path):
     """examples/frontend_replay.cpp (shaped after rgbd_tum.cc): extract + match against the previous frame"""
     exe = str(tmp_path / "frontend_replay")
     subprocess.check_call(["g++", "-std=c++17", "-O2", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "frontend_replay.cpp"),
-                           "-L" + os.path.join(ROOT, "xfeatslam_amd"), "-lxfeat_hip", "-Wl,-rpath," + os.path.join(ROOT, "xfeatslam_amd"),
+                           "-L" + os.path.join(ROOT, "xfeatslam_amd"), "-lxfeat_hip", "-lz", "-Wl,-rpath," + os.path.join(ROOT, "xfeatslam_amd"),
                            "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
     (tmp_path / "w.xfhw").write_bytes(WT.pack_blob(WT.make_synthetic(1234, 6.0)))
     # PGM sequence + TUM-style association list
