@@ -38,6 +38,12 @@ __host__ __device__ inline float ord2f(unsigned u) {
     return __builtin_bit_cast(float, u);
 }
 
+// hipcc (ROCm 7.2) pads the MFMA -> VALU-read hazard (18 wait states after a 16-pass v_mfma_f32_32x32x2_f32) along the
+// fall-through path only: with a taken branch between the last MFMA and the first read of its result a stale register
+// came back (k_conv_mfma_p<8,24,...>: 10 wait states).  Every kernel therefore lets the matrix pipe drain explicitly between
+// its K loop and an epilogue that branches; the scheduling barriers keep every instruction on its side of the nops.
+#define XFH_MFMA_SETTLE() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop 15\n\ts_nop 3" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+
 // ---- statistics finalisation ------------------------------------------------------------
 // Fold the npart (sum, sum of squares) fp64 partials of every channel in a FIXED order into
 // (mean, rstd).  Called by k_bn_finalize (one workgroup per frame) and, for small batches, by

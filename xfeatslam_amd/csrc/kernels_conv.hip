@@ -201,6 +201,45 @@ void k_conv_direct(ConvArgs a) {
     }
 }
 
+// Epilogue shared by k_conv_mfma and k_conv_mfma_p.  C/D layout of v_mfma_f32_32x32x2_f32: a lane holds channel (lane&31) of
+// tile n and the pixels (r&3) + 8*(r>>2) + 4*h of the wave's WH x WW pixel block.  The pixel row / column of register r
+// splits into a compile-time part and 4*h (WW >= 8), so the store address is  wave-uniform base + scalar offset(r) +
+// one per-lane 32-bit offset -- no 64-bit vector arithmetic and, for tiles that lie inside the map, no predicates.
+// (The conv kernels issue their VALU instructions on the same pipe as the f32 MFMA: PMC showed 2.5-9 VALU
+// instructions per MFMA in these kernels, most of them address arithmetic.)  Statistics: fp64 (sum, sum^2) per channel
+// over the lane's valid pixels in register order -- the order is part of the numerics contract.
+template <int COUT, int NT, int WW, int WH, int EPI>
+__device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[NT], float* __restrict__ wave_out /* pixel (0,0) of the wave's block */, int Wout,
+                                              int rows_left, int cols_left, int co0, int h, const float* __restrict__ bias,
+                                              double (&sum)[NT], double (&sq)[NT]) {
+    static_assert(WW >= 8 && WW * WH == 32, "pixel block of a wave");
+    XFH_MFMA_SETTLE();                                              // common.h: the epilogue branches
+    const bool full = rows_left >= WH && cols_left >= WW;          // wave-uniform
+    const int lane_off = 4 * h * COUT + co0;
+    const int rowstride = Wout * COUT;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int co = co0 + n * 32;
+        sum[n] = 0.0; sq[n] = 0.0;
+        float bv = 0.f;
+        if constexpr (EPI == EPI_BIAS) bv = (COUT % 32 == 0 || co < COUT) ? bias[co] : 0.f;
+        const bool cok = COUT % 32 == 0 || co < COUT;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int pb = (r & 3) + 8 * (r >> 2);                 // + 4*h
+            const int prow = pb / WW, pcol = pb % WW;              // compile-time; pcol + 4*h < WW
+            float* dst = wave_out + prow * rowstride + pcol * COUT + n * 32;      // uniform
+            const bool ok = full ? cok : (cok && prow < rows_left && pcol + 4 * h < cols_left);
+            if (ok) {
+                float v = acc[n][r];
+                if constexpr (EPI == EPI_BIAS) v += bv;
+                dst[lane_off] = v;
+                if constexpr (EPI == EPI_STATS) { const double dv = (double)v; sum[n] += dv; sq[n] = fma(dv, dv, sq[n]); }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // implicit-GEMM convolution on the f32 matrix cores.
 //   WM x WN waves per workgroup; each wave owns 32 output pixels (WH x WW) and NT tiles of 32
@@ -303,7 +342,7 @@ void k_conv_mfma(ConvArgs a) {
     }
     __syncthreads();
 
-    const int wave = t >> 6, lane = t & 63, i = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, i = lane & 31, h = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
     const int pr = i / WW, pc = i % WW;                     // pixel of this lane inside the wave tile
     const int ly = (wm * WH + pr) * ST, lx = pc * ST;        // its top-left input position in the tile
@@ -356,26 +395,11 @@ void k_conv_mfma(ConvArgs a) {
     }
 
     // ---- epilogue ---------------------------------------------------------------------
-    // C/D layout: lane holds channel (lane&31) of tile n, pixels (r&3) + 8*(r>>2) + 4*h.
-    float* outp = a.out + (size_t)b * a.out_stride;
     double sum[NT], sq[NT];
-#pragma unroll
-    for (int n = 0; n < NT; ++n) {
-        const int co = (wn * NT + n) * 32 + i;
-        sum[n] = 0.0; sq[n] = 0.0;
-        float bias = 0.f;
-        if constexpr (EPI == EPI_BIAS) bias = (co < COUT) ? a.bias[co] : 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int px = (r & 3) + 8 * (r >> 2) + 4 * h;
-            const int oy = ty0 + wm * WH + px / WW, ox = tx0 + px % WW;
-            if (oy < a.Hout && ox < a.Wout && co < COUT) {
-                float v = acc[n][r];
-                if constexpr (EPI == EPI_BIAS) v += bias;
-                outp[((size_t)oy * a.Wout + ox) * COUT + co] = v;
-                if constexpr (EPI == EPI_STATS) { const double dv = (double)v; sum[n] += dv; sq[n] = fma(dv, dv, sq[n]); }
-            }
-        }
+    {
+        const int oy0 = ty0 + wm * WH;
+        float* wave_out = a.out + (size_t)b * a.out_stride + ((size_t)oy0 * a.Wout + tx0) * COUT;
+        conv_epilogue<COUT, NT, WW, WH, EPI>(acc, wave_out, a.Wout, a.Hout - oy0, a.Wout - tx0, wn * NT * 32 + i, h, a.bias, sum, sq);
     }
     if constexpr (EPI == EPI_STATS) {
         double* s_red = (double*)smem;        // [WM][COUTP][2], the tiles are no longer needed
@@ -440,7 +464,7 @@ void k_conv_mfma_p(ConvArgs a, int ntile, int total) {
         *(f32x4*)(s_w + n * WS + c4 * 4) = *(const f32x4*)(a.w + (size_t)f * 4);
     }
     const int g = t % G;                         // this thread's channel group in every item it stages
-    const int wave = t >> 6, lane = t & 63, i = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, i = lane & 31, h = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
     const int pr = i / WW, pc = i % WW;
     const int ly = (wm * WH + pr) * ST, lx = pc * ST;
@@ -537,25 +561,11 @@ void k_conv_mfma_p(ConvArgs a, int ntile, int total) {
         // ---- epilogue of `tile` (C/D layout: channel (lane&31) of tile n, pixels (r&3) + 8*(r>>2) + 4*h)
         const int b = tile / ntile, tl = tile - b * ntile;
         const int tx0 = (tl % a.tiles_x) * TW, ty0 = (tl / a.tiles_x) * TH;
-        float* outp = a.out + (size_t)b * a.out_stride;
         double sum[NT], sq[NT];
-#pragma unroll
-        for (int n = 0; n < NT; ++n) {
-            const int co = (wn * NT + n) * 32 + i;
-            sum[n] = 0.0; sq[n] = 0.0;
-            float bias = 0.f;
-            if constexpr (EPI == EPI_BIAS) bias = (co < COUT) ? a.bias[co] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int px = (r & 3) + 8 * (r >> 2) + 4 * h;
-                const int oy = ty0 + wm * WH + px / WW, ox = tx0 + px % WW;
-                if (oy < a.Hout && ox < a.Wout && co < COUT) {
-                    float v = acc[n][r];
-                    if constexpr (EPI == EPI_BIAS) v += bias;
-                    outp[((size_t)oy * a.Wout + ox) * COUT + co] = v;
-                    if constexpr (EPI == EPI_STATS) { const double dv = (double)v; sum[n] += dv; sq[n] = fma(dv, dv, sq[n]); }
-                }
-            }
+        {
+            const int oy0 = ty0 + wm * WH;
+            float* wave_out = a.out + (size_t)b * a.out_stride + ((size_t)oy0 * a.Wout + tx0) * COUT;
+            conv_epilogue<COUT, NT, WW, WH, EPI>(acc, wave_out, a.Wout, a.Hout - oy0, a.Wout - tx0, wn * NT * 32 + i, h, a.bias, sum, sq);
         }
         if constexpr (EPI == EPI_STATS) {
 #pragma unroll

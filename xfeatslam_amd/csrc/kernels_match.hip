@@ -84,6 +84,7 @@ void k_dist_mfma(const float* __restrict__ d1, int n1, const float* __restrict__
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1[j], (g | j) ? acc[1][1] : Z16, 0, 0, 0);
         }
     }
+    XFH_MFMA_SETTLE();                                      // common.h: the epilogue branches
     // acc[rt][ct][r] = < row wr*64 + rt*32 + (r&3) + 8*(r>>2) + 4*h , column wc*64 + ct*32 + i >
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {

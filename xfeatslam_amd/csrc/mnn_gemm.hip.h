@@ -132,7 +132,7 @@ void k_mnn_gemm_img(const float* __restrict__ img1, int n1, const float* __restr
         }
     }
     if (PRIO) __builtin_amdgcn_s_setprio(0);
-
+    XFH_MFMA_SETTLE();                                      // common.h: the epilogue starts with a branch
     if (DBG == 1) {
         float sdbg = 0.f;
 #pragma unroll
