@@ -45,6 +45,11 @@ KP_GAIN = 6.0                     # "dense" synthetic weights: > 4096 NMS candid
 DOMINANT_LAYERS = (7, 17)         # k_conv_mfma<64,64,3,1,4,2,1,16,PRO_BN,EPI_STATS,32>: block3.1, block_fusion.1
 
 
+BN_MODES = {"batch": 0, "running": 1, "folded": 2}
+BN_TEXT = {"batch": "per-frame BatchNorm statistics", "running": "NOT the reference's semantics: running BatchNorm statistics, upstream eval()",
+           "folded": "NOT the reference's semantics: eval() BatchNorm folded into the convolution weights"}
+
+
 def conv_flops(H, W):
     """algorithmic flops per frame of the 3x3 64->64 layer at 1/8 resolution"""
     return 2.0 * (H // 8) * (W // 8) * 64 * 64 * 9
@@ -87,6 +92,9 @@ def main():
     ap.add_argument("--force-comm", action="store_true", help="run the RCCL exchange also with one rank")
     ap.add_argument("--no-legs", action="store_true", help="timed region only (no host_api / match / aux / cpu legs)")
     ap.add_argument("--serial-branch", action="store_true", help="XFH_FLAG_SERIAL_BRANCH: no overlapping kernels (for per-kernel profiles)")
+    ap.add_argument("--bn", choices=["batch", "running", "folded"], default="batch",
+                    help="BatchNorm mode of the timed region: batch = the reference's per-frame statistics (the headline), running = upstream eval(), "
+                         "folded = eval() folded into the weights at load (SURVEY.md N4)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0)); local_rank = int(os.environ.get("LOCAL_RANK", 0))
@@ -109,9 +117,11 @@ def main():
 
     B, H, W, K = args.batch, args.height, args.width, args.steps
     dev = local_rank if N > 1 else 0
-    blob = WT.pack_blob(WT.make_synthetic(1234, KP_GAIN))
+    bn_mode = BN_MODES[args.bn]
+    blob = WT.pack_blob(WT.make_synthetic(1234, KP_GAIN, with_bn=True))       # the running statistics are ignored in batch mode
     S = max(1, args.streams)
-    ctxs = [Context(nfeatures=NFEATURES, max_height=H, max_width=W, max_batch=B, device=dev, flags=capi.FLAG_SERIAL_BRANCH if args.serial_branch else 0) for _ in range(S)]
+    ctxs = [Context(nfeatures=NFEATURES, max_height=H, max_width=W, max_batch=B, device=dev, bn_mode=bn_mode,
+                    flags=capi.FLAG_SERIAL_BRANCH if args.serial_branch else 0) for _ in range(S)]
     for c_ in ctxs:
         c_.load_weights(blob)
     ctx = ctxs[0]
@@ -207,7 +217,7 @@ def main():
         "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"configs[1]: {H}x{W} u8 frames, XFeat extract, nfeatures {nf}, {B * S} distinct frames per GPU per step "
-                               f"({S} sub-batch(es) of {B} on separate HIP streams) (per-frame BatchNorm statistics), inputs and 4096-row records resident in HBM"
+                               f"({S} sub-batch(es) of {B} on separate HIP streams) ({BN_TEXT[args.bn]}), inputs and 4096-row records resident in HBM"
                                + (f", RCCL {args.gather} of the records through the C ABI (xfh_comm_*), overlapped with the next step" if use_comm else ""),
                    "frames_per_gpu_per_step": B * S, "sub_batches_in_flight": S, "height": H, "width": W, "nfeatures": nf,
                    "weights": f"synthetic seed 1234, keypoint-logit gain {KP_GAIN}", "parallelism": f"frames x{N}"},
@@ -222,7 +232,8 @@ def main():
     conv_traffic = None
     if traffic and traffic.get("conv_bytes_per_launch"):
         conv_traffic = traffic["conv_bytes_per_launch"] * (B / traffic["conv_batch"] if traffic.get("conv_batch") else 1.0)
-    out["roofline"] = {"kernel": "k_conv_mfma<64,64,3,1,4,2,1,16,1,0,32,1> (block3.1, block_fusion.1: 3x3 64->64 at 1/8 res)",
+    out["config"]["bn_mode"] = args.bn
+    out["roofline"] = {"kernel": "k_conv_mfma<64,64,3,...> (block3.1, block_fusion.1: 3x3 64->64 at 1/8 res)" + ("" if args.bn != "folded" else ", bias+ReLU epilogue"),
                        "measured": "HIP events attached to every dispatch of the kernel inside the timed region" if in_region else "single-stream pass of the same steps",
                        "bound": "mfma", "achieved": conv_tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": conv_tf / PEAK_F32_MFMA_TFLOPS,
                        "traffic": conv_traffic, "avg_launch_us": conv_us, "launches": n_conv, "flops_per_launch": conv_flops(H, W) * B}
@@ -259,6 +270,36 @@ def legs(out, args, lib, capi, synth, Context, ctx, blob, frames, d_in, d_recb, 
                            "note": "one 480x640 frame per xfh_extract_batch_device call, back to back on one stream (latency path of configs[1], device resident)"}
     capi.check(lib.xfh_extract_batch_device(ctx.h, in_ptr, B, H, W, 0, 0, rec_ptr), ctx.h)   # restore the batch records
     ctx.synchronize()
+
+    # ---- the same workload with upstream-XFeat eval() BatchNorm, exact (running) and folded into the weights
+    if args.bn == "batch":
+        bn = {}
+        for name in ("running", "folded"):
+            fc = Context(nfeatures=nf, max_height=H, max_width=W, max_batch=B, device=ctx.device, bn_mode=BN_MODES[name])
+            fc.load_weights(blob)
+            d_r = capi.DeviceBuffer(B * rec_bytes)
+            for _ in range(2):
+                capi.check(lib.xfh_extract_batch_device(fc.h, in_ptr, B, H, W, 0, 0, d_r.ptr), fc.h)
+            fc.synchronize()
+            fc.timing_enable(capi.K["CONV_MFMA"], sum(1 << l for l in DOMINANT_LAYERS))
+            nrun = max(5, min(20, args.steps))
+            t1 = time.perf_counter()
+            for _ in range(nrun):
+                capi.check(lib.xfh_extract_batch_device(fc.h, in_ptr, B, H, W, 0, 0, d_r.ptr), fc.h)
+            fc.synchronize()
+            dt = (time.perf_counter() - t1) / nrun
+            n_c, ms_c = fc.timing_read()
+            fc.timing_enable(0)
+            us = ms_c / max(n_c, 1) * 1e3
+            tf = conv_flops(H, W) * B / (us * 1e-6) / 1e12 if n_c else 0.0
+            bn[name] = {"frames_per_s": B / dt, "ms_per_step": dt * 1e3, "steps": nrun,
+                        "roofline": {"kernel": "same 3x3 64->64 launches as the headline" + (", bias+ReLU epilogue, no statistics" if name == "folded" else ""),
+                                     "bound": "mfma", "achieved": tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_F32_MFMA_TFLOPS,
+                                     "avg_launch_us": us, "launches": n_c}}
+            fc.close(); d_r.free()
+        bn["note"] = ("NOT the reference's semantics (its libtorch module stays in train mode, SURVEY.md Q1): upstream-XFeat eval() BatchNorm behind "
+                      "cfg.bn_mode; 'folded' = W*rstd, bias -mean*rstd, ReLU in the conv epilogue, no statistics kernels or partials")
+        out["bn_eval_modes"] = bn
 
     # ---- host API: the path the drop-in XFextractor::operator() takes (host image in, host keypoints / descriptors out)
     host = {}

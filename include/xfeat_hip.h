@@ -54,8 +54,11 @@ typedef struct {
  * statistics are always per frame, also in batched calls.  RUNNING_STATS is the upstream-XFeat
  * eval() behaviour: the running_mean / running_var buffers of the weight file are used instead (the
  * blob must carry them, otherwise xfh_load_weights returns XFH_ERR_BAD_WEIGHTS); the InstanceNorm of
- * the input image is per frame in both modes. */
-enum { XFH_BN_BATCH_STATS = 0, XFH_BN_RUNNING_STATS = 1 };
+ * the input image is per frame in all modes.
+ * RUNNING_FOLDED is the same eval() network with every BatchNorm folded into the preceding convolution when the weights
+ * are loaded (W' = W * rstd, b' = -mean * rstd, ReLU in the epilogue): no statistics are computed or applied at run time.
+ * Folding re-rounds the weights, so this mode equals RUNNING_STATS to ~1e-6, not bit for bit. */
+enum { XFH_BN_BATCH_STATS = 0, XFH_BN_RUNNING_STATS = 1, XFH_BN_RUNNING_FOLDED = 2 };
 
 typedef struct {
     int32_t device;        /* HIP device ordinal                                              */

@@ -237,6 +237,35 @@ def test_running_stats_mode(gpu_lib, oracle_mod):
     ctx.close()
 
 
+def test_running_folded_mode(gpu_lib, oracle_mod):
+    """XFH_BN_RUNNING_FOLDED: BatchNorm folded into the convolutions at load time.  Folding re-rounds the
+    weights, so the comparison with the oracle's eval() mode is a tolerance one: descriptors of the common keypoints within
+    1e-4, and the keypoint sets equal up to threshold/NMS near-ties (<= 1 % symmetric difference)."""
+    from xfeatslam_amd.extractor import Context
+    w = WT.make_synthetic(1234, 6.0, with_bn=True)
+    blob = WT.pack_blob(w)
+    for B, H, W in ((2, 160, 224), (12, 96, 128)):                     # consumer-fold regime and persistent-kernel regime
+        fr = synth.frames(B, H, W, seed=5)
+        ctx = Context(nfeatures=512, max_height=H, max_width=W, max_batch=B, bn_mode=2)
+        ctx.load_weights(blob)
+        recs = ctx.extract_batch(fr, (0, 100))
+        ctx1 = Context(nfeatures=512, max_height=H, max_width=W, max_batch=B, bn_mode=1)
+        ctx1.load_weights(blob)
+        recs1 = ctx1.extract_batch(fr, (0, 100))
+        ctx1.close(); ctx.close()
+        orc = oracle_mod.Oracle(blob, bn_mode=1)
+        for b in range(B):
+            hk, hd, hnv, hmono, _ = recs[b]
+            if b < 2:
+                ok, od, onv, omono = orc.extract(fr[b], 512, (0, 100))
+            else:                                                       # the exact (unfolded) HIP mode stands in for the oracle, itself checked above
+                ok, od, onv, omono, _ = recs1[b]
+            a, o = kp_set(hk), kp_set(ok)
+            assert len(a ^ o) <= max(2, 0.01 * len(o)), (B, b, len(a ^ o), len(o))
+            dd, ds, n = joined_desc_diff(hk, hd, ok, od)
+            assert n >= 0.99 * onv - 2 and dd < 1e-4, (B, b, dd, n, onv)
+
+
 def test_keypoint_rescale_flag(gpu_lib, oracle_mod):
     """XFH_FLAG_RESCALE_KEYPOINTS (upstream-XFeat coordinates) against the oracle in the same mode; the default stays the
     reference's no-op rescale.  The lapping-area split follows the reported x."""

@@ -77,7 +77,7 @@ int xfh_create(const xfh_config* cfg, xfh_ctx** out) {
     *out = nullptr;
     if (cfg->max_height < 32 || cfg->max_width < 32 || cfg->nfeatures < 1 || cfg->nfeatures > 65536 || cfg->max_batch < 1)
         return XFH_ERR_INVALID_ARG;
-    if (cfg->bn_mode != XFH_BN_BATCH_STATS && cfg->bn_mode != XFH_BN_RUNNING_STATS) return XFH_ERR_INVALID_ARG;
+    if (cfg->bn_mode != XFH_BN_BATCH_STATS && cfg->bn_mode != XFH_BN_RUNNING_STATS && cfg->bn_mode != XFH_BN_RUNNING_FOLDED) return XFH_ERR_INVALID_ARG;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return XFH_ERR_NO_DEVICE;
     if (cfg->device < 0 || cfg->device >= ndev) return XFH_ERR_NO_DEVICE;
@@ -169,7 +169,7 @@ int xfh_destroy(xfh_ctx* c) {
     F(c->d_gray); F(c->X); F(c->pre_part); F(c->xstat);
     for (int i = 0; i < XFH_NUM_LAYERS; ++i) { F(c->raw[i]); F(c->part[i]); F(c->stat[i]); }
     if (!c->is_twin) {                                   // a twin borrows the weights of its parent
-        for (int i = 0; i < XFH_NUM_LAYERS; ++i) { F(c->w.mfma[i]); F(c->w.alt[i]); F(c->w.alt2[i]); }
+        for (int i = 0; i < XFH_NUM_LAYERS; ++i) { F(c->w.mfma[i]); F(c->w.alt[i]); F(c->w.alt2[i]); F(c->w.bn_bias[i]); }
         for (int i = 0; i < 3; ++i) F(c->w.direct[i]);
         F(c->w.fus2); F(c->w.fus2_bias); F(c->w.skip_w); F(c->w.skip_b); F(c->w.heat2_w); F(c->w.heat2_b); F(c->w.kp3_w); F(c->w.kp3_b);
     }
@@ -246,43 +246,61 @@ static void twin_share_weights(xfh_ctx* c);
 int xfh_load_weights(xfh_ctx* c, const void* blob, size_t nbytes) {
     if (!c || !blob) return XFH_ERR_INVALID_ARG;
     HIPCK(c, hipSetDevice(c->cfg.device));
-    BlobEntry e; char nm[64];
+    BlobEntry e; char nm[80];
     for (int i = 0; i < XFH_NUM_LAYERS; ++i) {
         const LayerSpec& L = XFH_LAYERS[i];
         snprintf(nm, sizeof nm, "%s.layer.0.weight", L.name);
         if (!blob_find(blob, nbytes, nm, &e) || e.ndim != 4 || (int)e.dims[0] != L.cout || (int)e.dims[1] != L.cin || (int)e.dims[2] != L.ks || (int)e.dims[3] != L.ks) return XFH_ERR_BAD_WEIGHTS;
-        int rc;
-        if (i < 3) {
-            std::vector<float> o((size_t)9 * L.cin * L.cout);
-            for (int co = 0; co < L.cout; ++co) for (int ci = 0; ci < L.cin; ++ci) for (int ky = 0; ky < 3; ++ky) for (int kx = 0; kx < 3; ++kx)
-                o[(((size_t)ky * 3 + kx) * L.cin + ci) * L.cout + co] = e.p[(((size_t)co * L.cin + ci) * 3 + ky) * 3 + kx];
-            rc = upload(c, &c->w.direct[i], o);
-        } else {
-            const int coutp = (L.cout + 31) / 32 * 32;
-            rc = upload(c, &c->w.mfma[i], pack_mfma(e.p, L.cout, L.cin, L.ks, coutp));
-            if (rc == XFH_OK && L.ks == 3 && L.cin >= 64 && L.stride == 1 && i != 10 && i != 11)       // 7, 16, 17 and 13, 14: 32-channel chunks
-                rc = upload(c, &c->w.alt[i], pack_mfma(e.p, L.cout, L.cin, L.ks, coutp, 32));
-            if (rc == XFH_OK && L.ks == 3 && L.cin == 64 && L.cout == 64 && L.stride == 1)                 // 7, 10, 11, 16, 17: three taps per chunk
-                rc = upload(c, &c->w.alt2[i], pack_mfma(e.p, L.cout, L.cin, L.ks, coutp, 64, 3));
-            if (rc == XFH_OK && L.ks == 3 && L.cin <= 24 && L.cout == 24)                              // 3, 4, 5: all nine taps in one chunk (persistent kernels, block1.3)
-                rc = upload(c, &c->w.alt[i], pack_mfma(e.p, L.cout, L.cin, L.ks, coutp, 64, 9));
-        }
-        if (rc != XFH_OK) return rc;
-        if (c->cfg.bn_mode == XFH_BN_RUNNING_STATS) {
-            // eval() semantics: (running_mean, 1/sqrt(running_var + eps)) replace the per-frame statistics;
-            // written once for every frame slot, k_bn_finalize is then never launched
+        const bool running = c->cfg.bn_mode != XFH_BN_BATCH_STATS, folded = c->cfg.bn_mode == XFH_BN_RUNNING_FOLDED;
+        std::vector<float> mean, rstd;
+        if (running) {
+            // eval() semantics: (running_mean, 1/sqrt(running_var + eps)) replace the per-frame statistics
             BlobEntry em, ev; char n2[80];
             snprintf(nm, sizeof nm, "%s.layer.1.running_mean", L.name);
             snprintf(n2, sizeof n2, "%s.layer.1.running_var", L.name);
             if (!blob_find(blob, nbytes, nm, &em) || !blob_find(blob, nbytes, n2, &ev) || (int)em.dims[0] != L.cout || (int)ev.dims[0] != L.cout)
                 return XFH_ERR_BAD_WEIGHTS;
+            mean.assign(em.p, em.p + L.cout); rstd.resize(L.cout);
+            for (int ch = 0; ch < L.cout; ++ch) rstd[ch] = (float)(1.0 / sqrt((double)ev.p[ch] + 1e-5));
+        }
+        const size_t wcount = (size_t)L.cout * L.cin * L.ks * L.ks;
+        std::vector<float> wf(e.p, e.p + wcount);
+        if (folded)                                         // BatchNorm into the convolution: W' = W * rstd, b' = -mean * rstd
+            for (int co = 0; co < L.cout; ++co)
+                for (size_t q = 0; q < wcount / L.cout; ++q) wf[(size_t)co * (wcount / L.cout) + q] *= rstd[co];
+        const float* wp = wf.data();
+        int rc;
+        if (i < 3) {
+            std::vector<float> o((size_t)9 * L.cin * L.cout);
+            for (int co = 0; co < L.cout; ++co) for (int ci = 0; ci < L.cin; ++ci) for (int ky = 0; ky < 3; ++ky) for (int kx = 0; kx < 3; ++kx)
+                o[(((size_t)ky * 3 + kx) * L.cin + ci) * L.cout + co] = wp[(((size_t)co * L.cin + ci) * 3 + ky) * 3 + kx];
+            rc = upload(c, &c->w.direct[i], o);
+        } else {
+            const int coutp = (L.cout + 31) / 32 * 32;
+            rc = upload(c, &c->w.mfma[i], pack_mfma(wp, L.cout, L.cin, L.ks, coutp));
+            if (rc == XFH_OK && L.ks == 3 && L.cin >= 64 && L.stride == 1 && i != 10 && i != 11)       // 7, 16, 17 and 13, 14: 32-channel chunks
+                rc = upload(c, &c->w.alt[i], pack_mfma(wp, L.cout, L.cin, L.ks, coutp, 32));
+            if (rc == XFH_OK && L.ks == 3 && L.cin == 64 && L.cout == 64 && L.stride == 1)                 // 7, 10, 11, 16, 17: three taps per chunk
+                rc = upload(c, &c->w.alt2[i], pack_mfma(wp, L.cout, L.cin, L.ks, coutp, 64, 3));
+            if (rc == XFH_OK && L.ks == 3 && L.cin <= 24 && L.cout == 24)                              // 3, 4, 5: all nine taps in one chunk (persistent kernels, block1.3)
+                rc = upload(c, &c->w.alt[i], pack_mfma(wp, L.cout, L.cin, L.ks, coutp, 64, 9));
+        }
+        if (rc != XFH_OK) return rc;
+        if (running) {
+            // statistics slots of every frame: the file's values, or the identity when they are folded into the weights (the stored
+            // maps are then already activated, and relu((x - 0) * 1) leaves them unchanged in every consumer); k_bn_finalize is never launched
             std::vector<float> st((size_t)c->cfg.max_batch * 2 * L.cout);
             for (int b = 0; b < c->cfg.max_batch; ++b)
                 for (int ch = 0; ch < L.cout; ++ch) {
-                    st[(size_t)b * 2 * L.cout + ch] = em.p[ch];
-                    st[(size_t)b * 2 * L.cout + L.cout + ch] = (float)(1.0 / sqrt((double)ev.p[ch] + 1e-5));
+                    st[(size_t)b * 2 * L.cout + ch] = folded ? 0.f : mean[ch];
+                    st[(size_t)b * 2 * L.cout + L.cout + ch] = folded ? 1.f : rstd[ch];
                 }
             HIPCK(c, hipMemcpy(c->stat[i], st.data(), st.size() * sizeof(float), hipMemcpyHostToDevice));
+            if (folded) {
+                std::vector<float> bb((size_t)((L.cout + 31) / 32 * 32), 0.f);
+                for (int ch = 0; ch < L.cout; ++ch) bb[ch] = -mean[ch] * rstd[ch];
+                if ((rc = upload(c, &c->w.bn_bias[i], bb)) != XFH_OK) return rc;
+            }
         }
     }
     int rc;
@@ -362,7 +380,7 @@ int xfh_extract_batch(xfh_ctx* c, const uint8_t* gray, int B, int H, int W, int 
 static void twin_share_weights(xfh_ctx* c) {
     xfh_ctx* t = c->twin;
     t->w = c->w;
-    if (c->cfg.bn_mode == XFH_BN_RUNNING_STATS && c->w.loaded)
+    if (c->cfg.bn_mode != XFH_BN_BATCH_STATS && c->w.loaded)
         for (int i = 0; i < XFH_NUM_LAYERS; ++i)
             hipMemcpy(t->stat[i], c->stat[i], sizeof(float) * 2 * XFH_LAYERS[i].cout, hipMemcpyDeviceToDevice);
 }

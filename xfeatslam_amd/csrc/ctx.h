@@ -11,6 +11,7 @@ struct DevWeights {
     float* mfma[XFH_NUM_LAYERS] = {};                          // layers 3..22: [chunk][n][CB], k-permuted
     float* alt2[XFH_NUM_LAYERS] = {};                          // third packing: three taps per chunk (small-batch configurations)
     float* alt[XFH_NUM_LAYERS] = {};                           // second packing of some layers (32-channel chunks / all taps in one chunk), see launch_basic_layer
+    float* bn_bias[XFH_NUM_LAYERS] = {};                       // XFH_BN_RUNNING_FOLDED: -running_mean * rstd per output channel (rstd is folded into the weights)
     float* fus2 = nullptr;                                     // block_fusion.2 packed like an MFMA layer
     float* fus2_bias = nullptr;                                // [64]
     float* skip_w = nullptr; float* skip_b = nullptr;          // [24] each

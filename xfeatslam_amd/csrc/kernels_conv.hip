@@ -45,7 +45,10 @@ struct ConvArgs {
 // PRO_PLAIN: input used as is; PRO_BN: relu((x - mean) * rstd) of the producer; PRO_IN: InstanceNorm of the image;
 // PRO_B2IN / PRO_FUSE: the two element-wise glue steps of the backbone computed while staging (no intermediate tensor)
 enum { PRO_PLAIN = 0, PRO_BN = 1, PRO_IN = 2, PRO_B2IN = 3, PRO_FUSE = 4 };
-enum { EPI_STATS = 0, EPI_BIAS = 1 };
+// EPI_STATS: raw map + fp64 statistic partials (BasicLayer in batch-statistics mode); EPI_BIAS: + bias, no statistics
+// (block_fusion.2); EPI_BIAS_RELU: relu(. + bias) -- a BasicLayer whose BatchNorm was folded into weights and bias at load
+// (XFH_BN_RUNNING_FOLDED): the stored map is already activated and its consumers see identity statistics
+enum { EPI_STATS = 0, EPI_BIAS = 1, EPI_BIAS_RELU = 2 };
 
 // ATen upsample_bilinear2d (align_corners=false) source index / weights; see oracle lin_coeff
 __device__ __forceinline__ void lin_coeff_c(int in, int out, int d, int& i0, int& i1, float& l0, float& l1) {
@@ -101,7 +104,7 @@ void k_bn_finalize(const double* __restrict__ part, size_t part_stride, int npar
 // FOLD (small batches, PRO_BN): the workgroup folds the producer's statistic partials itself (LDS); otherwise the
 // finalised statistics come through the scalar cache -- staging them through LDS first would put a second dependent
 // memory round trip into every workgroup's latency chain, which is what bounds these kernels (measured 3.5x slower).
-template <int CIN, int COUT, int ST, int PRO, bool FOLD>
+template <int CIN, int COUT, int ST, int PRO, bool FOLD, int EPI>
 __global__ __launch_bounds__(256)
 void k_conv_direct(ConvArgs a) {
     constexpr int TI = 15 * ST + 3;
@@ -172,12 +175,17 @@ void k_conv_direct(ConvArgs a) {
 
     const int oy = ty0 + ty, ox = tx0 + tx;
     const bool valid = oy < a.Hout && ox < a.Wout;
+    if constexpr (EPI == EPI_BIAS_RELU) {
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) acc[co] = fmaxf(acc[co] + a.bias[co], 0.f);      // folded BatchNorm + ReLU
+    }
     if (valid) {
         float* o = a.out + (size_t)b * a.out_stride + ((size_t)oy * a.Wout + ox) * COUT;
 #pragma unroll
         for (int g = 0; g < COUT / 4; ++g)
             *(f32x4*)(o + g * 4) = f32x4{acc[g * 4], acc[g * 4 + 1], acc[g * 4 + 2], acc[g * 4 + 3]};
     }
+    if constexpr (EPI != EPI_STATS) return;
     // per-channel fp64 partial sums of this tile
 #pragma unroll
     for (int co = 0; co < COUT; ++co) s_out[t * (COUT + 1) + co] = valid ? acc[co] : 0.f;
@@ -208,9 +216,19 @@ void k_conv_direct(ConvArgs a) {
 // (The conv kernels issue their VALU instructions on the same pipe as the f32 MFMA: PMC showed 2.5-9 VALU
 // instructions per MFMA in these kernels, most of them address arithmetic.)  Statistics: fp64 (sum, sum^2) per channel
 // over the lane's valid pixels in register order -- the order is part of the numerics contract.
+// the lane's NT bias values; issued before the K loop so that the epilogue never waits for a global load
+template <int COUT, int NT, int EPI>
+__device__ __forceinline__ void conv_bias(const float* __restrict__ bias, int co0, float (&bv)[NT]) {
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        bv[n] = 0.f;
+        if constexpr (EPI != EPI_STATS) bv[n] = (COUT % 32 == 0 || co0 + n * 32 < COUT) ? bias[co0 + n * 32] : 0.f;
+    }
+}
+
 template <int COUT, int NT, int WW, int WH, int EPI>
 __device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[NT], float* __restrict__ wave_out /* pixel (0,0) of the wave's block */, int Wout,
-                                              int rows_left, int cols_left, int co0, int h, const float* __restrict__ bias,
+                                              int rows_left, int cols_left, int co0, int h, const float (&bias)[NT] /* conv_bias(): loaded before the K loop */,
                                               double (&sum)[NT], double (&sq)[NT]) {
     static_assert(WW >= 8 && WW * WH == 32, "pixel block of a wave");
     XFH_MFMA_SETTLE();                                              // common.h: the epilogue branches
@@ -221,8 +239,7 @@ __device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[NT], float* __
     for (int n = 0; n < NT; ++n) {
         const int co = co0 + n * 32;
         sum[n] = 0.0; sq[n] = 0.0;
-        float bv = 0.f;
-        if constexpr (EPI == EPI_BIAS) bv = (COUT % 32 == 0 || co < COUT) ? bias[co] : 0.f;
+        const float bv = bias[n];
         const bool cok = COUT % 32 == 0 || co < COUT;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -232,7 +249,8 @@ __device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[NT], float* __
             const bool ok = full ? cok : (cok && prow < rows_left && pcol + 4 * h < cols_left);
             if (ok) {
                 float v = acc[n][r];
-                if constexpr (EPI == EPI_BIAS) v += bv;
+                if constexpr (EPI != EPI_STATS) v += bv;
+                if constexpr (EPI == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
                 dst[lane_off] = v;
                 if constexpr (EPI == EPI_STATS) { const double dv = (double)v; sum[n] += dv; sq[n] = fma(dv, dv, sq[n]); }
             }
@@ -347,6 +365,8 @@ void k_conv_mfma(ConvArgs a) {
     const int pr = i / WW, pc = i % WW;                     // pixel of this lane inside the wave tile
     const int ly = (wm * WH + pr) * ST, lx = pc * ST;        // its top-left input position in the tile
 
+    float biasv[NT];
+    conv_bias<COUT, NT, EPI>(a.bias, wn * NT * 32 + i, biasv);
     f32x16 acc[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n)
@@ -399,7 +419,7 @@ void k_conv_mfma(ConvArgs a) {
     {
         const int oy0 = ty0 + wm * WH;
         float* wave_out = a.out + (size_t)b * a.out_stride + ((size_t)oy0 * a.Wout + tx0) * COUT;
-        conv_epilogue<COUT, NT, WW, WH, EPI>(acc, wave_out, a.Wout, a.Hout - oy0, a.Wout - tx0, wn * NT * 32 + i, h, a.bias, sum, sq);
+        conv_epilogue<COUT, NT, WW, WH, EPI>(acc, wave_out, a.Wout, a.Hout - oy0, a.Wout - tx0, wn * NT * 32 + i, h, biasv, sum, sq);
     }
     if constexpr (EPI == EPI_STATS) {
         double* s_red = (double*)smem;        // [WM][COUTP][2], the tiles are no longer needed
@@ -527,6 +547,8 @@ void k_conv_mfma_p(ConvArgs a, int ntile, int total) {
 
     int tile = blockIdx.x;
     if (tile >= total) return;
+    float biasv[NT];
+    conv_bias<COUT, NT, EPI>(a.bias, wn * NT * 32 + i, biasv);
     load_tile(tile);
     store_tile(tile);
     __syncthreads();                              // weights and the first tile are in LDS
@@ -565,7 +587,7 @@ void k_conv_mfma_p(ConvArgs a, int ntile, int total) {
         {
             const int oy0 = ty0 + wm * WH;
             float* wave_out = a.out + (size_t)b * a.out_stride + ((size_t)oy0 * a.Wout + tx0) * COUT;
-            conv_epilogue<COUT, NT, WW, WH, EPI>(acc, wave_out, a.Wout, a.Hout - oy0, a.Wout - tx0, wn * NT * 32 + i, h, a.bias, sum, sq);
+            conv_epilogue<COUT, NT, WW, WH, EPI>(acc, wave_out, a.Wout, a.Hout - oy0, a.Wout - tx0, wn * NT * 32 + i, h, biasv, sum, sq);
         }
         if constexpr (EPI == EPI_STATS) {
 #pragma unroll
@@ -659,8 +681,9 @@ static hipError_t conv_direct_launch(xfh_ctx* c, const ConvArgs& a, int B, int* 
     aa.tiles_x = (a.Wout + 15) / 16;
     const int ntile = aa.tiles_x * ((a.Hout + 15) / 16);
     if (npart_out) *npart_out = ntile;
-    if (PRO == PRO_BN && a.st.part) launch_k(c, XFH_K_CONV_DIRECT, layer, k_conv_direct<CIN, COUT, ST, PRO, PRO == PRO_BN>, dim3(ntile, 1, B), dim3(256), 0, aa);
-    else launch_k(c, XFH_K_CONV_DIRECT, layer, k_conv_direct<CIN, COUT, ST, PRO, false>, dim3(ntile, 1, B), dim3(256), 0, aa);
+    if (a.bias) launch_k(c, XFH_K_CONV_DIRECT, layer, k_conv_direct<CIN, COUT, ST, PRO, false, EPI_BIAS_RELU>, dim3(ntile, 1, B), dim3(256), 0, aa);
+    else if (PRO == PRO_BN && a.st.part) launch_k(c, XFH_K_CONV_DIRECT, layer, k_conv_direct<CIN, COUT, ST, PRO, PRO == PRO_BN, EPI_STATS>, dim3(ntile, 1, B), dim3(256), 0, aa);
+    else launch_k(c, XFH_K_CONV_DIRECT, layer, k_conv_direct<CIN, COUT, ST, PRO, false, EPI_STATS>, dim3(ntile, 1, B), dim3(256), 0, aa);
     return hipGetLastError();
 }
 
@@ -680,7 +703,7 @@ int conv_layer_npart(int li, int Hout, int Wout) {
 StatSrc stat_src(xfh_ctx* c, int j, int B) {
     StatSrc s{};
     s.stat = c->stat[j];
-    if (c->cfg.bn_mode != XFH_BN_RUNNING_STATS && consumer_fold(B)) {
+    if (c->cfg.bn_mode == XFH_BN_BATCH_STATS && consumer_fold(B)) {
         s.part = c->part[j]; s.part_stride = c->part_stride[j]; s.npart = c->npart[j];
         s.count = (double)c->lh[j] * (double)c->lw[j]; s.stat_out = c->stat[j];
     }
@@ -690,7 +713,8 @@ StatSrc stat_src(xfh_ctx* c, int j, int B) {
 // BasicLayer li: conv + statistics partials (+ finalize for large batches).  `in`: producer tensor; src >= 0: the
 // BasicLayer whose BatchNorm + ReLU is applied while staging (PRO_BN / PRO_B2IN / PRO_FUSE), src == -1: plain input,
 // src == -2: InstanceNorm of the image (block1.0).
-hipError_t launch_basic_layer(xfh_ctx* c, int li, const float* in, size_t in_stride, int src, int pro, int Hin, int Win, int B) {
+template <int EPI>
+static hipError_t launch_basic_layer_t(xfh_ctx* c, int li, const float* in, size_t in_stride, int src, int pro, int Hin, int Win, int B) {
     const LayerSpec& L = XFH_LAYERS[li];
     const int pad = L.ks / 2;
     const int Hout = (Hin + 2 * pad - L.ks) / L.stride + 1, Wout = (Win + 2 * pad - L.ks) / L.stride + 1;
@@ -700,10 +724,10 @@ hipError_t launch_basic_layer(xfh_ctx* c, int li, const float* in, size_t in_str
     if (src >= 0) a.st = stat_src(c, src, B);
     else if (src == -2) a.st.stat = c->xstat;
     a.w = (li < 3) ? c->w.direct[li] : c->w.mfma[li];
-    a.bias = nullptr;
+    a.bias = (EPI == EPI_BIAS_RELU) ? c->w.bn_bias[li] : nullptr;
     a.out = c->raw[li]; a.out_stride = c->raw_stride[li]; a.Hout = Hout; a.Wout = Wout;
     a.part = c->part[li]; a.part_stride = c->part_stride[li];
-    const bool running = c->cfg.bn_mode == XFH_BN_RUNNING_STATS;
+    const bool running = c->cfg.bn_mode != XFH_BN_BATCH_STATS;
     if (pro == PRO_B2IN) {
         const size_t xs = (size_t)c->Hmax * c->Wmax;
         a.pool = c->skip_pool; a.pool_stride = xs / 16; a.skip_w = c->w.skip_w; a.skip_b = c->w.skip_b;
@@ -722,18 +746,18 @@ hipError_t launch_basic_layer(xfh_ctx* c, int li, const float* in, size_t in_str
             // all nine taps of the weights in one LDS chunk (no barrier inside the K = 72 loop): 49.5 -> 46.2 us at B = 32;
             // the same form measured slower for the 24 -> 24 layers (95 vs 91 us)
             a.w = c->w.alt[li];
-            if (persistent(B)) e = conv_mfma_p_launch<8, 24, 3, 2, 4, 1, 1, 16, PRO_BN, EPI_STATS>(c, a, B, &np, li);
-            else e = conv_mfma_launch<8, 24, 3, 2, 4, 1, 1, 16, PRO_BN, EPI_STATS, 64, 9>(c, a, B, &np, li);
+            if (persistent(B)) e = conv_mfma_p_launch<8, 24, 3, 2, 4, 1, 1, 16, PRO_BN, EPI>(c, a, B, &np, li);
+            else e = conv_mfma_launch<8, 24, 3, 2, 4, 1, 1, 16, PRO_BN, EPI, 64, 9>(c, a, B, &np, li);
             break;
         case 4:                                                                                                 // input = relu(bn(block1.3)) + skip1(x), computed while staging
-            if (persistent(B)) { a.w = c->w.alt[li]; e = conv_mfma_p_launch<24, 24, 3, 1, 4, 1, 1, 16, PRO_B2IN, EPI_STATS>(c, a, B, &np, li); }
-            else e = conv_mfma_launch<24, 24, 3, 1, 4, 1, 1, 16, PRO_B2IN, EPI_STATS>(c, a, B, &np, li);
+            if (persistent(B)) { a.w = c->w.alt[li]; e = conv_mfma_p_launch<24, 24, 3, 1, 4, 1, 1, 16, PRO_B2IN, EPI>(c, a, B, &np, li); }
+            else e = conv_mfma_launch<24, 24, 3, 1, 4, 1, 1, 16, PRO_B2IN, EPI>(c, a, B, &np, li);
             break;
         case 5:
-            if (persistent(B)) { a.w = c->w.alt[li]; e = conv_mfma_p_launch<24, 24, 3, 1, 4, 1, 1, 16, PRO_BN, EPI_STATS>(c, a, B, &np, li); }
-            else e = conv_mfma_launch<24, 24, 3, 1, 4, 1, 1, 16, PRO_BN, EPI_STATS>(c, a, B, &np, li);
+            if (persistent(B)) { a.w = c->w.alt[li]; e = conv_mfma_p_launch<24, 24, 3, 1, 4, 1, 1, 16, PRO_BN, EPI>(c, a, B, &np, li); }
+            else e = conv_mfma_launch<24, 24, 3, 1, 4, 1, 1, 16, PRO_BN, EPI>(c, a, B, &np, li);
             break;
-        case 6: e = conv_mfma_launch<24, 64, 3, 2, 4, 1, 2, 16, PRO_BN, EPI_STATS>(c, a, B, &np, li); break;
+        case 6: e = conv_mfma_launch<24, 64, 3, 2, 4, 1, 2, 16, PRO_BN, EPI>(c, a, B, &np, li); break;
         case 7: case 17: case 16:
             // the dominant 3x3 64->64 instance: 8x16 pixels x 64 channels per workgroup, 8 waves (4 x 2), 32-channel weight
             // chunks (67 KB LDS -> 2 workgroups per CU); measured 70 us vs 77 us for the 4-wave / 64-channel-chunk form at
@@ -741,36 +765,36 @@ hipError_t launch_basic_layer(xfh_ctx* c, int li, const float* in, size_t in_str
             // block_fusion.0 (16) builds its input x3 + up2(x4) + up4(x5) while staging.
             if (small_batch(B)) {
                 a.w = c->w.alt2[li];
-                if (li == 16) e = conv_mfma_launch<64, 64, 3, 1, 1, 2, 1, 16, PRO_FUSE, EPI_STATS, 64, 3>(c, a, B, &np, li);
-                else e = conv_mfma_launch<64, 64, 3, 1, 1, 2, 1, 16, PRO_BN, EPI_STATS, 64, 3>(c, a, B, &np, li);
+                if (li == 16) e = conv_mfma_launch<64, 64, 3, 1, 1, 2, 1, 16, PRO_FUSE, EPI, 64, 3>(c, a, B, &np, li);
+                else e = conv_mfma_launch<64, 64, 3, 1, 1, 2, 1, 16, PRO_BN, EPI, 64, 3>(c, a, B, &np, li);
             } else {
                 a.w = c->w.alt[li];
-                if (li == 16) e = conv_mfma_launch<64, 64, 3, 1, 4, 2, 1, 16, PRO_FUSE, EPI_STATS, 32>(c, a, B, &np, li);
-                else e = conv_mfma_launch<64, 64, 3, 1, 4, 2, 1, 16, PRO_BN, EPI_STATS, 32>(c, a, B, &np, li);
+                if (li == 16) e = conv_mfma_launch<64, 64, 3, 1, 4, 2, 1, 16, PRO_FUSE, EPI, 32>(c, a, B, &np, li);
+                else e = conv_mfma_launch<64, 64, 3, 1, 4, 2, 1, 16, PRO_BN, EPI, 32>(c, a, B, &np, li);
             }
             break;
         case 8:
-            if (persistent(B)) e = conv_mfma_p_launch<64, 64, 1, 1, 4, 1, 2, 16, PRO_BN, EPI_STATS>(c, a, B, &np, li);
-            else e = conv_mfma_launch<64, 64, 1, 1, 4, 1, 2, 16, PRO_BN, EPI_STATS>(c, a, B, &np, li);
+            if (persistent(B)) e = conv_mfma_p_launch<64, 64, 1, 1, 4, 1, 2, 16, PRO_BN, EPI>(c, a, B, &np, li);
+            else e = conv_mfma_launch<64, 64, 1, 1, 4, 1, 2, 16, PRO_BN, EPI>(c, a, B, &np, li);
             break;
-        case 9: e = conv_mfma_launch<64, 64, 3, 2, 2, 2, 1, 8, PRO_BN, EPI_STATS>(c, a, B, &np, li); break;
+        case 9: e = conv_mfma_launch<64, 64, 3, 2, 2, 2, 1, 8, PRO_BN, EPI>(c, a, B, &np, li); break;
         case 10: case 11:
-            if (small_batch(B)) { a.w = c->w.alt2[li]; e = conv_mfma_launch<64, 64, 3, 1, 2, 2, 1, 8, PRO_BN, EPI_STATS, 64, 3>(c, a, B, &np, li); }   // three taps per chunk
-            else e = conv_mfma_launch<64, 64, 3, 1, 2, 2, 1, 8, PRO_BN, EPI_STATS>(c, a, B, &np, li);
+            if (small_batch(B)) { a.w = c->w.alt2[li]; e = conv_mfma_launch<64, 64, 3, 1, 2, 2, 1, 8, PRO_BN, EPI, 64, 3>(c, a, B, &np, li); }   // three taps per chunk
+            else e = conv_mfma_launch<64, 64, 3, 1, 2, 2, 1, 8, PRO_BN, EPI>(c, a, B, &np, li);
             break;
-        case 12: e = conv_mfma_launch<64, 128, 3, 2, 1, 4, 1, 8, PRO_BN, EPI_STATS>(c, a, B, &np, li); break;
+        case 12: e = conv_mfma_launch<64, 128, 3, 2, 1, 4, 1, 8, PRO_BN, EPI>(c, a, B, &np, li); break;
         case 13: case 14:       // 32-channel weight chunks: 69 KB LDS -> 2 workgroups per CU, 58 -> 50 us at B = 32
-            if (!small_batch(B)) { a.w = c->w.alt[li]; e = conv_mfma_launch<128, 128, 3, 1, 1, 4, 1, 8, PRO_BN, EPI_STATS, 32>(c, a, B, &np, li); }
-            else e = conv_mfma_launch<128, 128, 3, 1, 1, 4, 1, 8, PRO_BN, EPI_STATS>(c, a, B, &np, li);
+            if (!small_batch(B)) { a.w = c->w.alt[li]; e = conv_mfma_launch<128, 128, 3, 1, 1, 4, 1, 8, PRO_BN, EPI, 32>(c, a, B, &np, li); }
+            else e = conv_mfma_launch<128, 128, 3, 1, 1, 4, 1, 8, PRO_BN, EPI>(c, a, B, &np, li);
             break;
-        case 15: e = conv_mfma_launch<128, 64, 1, 1, 1, 2, 1, 8, PRO_BN, EPI_STATS>(c, a, B, &np, li); break;
+        case 15: e = conv_mfma_launch<128, 64, 1, 1, 1, 2, 1, 8, PRO_BN, EPI>(c, a, B, &np, li); break;
         case 18: case 20:                                                                                      // inputs: feats / unfold(xhat)
-            if (persistent(B)) e = conv_mfma_p_launch<64, 64, 1, 1, 4, 1, 2, 16, PRO_PLAIN, EPI_STATS>(c, a, B, &np, li);
-            else e = conv_mfma_launch<64, 64, 1, 1, 4, 1, 2, 16, PRO_PLAIN, EPI_STATS>(c, a, B, &np, li);
+            if (persistent(B)) e = conv_mfma_p_launch<64, 64, 1, 1, 4, 1, 2, 16, PRO_PLAIN, EPI>(c, a, B, &np, li);
+            else e = conv_mfma_launch<64, 64, 1, 1, 4, 1, 2, 16, PRO_PLAIN, EPI>(c, a, B, &np, li);
             break;
         case 19: case 21: case 22:
-            if (persistent(B)) e = conv_mfma_p_launch<64, 64, 1, 1, 4, 1, 2, 16, PRO_BN, EPI_STATS>(c, a, B, &np, li);
-            else e = conv_mfma_launch<64, 64, 1, 1, 4, 1, 2, 16, PRO_BN, EPI_STATS>(c, a, B, &np, li);
+            if (persistent(B)) e = conv_mfma_p_launch<64, 64, 1, 1, 4, 1, 2, 16, PRO_BN, EPI>(c, a, B, &np, li);
+            else e = conv_mfma_launch<64, 64, 1, 1, 4, 1, 2, 16, PRO_BN, EPI>(c, a, B, &np, li);
             break;
         default: return hipErrorInvalidValue;
     }
@@ -780,6 +804,11 @@ hipError_t launch_basic_layer(xfh_ctx* c, int li, const float* in, size_t in_str
     hipLaunchKernelGGL(k_bn_finalize, dim3(B), dim3(256), 0, c->stream, (const double*)c->part[li], c->part_stride[li], np,
                        L.cout, (double)Hout * (double)Wout, c->stat[li]);
     return hipGetLastError();
+}
+
+hipError_t launch_basic_layer(xfh_ctx* c, int li, const float* in, size_t in_stride, int src, int pro, int Hin, int Win, int B) {
+    if (c->cfg.bn_mode == XFH_BN_RUNNING_FOLDED) return launch_basic_layer_t<EPI_BIAS_RELU>(c, li, in, in_stride, src, pro, Hin, Win, B);
+    return launch_basic_layer_t<EPI_STATS>(c, li, in, in_stride, src, pro, Hin, Win, B);
 }
 
 // block_fusion.2: Conv2d(64,64,1) with bias, no BN (src/XFeat.cc:75) -> feats

@@ -24,7 +24,7 @@ class Context:
         lib().xfh_config_default(C.byref(cfg))
         cfg.device, cfg.max_height, cfg.max_width = device, max_height, max_width
         cfg.nfeatures, cfg.max_batch, cfg.nms_threshold = nfeatures, max_batch, nms_threshold
-        cfg.bn_mode = bn_mode          # 0 = batch statistics (the reference), 1 = running statistics (upstream eval())
+        cfg.bn_mode = bn_mode          # 0 = batch statistics (the reference), 1 = running statistics (upstream eval()), 2 = the same folded into the weights
         cfg.flags = flags              # capi.FLAG_*; 0 = the reference's behaviour
         h = C.c_void_p()
         check(lib().xfh_create(C.byref(cfg), C.byref(h)))
