@@ -110,7 +110,7 @@ int xfh_create(const xfh_config* cfg, xfh_ctx** out) {
     for (int i = 0; i < XFH_NUM_LAYERS; ++i) {
         const int C = XFH_LAYERS[i].cout;
         c->raw_stride[i] = (size_t)lh[i] * lw[i] * C;
-        A(c->raw[i], sizeof(float) * B * c->raw_stride[i]);
+        if (i != 0) A(c->raw[i], sizeof(float) * B * c->raw_stride[i]);        // block1.0 is never materialised (k_block1_stats / PRO_L0)
         c->part_stride[i] = (size_t)conv_layer_npart(i, lh[i], lw[i]) * C * 2;
         A(c->part[i], sizeof(double) * B * c->part_stride[i]);
         A(c->stat[i], sizeof(float) * B * 2 * C);
@@ -738,6 +738,7 @@ int xfh_debug_tensor(xfh_ctx* c, int id, int frame, float* out, size_t cap, size
         default:
             if (id >= XFH_T_RAW0 && id < XFH_T_RAW0 + XFH_NUM_LAYERS) {
                 const int i = id - XFH_T_RAW0;
+                if (!c->raw[i]) return XFH_ERR_INVALID_ARG;                    // block1.0
                 src = c->raw[i] + frame * c->raw_stride[i]; n = (size_t)c->lh[i] * c->lw[i] * XFH_LAYERS[i].cout;
             } else if (id >= XFH_T_STAT0 && id < XFH_T_STAT0 + XFH_NUM_LAYERS) {
                 const int i = id - XFH_T_STAT0;

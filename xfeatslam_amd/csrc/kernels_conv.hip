@@ -40,11 +40,14 @@ struct ConvArgs {
     // PRO_FUSE (block_fusion.0: input = x3 + up2(x4) + up4(x5), XFeat.cc:159-166): `in` / st are block3.2 (x3)
     const float* r4; size_t s4; int H4, W4; StatSrc st4;      // block4.2
     const float* r5; size_t s5; int H5, W5; StatSrc st5;      // block5.3
+    // PRO_L0 (block1.1: its input relu(bn(block1.0)) is recomputed from the image while staging): `in` = image X, st = statistics of
+    // block1.0, xstat = InstanceNorm statistics [B][2], w0 = block1.0 weights [9][4], bias0 = its folded-BN bias (EPI_BIAS_RELU) or null
+    const float* xstat; const float* w0; const float* bias0;
 };
 
 // PRO_PLAIN: input used as is; PRO_BN: relu((x - mean) * rstd) of the producer; PRO_IN: InstanceNorm of the image;
 // PRO_B2IN / PRO_FUSE: the two element-wise glue steps of the backbone computed while staging (no intermediate tensor)
-enum { PRO_PLAIN = 0, PRO_BN = 1, PRO_IN = 2, PRO_B2IN = 3, PRO_FUSE = 4 };
+enum { PRO_PLAIN = 0, PRO_BN = 1, PRO_IN = 2, PRO_B2IN = 3, PRO_FUSE = 4, PRO_L0 = 5 };
 // EPI_STATS: raw map + fp64 statistic partials (BasicLayer in batch-statistics mode); EPI_BIAS: + bias, no statistics
 // (block_fusion.2); EPI_BIAS_RELU: relu(. + bias) -- a BasicLayer whose BatchNorm was folded into weights and bias at load
 // (XFH_BN_RUNNING_FOLDED): the stored map is already activated and its consumers see identity statistics
@@ -100,6 +103,87 @@ void k_bn_finalize(const double* __restrict__ part, size_t part_stride, int npar
 }
 
 // ------------------------------------------------------------------------------------
+// block1.0 (Conv 1->4, 3x3 on the InstanceNorm'ed image) is never written to HBM: at full resolution its 4-channel map is
+// the largest tensor of the network (4.9 MB per VGA frame, written once and read once = 2.5 GB per 256-frame batch), while
+// computing it costs 36 fma per pixel.  k_block1_stats makes the one pass its BatchNorm statistics need (image in, fp64
+// partials out), and block1.1 recomputes the values it consumes while staging its input tile (PRO_L0 in k_conv_direct).
+// Both evaluate l0_conv() on the same normalised pixels, so the statistics describe exactly the values that are used.
+__device__ __forceinline__ double wave_sum_f64(double v) {
+    v += __shfl_xor(v, 32); v += __shfl_xor(v, 16); v += __shfl_xor(v, 8);
+    v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
+    return v;
+}
+// win: 3x3 window of the normalised image (zero outside: Conv2d padding); w: [9][4], wave-uniform.  Two channels per
+// v_pk_fma_f32 (the same IEEE fma per channel as the scalar chain, in the same tap order).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void l0_conv(const float (&win)[9], const float* __restrict__ w, float (&acc)[4]) {
+    f32x2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const f32x2 v = {win[k], win[k]};
+        a0 = __builtin_elementwise_fma(v, f32x2{w[k * 4], w[k * 4 + 1]}, a0);
+        a1 = __builtin_elementwise_fma(v, f32x2{w[k * 4 + 2], w[k * 4 + 3]}, a1);
+    }
+    acc[0] = a0.x; acc[1] = a0.y; acc[2] = a1.x; acc[3] = a1.y;
+}
+
+// grid (tiles of 128 x 32 pixels, 1, B), 256 threads = 32 x 8: a thread owns a strip of 4 pixels x 4 rows and slides a
+// 3 x 6 register window down it; the image comes straight from global memory (one 16-byte load + the two halo pixels per
+// row, the overlap between neighbours is served by the vector L1) -- no LDS staging, one barrier for the 4-wave fold.
+constexpr int L0S_TW = 128, L0S_TH = 32, L0S_R = 4;
+__global__ __launch_bounds__(256)
+void k_block1_stats(const float* __restrict__ X, size_t x_stride, const float* __restrict__ xstat, int H, int W, int tiles_x,
+                    const float* __restrict__ w0, double* __restrict__ part, size_t part_stride) {
+    __shared__ double s_red[4 * 8];
+    const int t = threadIdx.x, b = blockIdx.z, tile = blockIdx.x;
+    const int gx = (tile % tiles_x) * L0S_TW + (t & 31) * 4, gy0 = (tile / tiles_x) * L0S_TH + (t >> 5) * L0S_R;
+    const float* x = X + (size_t)b * x_stride;
+    const float m = xstat[b * 2], r = xstat[b * 2 + 1];
+    // row gy of the normalised, zero-padded image at columns gx-1 .. gx+4 (W % 4 == 0: the 16-byte load is all in or all out)
+    auto load_row = [&](int gy, float (&row)[6]) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) row[j] = 0.f;
+        if (gy >= 0 && gy < H) {
+            const float* p = x + (size_t)gy * W + gx;
+            if (gx < W) {
+                const f32x4 v = *(const f32x4*)p;
+                row[1] = (v.x - m) * r; row[2] = (v.y - m) * r; row[3] = (v.z - m) * r; row[4] = (v.w - m) * r;
+            }
+            if (gx > 0 && gx - 1 < W) row[0] = (p[-1] - m) * r;
+            if (gx + 4 < W) row[5] = (p[4] - m) * r;
+        }
+    };
+    float win[3][6];
+    load_row(gy0 - 1, win[0]);
+    load_row(gy0, win[1]);
+    double sum[4] = {0.0, 0.0, 0.0, 0.0}, sq[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int i = 0; i < L0S_R; ++i) {
+        load_row(gy0 + i + 1, win[(i + 2) % 3]);
+        const float (&r0)[6] = win[i % 3], (&r1)[6] = win[(i + 1) % 3], (&r2)[6] = win[(i + 2) % 3];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float wq[9] = {r0[q], r0[q + 1], r0[q + 2], r1[q], r1[q + 1], r1[q + 2], r2[q], r2[q + 1], r2[q + 2]};
+            float acc[4];
+            l0_conv(wq, w0, acc);
+            if (gy0 + i < H && gx + q < W) {
+#pragma unroll
+                for (int co = 0; co < 4; ++co) { const double d = (double)acc[co]; sum[co] += d; sq[co] = fma(d, d, sq[co]); }
+            }
+        }
+    }
+#pragma unroll
+    for (int co = 0; co < 4; ++co) { sum[co] = wave_sum_f64(sum[co]); sq[co] = wave_sum_f64(sq[co]); }
+    if ((t & 63) == 0) {
+#pragma unroll
+        for (int co = 0; co < 4; ++co) { s_red[(t >> 6) * 8 + co * 2] = sum[co]; s_red[(t >> 6) * 8 + co * 2 + 1] = sq[co]; }
+    }
+    __syncthreads();
+    if (t < 8)
+        part[(size_t)b * part_stride + (size_t)tile * 8 + t] = (s_red[t] + s_red[8 + t]) + (s_red[16 + t] + s_red[24 + t]);
+}
+
+// ------------------------------------------------------------------------------------
 // direct convolution 3x3 for block1.  16x16 output pixels per workgroup.
 // FOLD (small batches, PRO_BN): the workgroup folds the producer's statistic partials itself (LDS); otherwise the
 // finalised statistics come through the scalar cache -- staging them through LDS first would put a second dependent
@@ -109,8 +193,10 @@ __global__ __launch_bounds__(256)
 void k_conv_direct(ConvArgs a) {
     constexpr int TI = 15 * ST + 3;
     constexpr int SL = 256 / COUT;
+    static_assert(PRO != PRO_L0 || (CIN == 4 && ST == 2 && COUT == 8), "PRO_L0 is block1.1");
+    constexpr int XW = TI + 2, XS = XW + 1;      // PRO_L0: image window of the tile's block1.0 inputs, row stride
     __shared__ __attribute__((aligned(16))) float s_in[TI * TI * CIN];
-    __shared__ __attribute__((aligned(16))) float s_out[256 * (COUT + 1)];
+    __shared__ __attribute__((aligned(16))) float s_out[(PRO == PRO_L0 && XW * XS > 256 * (COUT + 1)) ? XW * XS : 256 * (COUT + 1)];
     __shared__ double s_red[(SL * COUT * 2 > 512) ? SL * COUT * 2 : 512];
     const int t = threadIdx.x, b = blockIdx.z;
     const int tile = blockIdx.x, tx0 = (tile % a.tiles_x) * 16, ty0 = (tile / a.tiles_x) * 16;
@@ -122,26 +208,84 @@ void k_conv_direct(ConvArgs a) {
     // stage the activated input tile, zero outside the image (Conv2d zero padding)
     constexpr int VEC = (CIN >= 4) ? 4 : 1;
     constexpr int G = CIN / VEC;
-    for (int item = t; item < TI * TI * G; item += 256) {
-        const int pix = item / G, g = item % G;
-        const int iy = pix / TI, ix = pix % TI;
-        const int gy = ty0 * ST - 1 + iy, gx = tx0 * ST - 1 + ix;
-        const bool ok = gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win;
-        if constexpr (VEC == 4) {
+    if constexpr (PRO == PRO_L0) {
+        // block1.0 recomputed: normalised image window -> conv 1->4 -> BatchNorm + ReLU -> s_in (see k_block1_stats)
+        float* s_x = s_out;                                                                       // free until the epilogue
+        const float xm = a.xstat[b * 2], xr = a.xstat[b * 2 + 1];
+        // all loads of a thread are issued before the first use (clamped addresses, no branches around them)
+        constexpr int NX = (XW * XW + 255) / 256;
+        float xv[NX];
+#pragma unroll
+        for (int k = 0; k < NX; ++k) {
+            const int item = t + k * 256, iy = item / XW, ix = item % XW;
+            const int gy = ty0 * ST - 2 + iy, gx = tx0 * ST - 2 + ix;
+            xv[k] = in[(size_t)min(max(gy, 0), a.Hin - 1) * a.Win + min(max(gx, 0), a.Win - 1)];
+        }
+#pragma unroll
+        for (int k = 0; k < NX; ++k) {
+            const int item = t + k * 256, iy = item / XW, ix = item % XW;
+            const int gy = ty0 * ST - 2 + iy, gx = tx0 * ST - 2 + ix;
+            const bool ok = gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win;
+            if (item < XW * XW) s_x[iy * XS + ix] = ok ? (xv[k] - xm) * xr : 0.f;
+        }
+        __syncthreads();
+        for (int pix = t; pix < TI * TI; pix += 256) {
+            const int iy = pix / TI, ix = pix % TI;
+            const int gy = ty0 * ST - 1 + iy, gx = tx0 * ST - 1 + ix;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ok) {
-                v = *(const f32x4*)(in + ((size_t)gy * a.Win + gx) * CIN + g * 4);
+            if (gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win) {
+                const float* sp = s_x + iy * XS + ix;
+                const float win[9] = {sp[0], sp[1], sp[2], sp[XS], sp[XS + 1], sp[XS + 2], sp[2 * XS], sp[2 * XS + 1], sp[2 * XS + 2]};
+                float acc[4];
+                l0_conv(win, a.w0, acc);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float m = FOLD ? s_stat[g * 4 + q] : st[g * 4 + q], r = FOLD ? s_stat[CIN + g * 4 + q] : st[CIN + g * 4 + q];
-                    v[q] = fmaxf((v[q] - m) * r, 0.f);
+                    if constexpr (EPI == EPI_BIAS_RELU) v[q] = fmaxf(acc[q] + a.bias0[q], 0.f);
+                    else {
+                        const float m = FOLD ? s_stat[q] : st[q], r = FOLD ? s_stat[CIN + q] : st[CIN + q];
+                        v[q] = fmaxf((acc[q] - m) * r, 0.f);
+                    }
                 }
             }
-            *(f32x4*)(s_in + pix * CIN + g * 4) = v;
-        } else {
-            float v = 0.f;
-            if (ok) v = (in[(size_t)gy * a.Win + gx] - st[0]) * st[1];    // InstanceNorm, no ReLU
-            s_in[pix] = v;
+            *(f32x4*)(s_in + pix * CIN) = v;
+        }
+    } else
+    {
+        // a thread stages whole pixels (the channel group index is then a compile-time constant and the statistics stay in
+        // scalar registers); all loads are issued before the first use: clamped addresses, no branches around them
+        constexpr int NI = (TI * TI + 255) / 256;
+        f32x4 iv[NI][G];
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            const int pix = t + k * 256;
+            const int gy = min(max(ty0 * ST - 1 + pix / TI, 0), a.Hin - 1), gx = min(max(tx0 * ST - 1 + pix % TI, 0), a.Win - 1);
+            const float* p = in + ((size_t)gy * a.Win + gx) * CIN;
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                if constexpr (VEC == 4) iv[k][g] = *(const f32x4*)(p + g * 4);
+                else iv[k][g].x = p[0];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            const int pix = t + k * 256;
+            const int gy = ty0 * ST - 1 + pix / TI, gx = tx0 * ST - 1 + pix % TI;
+            const bool ok = gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win;
+            if (pix >= TI * TI) continue;
+            if constexpr (VEC == 4) {
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    f32x4 v = iv[k][g];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float m = FOLD ? s_stat[g * 4 + q] : st[g * 4 + q], r = FOLD ? s_stat[CIN + g * 4 + q] : st[CIN + g * 4 + q];
+                        v[q] = ok ? fmaxf((v[q] - m) * r, 0.f) : 0.f;
+                    }
+                    *(f32x4*)(s_in + pix * CIN + g * 4) = v;
+                }
+            } else {
+                s_in[pix] = ok ? (iv[k][0].x - st[0]) * st[1] : 0.f;        // InstanceNorm, no ReLU
+            }
         }
     }
     __syncthreads();
@@ -186,27 +330,26 @@ void k_conv_direct(ConvArgs a) {
             *(f32x4*)(o + g * 4) = f32x4{acc[g * 4], acc[g * 4 + 1], acc[g * 4 + 2], acc[g * 4 + 3]};
     }
     if constexpr (EPI != EPI_STATS) return;
-    // per-channel fp64 partial sums of this tile
+    // per-channel fp64 partial sums of this tile: thread (c, j) adds the pixels j, j + SL, ... of channel c, the slices
+    // of a wave are folded with shuffles and the four waves through LDS -- a fixed order, and no serial chain
 #pragma unroll
     for (int co = 0; co < COUT; ++co) s_out[t * (COUT + 1) + co] = valid ? acc[co] : 0.f;
     __syncthreads();
-    if (t < SL * COUT) {
+    {
         const int c = t % COUT, j = t / COUT;
         double s = 0.0, ss = 0.0;
-        for (int p = j; p < 256; p += SL) {
-            const double v = (double)s_out[p * (COUT + 1) + c];
+#pragma unroll
+        for (int p = 0; p < 256 / SL; ++p) {
+            const double v = (double)s_out[(j + p * SL) * (COUT + 1) + c];
             s += v; ss = fma(v, v, ss);
         }
-        s_red[(j * COUT + c) * 2 + 0] = s;
-        s_red[(j * COUT + c) * 2 + 1] = ss;
+#pragma unroll
+        for (int off = COUT; off < 64; off <<= 1) { s += __shfl_xor(s, off); ss += __shfl_xor(ss, off); }
+        if ((t & 63) < COUT) { s_red[((t >> 6) * COUT + c) * 2] = s; s_red[((t >> 6) * COUT + c) * 2 + 1] = ss; }
     }
     __syncthreads();
-    if (t < COUT) {
-        double S = 0.0, SS = 0.0;
-        for (int q = 0; q < SL; ++q) { S += s_red[(q * COUT + t) * 2 + 0]; SS += s_red[(q * COUT + t) * 2 + 1]; }
-        double* p = a.part + (size_t)b * a.part_stride + ((size_t)tile * COUT + t) * 2;
-        p[0] = S; p[1] = SS;
-    }
+    if (t < 2 * COUT)
+        a.part[(size_t)b * a.part_stride + (size_t)tile * COUT * 2 + t] = (s_red[t] + s_red[2 * COUT + t]) + (s_red[4 * COUT + t] + s_red[6 * COUT + t]);
 }
 
 // Epilogue shared by k_conv_mfma and k_conv_mfma_p.  C/D layout of v_mfma_f32_32x32x2_f32: a lane holds channel (lane&31) of
@@ -682,7 +825,7 @@ static hipError_t conv_direct_launch(xfh_ctx* c, const ConvArgs& a, int B, int* 
     const int ntile = aa.tiles_x * ((a.Hout + 15) / 16);
     if (npart_out) *npart_out = ntile;
     if (a.bias) launch_k(c, XFH_K_CONV_DIRECT, layer, k_conv_direct<CIN, COUT, ST, PRO, false, EPI_BIAS_RELU>, dim3(ntile, 1, B), dim3(256), 0, aa);
-    else if (PRO == PRO_BN && a.st.part) launch_k(c, XFH_K_CONV_DIRECT, layer, k_conv_direct<CIN, COUT, ST, PRO, PRO == PRO_BN, EPI_STATS>, dim3(ntile, 1, B), dim3(256), 0, aa);
+    else if ((PRO == PRO_BN || PRO == PRO_L0) && a.st.part) launch_k(c, XFH_K_CONV_DIRECT, layer, k_conv_direct<CIN, COUT, ST, PRO, PRO == PRO_BN || PRO == PRO_L0, EPI_STATS>, dim3(ntile, 1, B), dim3(256), 0, aa);
     else launch_k(c, XFH_K_CONV_DIRECT, layer, k_conv_direct<CIN, COUT, ST, PRO, false, EPI_STATS>, dim3(ntile, 1, B), dim3(256), 0, aa);
     return hipGetLastError();
 }
@@ -690,6 +833,7 @@ static hipError_t conv_direct_launch(xfh_ctx* c, const ConvArgs& a, int B, int* 
 // number of statistic partials a layer produces per frame (needed to size buffers up front)
 int conv_layer_npart(int li, int Hout, int Wout) {
     auto cdiv = [](int a, int b) { return (a + b - 1) / b; };
+    if (li == 0) return cdiv(Wout, L0S_TW) * cdiv(Hout, L0S_TH);          // k_block1_stats
     if (li < 3) return cdiv(Wout, 16) * cdiv(Hout, 16);
     switch (li) {
         case 7: case 16: case 17: return cdiv(Wout, 16) * cdiv(Hout, 2);     // 8x16 pixels; 2x16 in the small-batch configuration (the larger count sizes the buffers)
@@ -739,8 +883,17 @@ static hipError_t launch_basic_layer_t(xfh_ctx* c, int li, const float* in, size
     int np = 0;
     hipError_t e = hipSuccess;
     switch (li) {
-        case 0: e = conv_direct_launch<1, 4, 1, PRO_IN>(c, a, B, &np, li); break;
-        case 1: e = conv_direct_launch<4, 8, 2, PRO_BN>(c, a, B, &np, li); break;
+        case 0:
+            // statistics only (k_block1_stats); nothing to do when they come from the weight file
+            np = conv_layer_npart(0, Hout, Wout);
+            if (!running)
+                launch_k(c, XFH_K_CONV_DIRECT, li, k_block1_stats, dim3(np, 1, B), dim3(256), 0, in, in_stride, (const float*)c->xstat, Hin, Win,
+                         (Wout + L0S_TW - 1) / L0S_TW, (const float*)c->w.direct[0], c->part[0], c->part_stride[0]);
+            break;
+        case 1:
+            a.xstat = c->xstat; a.w0 = c->w.direct[0]; a.bias0 = (EPI == EPI_BIAS_RELU) ? c->w.bn_bias[0] : nullptr;
+            e = conv_direct_launch<4, 8, 2, PRO_L0>(c, a, B, &np, li);
+            break;
         case 2: e = conv_direct_launch<8, 8, 1, PRO_BN>(c, a, B, &np, li); break;
         case 3:
             // all nine taps of the weights in one LDS chunk (no barrier inside the K = 72 loop): 49.5 -> 46.2 us at B = 32;

@@ -622,7 +622,7 @@ StatSrc stat_src(xfh_ctx* c, int j, int B);
 bool consumer_fold(int B);
 
 #define CK(x) do { hipError_t _e = (x); if (_e != hipSuccess) return _e; } while (0)
-enum { PRO_PLAIN = 0, PRO_BN = 1, PRO_IN = 2, PRO_B2IN = 3, PRO_FUSE = 4 };
+enum { PRO_PLAIN = 0, PRO_BN = 1, PRO_IN = 2, PRO_B2IN = 3, PRO_FUSE = 4, PRO_L0 = 5 };
 
 hipError_t run_extract(xfh_ctx* c, const uint8_t* d_gray, int B, int H0, int W0, int lap0, int lap1, uint8_t* d_records, bool write_padding) {
     const int H = (H0 / 32) * 32, W = (W0 / 32) * 32;
@@ -672,7 +672,7 @@ hipError_t run_extract(xfh_ctx* c, const uint8_t* d_gray, int B, int H0, int W0,
     auto backbone = [&]() -> hipError_t {
     // block1
     CK(launch_basic_layer(c, 0, c->X, xs, -2, PRO_IN, H, W, B));
-    CK(launch_basic_layer(c, 1, c->raw[0], c->raw_stride[0], 0, PRO_BN, c->lh[0], c->lw[0], B));
+    CK(launch_basic_layer(c, 1, c->X, xs, 0, PRO_L0, H, W, B));               // block1.0 is recomputed from the image while staging
     CK(launch_basic_layer(c, 2, c->raw[1], c->raw_stride[1], 1, PRO_BN, c->lh[1], c->lw[1], B));
     CK(launch_basic_layer(c, 3, c->raw[2], c->raw_stride[2], 2, PRO_BN, c->lh[2], c->lw[2], B));
     // block2 (block2.0 adds skip1(x) to x1 while staging), block3
