@@ -45,6 +45,18 @@ KP_GAIN = 6.0                     # "dense" synthetic weights: > 4096 NMS candid
 DOMINANT_LAYERS = (7, 17)         # k_conv_mfma<64,64,3,1,4,2,1,16,PRO_BN,EPI_STATS,32>: block3.1, block_fusion.1
 
 
+# (cin, cout, kernel, output resolution divisor) of every convolution of the network (reference src/XFeat.cc:27-103)
+NET_CONVS = [(1, 4, 3, 1), (4, 8, 3, 2), (8, 8, 3, 2), (8, 24, 3, 4), (24, 24, 3, 4), (24, 24, 3, 4), (24, 64, 3, 8), (64, 64, 3, 8), (64, 64, 1, 8),
+             (64, 64, 3, 16), (64, 64, 3, 16), (64, 64, 3, 16), (64, 128, 3, 32), (128, 128, 3, 32), (128, 128, 3, 32), (128, 64, 1, 32),
+             (64, 64, 3, 8), (64, 64, 3, 8), (64, 64, 1, 8), (64, 64, 1, 8), (64, 64, 1, 8), (64, 1, 1, 8), (64, 64, 1, 8), (64, 64, 1, 8), (64, 64, 1, 8),
+             (64, 65, 1, 8), (1, 24, 1, 4)]
+
+
+def net_flops(H, W):
+    """algorithmic flops of all convolutions of one frame (2 * K * K * Cin * Cout per output pixel): 2.62 GFLOP at VGA"""
+    return float(sum(2 * k * k * ci * co * (H // d) * (W // d) for ci, co, k, d in NET_CONVS))
+
+
 BN_MODES = {"batch": 0, "running": 1, "folded": 2}
 BN_TEXT = {"batch": "per-frame BatchNorm statistics", "running": "NOT the reference's semantics: running BatchNorm statistics, upstream eval()",
            "folded": "NOT the reference's semantics: eval() BatchNorm folded into the convolution weights"}
@@ -82,10 +94,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=256, help="frames per sub-batch (per GPU per step: batch x streams)")
+    ap.add_argument("--batch", type=int, default=64, help="frames per sub-batch (per GPU per step: batch x streams)")
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--width", type=int, default=640)
-    ap.add_argument("--streams", type=int, default=1, help="independent sub-batches in flight (one ctx + HIP stream each)")
+    ap.add_argument("--streams", type=int, default=4, help="sub-batches in flight per GPU (one ctx with its own HIP streams each)")
     ap.add_argument("--match-iters", type=int, default=300)
     ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the bounded all-core CPU-baseline sample (0 = skip)")
     ap.add_argument("--gather", choices=["allgather", "root", "compact"], default="allgather")
@@ -126,7 +138,7 @@ def main():
         c_.load_weights(blob)
     ctx = ctxs[0]
     # frame i of the global batch goes to rank i mod N (weak scaling: S*B frames per GPU per step); every frame is distinct
-    frames = synth.frames(B, H, W, seed=42 + 1000 * rank)
+    frames = synth.frames(B * S, H, W, seed=42 + 1000 * rank)        # every frame of the step is distinct, also across sub-batches
     rec_bytes = ctx.rec_bytes
     nf = NFEATURES
 
@@ -152,11 +164,13 @@ def main():
         g = step_no[0] & 1 if use_comm else 0
         if use_comm:
             comm.fence(g)                                  # the collective that last read generation g has finished
+            for c_ in ctxs[1:]:
+                comm.fence_ctx(c_, g)
         for k, c_ in enumerate(ctxs):
-            capi.check(lib.xfh_extract_batch_device(c_.h, in_ptr, B, H, W, 0, 0, d_rec[g].ptr + k * B * rec_bytes), c_.h)
+            capi.check(lib.xfh_extract_batch_device(c_.h, in_ptr + k * B * H * W, B, H, W, 0, 0, d_rec[g].ptr + k * B * rec_bytes), c_.h)
         if use_comm:
             for c_ in ctxs[1:]:
-                c_.synchronize()                           # only ctx 0's stream orders the collective
+                comm.wait_ctx(c_)                          # the collective waits for every sub-batch, not only ctx 0's
             if args.gather == "allgather":
                 comm.allgather_records(d_rec[g].ptr, S * B, d_all[g].ptr, g)
             elif args.gather == "root":
@@ -177,13 +191,15 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
-    # roofline of the dominant kernel: dispatch-attached HIP events (hipExtLaunchKernelGGL) on every launch of that
-    # kernel.  With one sub-batch in flight (the default) they are taken INSIDE the timed region, on the stream the
-    # kernel runs on; rocprofv3 --kernel-trace of the same command reports the same average.
+    # roofline of the dominant kernel: dispatch-attached HIP events (hipExtLaunchKernelGGL) on every launch of that kernel
+    # INSIDE the timed region, on the streams the kernel runs on, in every ctx; rocprofv3 --kernel-trace of the same command
+    # reports the same average.  With several sub-batches in flight a launch shares the CUs with the other ctx' kernels, so
+    # its duration is longer than the kernel's own speed: that one is measured after the region (`isolated`, one ctx alone).
     layer_mask = sum(1 << l for l in DOMINANT_LAYERS)
-    in_region = S == 1 and K * len(DOMINANT_LAYERS) <= 4096
+    in_region = K * len(DOMINANT_LAYERS) <= 4096
     if in_region:
-        ctx.timing_enable(capi.K["CONV_MFMA"], layer_mask)
+        for c_ in ctxs:
+            c_.timing_enable(capi.K["CONV_MFMA"], layer_mask)
     sync()
     t0 = time.perf_counter()
     for _ in range(K):
@@ -193,14 +209,17 @@ def main():
     if use_comm:
         comm.synchronize()
     elapsed = sync(time.perf_counter() - t0)               # barrier; MAX over ranks
-    if not in_region:
-        # several sub-batches in flight share the CUs, so a launch's duration is not the kernel's own speed:
-        # time the kernel in the same K steps once more on ONE stream
-        ctx.timing_enable(capi.K["CONV_MFMA"], layer_mask)
-        for _ in range(min(K, 2000)):
-            capi.check(lib.xfh_extract_batch_device(ctx.h, in_ptr, B, H, W, 0, 0, rec_ptr), ctx.h)
-        ctx.synchronize()
-    n_conv, ms_conv = ctx.timing_read()
+    n_conv, ms_conv = 0, 0.0
+    if in_region:
+        for c_ in ctxs:
+            n_, ms_ = c_.timing_read()
+            n_conv += n_; ms_conv += ms_
+            c_.timing_enable(0)
+    ctx.timing_enable(capi.K["CONV_MFMA"], layer_mask)
+    for _ in range(min(K, 40)):
+        capi.check(lib.xfh_extract_batch_device(ctx.h, in_ptr, B, H, W, 0, 0, rec_ptr), ctx.h)
+    ctx.synchronize()
+    n_iso, ms_iso = ctx.timing_read()
     ctx.timing_enable(0)
     frames_per_s = N * B * S * K / elapsed
 
@@ -211,13 +230,15 @@ def main():
 
     conv_us = ms_conv / max(n_conv, 1) * 1e3
     conv_tf = conv_flops(H, W) * B / (conv_us * 1e-6) / 1e12 if n_conv else 0.0
+    iso_us = ms_iso / max(n_iso, 1) * 1e3
+    iso_tf = conv_flops(H, W) * B / (iso_us * 1e-6) / 1e12 if n_iso else 0.0
     out = {
         "metric": "XFeat frames/s (VGA, 4096 kpts) + 4096x4096 desc-match pairs/s",
         "value": frames_per_s, "unit": "frames/s", "n_gpus": N, "steps": K, "warmup": args.warmup,
         "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"configs[1]: {H}x{W} u8 frames, XFeat extract, nfeatures {nf}, {B * S} distinct frames per GPU per step "
-                               f"({S} sub-batch(es) of {B} on separate HIP streams) ({BN_TEXT[args.bn]}), inputs and 4096-row records resident in HBM"
+                               f"({S} sub-batch(es) of {B}, each on its own ctx / HIP streams) ({BN_TEXT[args.bn]}), inputs and 4096-row records resident in HBM"
                                + (f", RCCL {args.gather} of the records through the C ABI (xfh_comm_*), overlapped with the next step" if use_comm else ""),
                    "frames_per_gpu_per_step": B * S, "sub_batches_in_flight": S, "height": H, "width": W, "nfeatures": nf,
                    "weights": f"synthetic seed 1234, keypoint-logit gain {KP_GAIN}", "parallelism": f"frames x{N}"},
@@ -233,10 +254,17 @@ def main():
     if traffic and traffic.get("conv_bytes_per_launch"):
         conv_traffic = traffic["conv_bytes_per_launch"] * (B / traffic["conv_batch"] if traffic.get("conv_batch") else 1.0)
     out["config"]["bn_mode"] = args.bn
-    out["roofline"] = {"kernel": "k_conv_mfma<64,64,3,...> (block3.1, block_fusion.1: 3x3 64->64 at 1/8 res)" + ("" if args.bn != "folded" else ", bias+ReLU epilogue"),
-                       "measured": "HIP events attached to every dispatch of the kernel inside the timed region" if in_region else "single-stream pass of the same steps",
+    step_tf = net_flops(H, W) * frames_per_s / N / 1e12
+    out["step_roofline"] = {"what": "all convolutions of the network (algorithmic flops per frame) x frames/s per GPU of the timed region, against the f32 MFMA peak: "
+                                    "the whole step, every non-convolution kernel and every gap included",
+                            "flops_per_frame": net_flops(H, W), "achieved": step_tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": step_tf / PEAK_F32_MFMA_TFLOPS}
+    kname = "k_conv_mfma<64,64,3,...> (block3.1, block_fusion.1: 3x3 64->64 at 1/8 res)" + ("" if args.bn != "folded" else ", bias+ReLU epilogue")
+    out["roofline"] = {"kernel": kname,
+                       "measured": "HIP events attached to every dispatch of the kernel inside the timed region (all ctx)" + ("; the launches share the CUs with the other sub-batches' kernels" if S > 1 else ""),
                        "bound": "mfma", "achieved": conv_tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": conv_tf / PEAK_F32_MFMA_TFLOPS,
-                       "traffic": conv_traffic, "avg_launch_us": conv_us, "launches": n_conv, "flops_per_launch": conv_flops(H, W) * B}
+                       "traffic": conv_traffic, "avg_launch_us": conv_us, "launches": n_conv, "flops_per_launch": conv_flops(H, W) * B,
+                       "isolated": {"note": f"the same launches ({B} frames) with one ctx alone on the GPU, after the timed region",
+                                    "achieved": iso_tf, "frac": iso_tf / PEAK_F32_MFMA_TFLOPS, "avg_launch_us": iso_us, "launches": n_iso}}
 
     if not args.no_legs:
         legs(out, args, lib, capi, synth, Context, ctx, blob, frames, d_in, d_rec[0], B, H, W, nf, rec_bytes, traffic, N)
@@ -274,29 +302,42 @@ def legs(out, args, lib, capi, synth, Context, ctx, blob, frames, d_in, d_recb, 
     # ---- the same workload with upstream-XFeat eval() BatchNorm, exact (running) and folded into the weights
     if args.bn == "batch":
         bn = {}
+        S = max(1, args.streams)
         for name in ("running", "folded"):
-            fc = Context(nfeatures=nf, max_height=H, max_width=W, max_batch=B, device=ctx.device, bn_mode=BN_MODES[name])
-            fc.load_weights(blob)
-            d_r = capi.DeviceBuffer(B * rec_bytes)
+            fcs = [Context(nfeatures=nf, max_height=H, max_width=W, max_batch=B, device=ctx.device, bn_mode=BN_MODES[name]) for _ in range(S)]
+            for fc in fcs:
+                fc.load_weights(blob)
+            d_r = capi.DeviceBuffer(S * B * rec_bytes)
+            def bn_step():
+                for k, fc in enumerate(fcs):
+                    capi.check(lib.xfh_extract_batch_device(fc.h, in_ptr + k * B * H * W, B, H, W, 0, 0, d_r.ptr + k * B * rec_bytes), fc.h)
             for _ in range(2):
-                capi.check(lib.xfh_extract_batch_device(fc.h, in_ptr, B, H, W, 0, 0, d_r.ptr), fc.h)
-            fc.synchronize()
-            fc.timing_enable(capi.K["CONV_MFMA"], sum(1 << l for l in DOMINANT_LAYERS))
+                bn_step()
+            for fc in fcs:
+                fc.synchronize()
             nrun = max(5, min(20, args.steps))
             t1 = time.perf_counter()
             for _ in range(nrun):
+                bn_step()
+            for fc in fcs:
+                fc.synchronize()
+            dt = (time.perf_counter() - t1) / nrun
+            fc = fcs[0]
+            fc.timing_enable(capi.K["CONV_MFMA"], sum(1 << l for l in DOMINANT_LAYERS))
+            for _ in range(nrun):
                 capi.check(lib.xfh_extract_batch_device(fc.h, in_ptr, B, H, W, 0, 0, d_r.ptr), fc.h)
             fc.synchronize()
-            dt = (time.perf_counter() - t1) / nrun
             n_c, ms_c = fc.timing_read()
             fc.timing_enable(0)
             us = ms_c / max(n_c, 1) * 1e3
             tf = conv_flops(H, W) * B / (us * 1e-6) / 1e12 if n_c else 0.0
-            bn[name] = {"frames_per_s": B / dt, "ms_per_step": dt * 1e3, "steps": nrun,
-                        "roofline": {"kernel": "same 3x3 64->64 launches as the headline" + (", bias+ReLU epilogue, no statistics" if name == "folded" else ""),
-                                     "bound": "mfma", "achieved": tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_F32_MFMA_TFLOPS,
-                                     "avg_launch_us": us, "launches": n_c}}
-            fc.close(); d_r.free()
+            bn[name] = {"frames_per_s": S * B / dt, "ms_per_step": dt * 1e3, "steps": nrun,
+                        "roofline_isolated": {"kernel": "same 3x3 64->64 launches as the headline" + (", bias+ReLU epilogue, no statistics" if name == "folded" else ""),
+                                              "bound": "mfma", "achieved": tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_F32_MFMA_TFLOPS,
+                                              "avg_launch_us": us, "launches": n_c}}
+            for fc in fcs:
+                fc.close()
+            d_r.free()
         bn["note"] = ("NOT the reference's semantics (its libtorch module stays in train mode, SURVEY.md Q1): upstream-XFeat eval() BatchNorm behind "
                       "cfg.bn_mode; 'folded' = W*rstd, bias -mean*rstd, ReLU in the conv epilogue, no statistics kernels or partials")
         out["bn_eval_modes"] = bn

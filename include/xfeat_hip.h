@@ -224,6 +224,11 @@ int xfh_gather_compact_root(xfh_ctx* ctx, const void* d_records, int B, void* d_
 int xfh_unpack_compact(const void* shard, size_t nbytes, int frame, int nfeatures, xfh_keypoint* kps_out, float* desc_out, int* n_valid, int* mono_index);
 int xfh_allgather_bytes(xfh_ctx* ctx, const void* d_send, size_t nbytes, void* d_recv, int gen);   /* e.g. timings, barriers */
 int xfh_comm_fence(xfh_ctx* ctx, int gen);
+/* Several ctx of one GPU feeding one communicator (sub-batches of a step, each extracted by its own ctx into one record buffer):
+ * xfh_comm_wait_ctx makes the NEXT collective of `ctx` also wait for the work queued on `other` so far; xfh_comm_fence_ctx is
+ * xfh_comm_fence for `other`'s stream.  Neither synchronises the host nor orders the two ctx streams against each other. */
+int xfh_comm_wait_ctx(xfh_ctx* ctx, xfh_ctx* other);
+int xfh_comm_fence_ctx(xfh_ctx* ctx, xfh_ctx* other, int gen);
 int xfh_comm_synchronize(xfh_ctx* ctx);
 
 /* ---- plumbing ----------------------------------------------------------------------- */

@@ -98,6 +98,40 @@ def test_config3_batch8_720p_device_resident(gpu_lib, oracle_mod):
         assert n == onv and dd < DESC_TOL and ds < 1e-6, b
 
 
+def test_concurrent_contexts_share_the_gpu(gpu_lib):
+    """four ctx on one GPU with work in flight at the same time (how bench.py fills the device: the HBM-bound kernels of one
+    sub-batch run beside the MFMA-bound convolutions of another): back-to-back device-resident calls, no synchronisation in
+    between, every record equal to the one the frame gets from a lone serial ctx."""
+    from xfeatslam_amd.extractor import Context
+    H, W, nf, S, B = 96, 128, 256, 4, 12
+    blob = WT.pack_blob(WT.make_synthetic(1234, 6.0))
+    fr = synth.frames(2 * S * B, H, W, seed=77)
+    L = capi.lib()
+    ref_ctx = Context(nfeatures=nf, max_height=H, max_width=W, max_batch=B, flags=capi.FLAG_SERIAL_BRANCH); ref_ctx.load_weights(blob)
+    ref = []
+    for i in range(0, len(fr), B):
+        ref += ref_ctx.extract_batch(fr[i:i + B], (0, 64))
+    ref_ctx.close()
+    ctxs = [_ctx(nf, H, W, B=B) for _ in range(S)]
+    for c in ctxs:
+        c.load_weights(blob)
+    d_in = capi.DeviceBuffer(fr.nbytes).upload(fr)
+    d_rec = capi.DeviceBuffer(len(fr) * ctxs[0].rec_bytes)
+    rb = ctxs[0].rec_bytes
+    for rnd in range(2):
+        for k, c in enumerate(ctxs):
+            off = (rnd * S + k) * B
+            capi.check(L.xfh_extract_batch_device(c.h, d_in.ptr + off * H * W, B, H, W, 0, 64, d_rec.ptr + off * rb), c.h)
+    for c in ctxs:
+        c.synchronize()
+    recs = ctxs[0].parse_records(d_rec.download(np.uint8, len(fr) * rb), len(fr))
+    for c in ctxs:
+        c.close()
+    for i, (a, b) in enumerate(zip(recs, ref)):
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y), i
+
+
 def test_stage_tensors_match_oracle(gpu_lib, oracle_mod, weights_std):
     """every intermediate of the forward pass; convolutions and statistics are the same fp32/fp64
     expression on both sides (one fma chain in (ky,kx,ci) order) -> expected bit exact"""

@@ -81,6 +81,8 @@ SYMBOLS = [
     ("xfh_unpack_compact", _i, [_vp, _sz, _i, _i, _vp, _vp, _pi, _pi]),
     ("xfh_allgather_bytes", _i, [_vp, _vp, _sz, _vp, _i]),
     ("xfh_comm_fence", _i, [_vp, _i]),
+    ("xfh_comm_wait_ctx", _i, [_vp, _vp]),
+    ("xfh_comm_fence_ctx", _i, [_vp, _vp, _i]),
     ("xfh_comm_synchronize", _i, [_vp]),
     ("xfh_synchronize", _i, [_vp]),
     ("xfh_set_stream", _i, [_vp, _vp]),

@@ -99,6 +99,7 @@ int xfh_create(const xfh_config* cfg, xfh_ctx** out) {
     if (hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) != hipSuccess) return fail(XFH_ERR_HIP);
     if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) return fail(XFH_ERR_HIP);
     if (hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) return fail(XFH_ERR_HIP);
+    if (hipEventCreateWithFlags(&c->ev_out, hipEventDisableTiming) != hipSuccess) return fail(XFH_ERR_HIP);
     const size_t xs = (size_t)c->Hmax * c->Wmax;
     A(c->d_gray, (size_t)B * cfg->max_height * cfg->max_width);
     A(c->X, sizeof(float) * B * xs);
@@ -185,6 +186,7 @@ int xfh_destroy(xfh_ctx* c) {
     if (c->timer.ev) { for (int i = 0; i < 2 * KTimer::MAXEV; ++i) if (c->timer.ev[i]) hipEventDestroy(c->timer.ev[i]); free(c->timer.ev); }
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->ev_join) hipEventDestroy(c->ev_join);
+    if (c->ev_out) hipEventDestroy(c->ev_out);
     if (c->aux_stream) hipStreamDestroy(c->aux_stream);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;

@@ -274,6 +274,22 @@ int xfh_comm_fence(xfh_ctx* c, int gen) {
     return XFH_OK;
 }
 
+// several ctx feed one communicator (sub-batches of a step, each on its own ctx): the collective also waits for `other`'s
+// stream, and `other` does not overwrite generation `gen` before the collective that read it has finished -- both without
+// a host synchronisation and without tying the ctx streams to each other
+int xfh_comm_wait_ctx(xfh_ctx* c, xfh_ctx* other) {
+    if (!c || !c->comm || !other || other->cfg.device != c->cfg.device) return XFH_ERR_INVALID_ARG;
+    HIPCK(c, hipSetDevice(c->cfg.device));
+    HIPCK(c, hipEventRecord(other->ev_out, other->stream));
+    HIPCK(c, hipStreamWaitEvent(c->comm->stream, other->ev_out, 0));
+    return XFH_OK;
+}
+int xfh_comm_fence_ctx(xfh_ctx* c, xfh_ctx* other, int gen) {
+    if (!c || !c->comm || !other || gen < 0 || gen > 1 || other->cfg.device != c->cfg.device) return XFH_ERR_INVALID_ARG;
+    if (c->comm->used[gen]) HIPCK(c, hipStreamWaitEvent(other->stream, c->comm->ev_done[gen], 0));
+    return XFH_OK;
+}
+
 int xfh_comm_synchronize(xfh_ctx* c) {
     if (!c || !c->comm) return XFH_ERR_INVALID_ARG;
     HIPCK(c, hipStreamSynchronize(c->comm->stream));

@@ -29,6 +29,7 @@ struct xfh_ctx {
     hipStream_t stream = nullptr;   // own_stream or an external one
     hipStream_t aux_stream = nullptr;                  // keypoint branch of run_extract (forked / joined with the two events)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_out = nullptr;                       // "everything queued on the ctx stream so far", for another ctx' communicator (xfh_comm_wait_ctx)
     std::string hip_err;
 
     DevWeights w;

@@ -113,6 +113,13 @@ class Comm:
     def fence(self, gen: int):
         self.capi.check(self.capi.lib().xfh_comm_fence(self.ctx.h, gen), self.ctx.h)
 
+    def wait_ctx(self, other):
+        """the next collective also waits for what is queued on `other` (a second ctx of this GPU) so far"""
+        self.capi.check(self.capi.lib().xfh_comm_wait_ctx(self.ctx.h, other.h), self.ctx.h)
+
+    def fence_ctx(self, other, gen: int):
+        self.capi.check(self.capi.lib().xfh_comm_fence_ctx(self.ctx.h, other.h, gen), self.ctx.h)
+
     def synchronize(self):
         self.capi.check(self.capi.lib().xfh_comm_synchronize(self.ctx.h), self.ctx.h)
 
