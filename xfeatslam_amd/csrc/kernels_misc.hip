@@ -554,26 +554,58 @@ void k_select(const u64* __restrict__ cand, size_t cand_cap, const int* __restri
     place_sorted<4>(key, t, b, N, W, nfeatures, lap0, lap1, rw, slot_src, sel_key, sel_n, records, rec_bytes, n_cand, wsumF, wsumB);
 }
 
-// ---- k_desc: one wave per output slot, lane = descriptor channel ---------------------------------
+// ---- k_feat_norm: ||feats(p)||_2 of every feature pixel, one thread per pixel -------------------
+// F::normalize(M1, dim=1) (XFextractor.cc:273) divides every pixel of the feature map by max(||.||_2, 1e-12): the norm is the
+// oracle's expression (fp64 sum of squares over the channels in order, fp32 sqrt, max) and is all that is stored -- the
+// normalised map itself is never written, k_desc divides the four pixels a sample touches.  A thread walks the 64 channels
+// of its pixel: 128 fp64 operations per pixel, where a cross-lane reduction per sampled pixel cost ten times that.
 __global__ __launch_bounds__(256)
-void k_desc(const float* __restrict__ feats, size_t m_stride, const int* __restrict__ slot_src, const u64* __restrict__ sel_key,
+void k_feat_norm(const float* __restrict__ feats, size_t m_stride, int npix, float* __restrict__ nrm, size_t n_stride) {
+    const int b = blockIdx.z, p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= npix) return;
+    const float* m = feats + (size_t)b * m_stride + (size_t)p * 64;
+    double ss = 0.0;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+        const f32x4 v = *(const f32x4*)(m + g * 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ss = fma((double)v[q], (double)v[q], ss);
+    }
+    nrm[(size_t)b * n_stride + p] = fmaxf((float)sqrt(ss), 1e-12f);
+}
+
+// IEEE a / d for several a and one d: the refined reciprocal and the quotient correction of the compiler's own division
+// expansion (v_rcp + Newton step, q = a*r, two residual corrections), with the reciprocal shared.  Bit-identical to a / d
+// whenever the expansion's scaling stage is the identity, i.e. for all operands here: d in [1e-12, 1e6], |a| <= 1e6 and
+// either zero or above 1e-20.
+struct Recip { float d, r; };
+__device__ __forceinline__ Recip recip_of(float d) {
+    float r = __builtin_amdgcn_rcpf(d);
+    r = fmaf(fmaf(-d, r, 1.0f), r, r);
+    return Recip{d, r};
+}
+__device__ __forceinline__ float div_by(float a, const Recip& k) {
+    float q = a * k.r;
+    q = fmaf(fmaf(-k.d, q, a), k.r, q);
+    return fmaf(fmaf(-k.d, q, a), k.r, q);
+}
+
+// ---- k_desc: 16 lanes per output slot (4 slots per wave), a lane owns 4 descriptor channels -------
+__global__ __launch_bounds__(256)
+void k_desc(const float* __restrict__ feats, size_t m_stride, const float* __restrict__ fnorm, size_t n_stride,
+            const int* __restrict__ slot_src, const u64* __restrict__ sel_key,
             int H, int W, int nfeatures, float rw, float rh, uint8_t* __restrict__ records, size_t rec_bytes, size_t kps_off, size_t desc_off, int write_padding) {
     const int b = blockIdx.z;
-    const int slot = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (slot >= nfeatures) return;
+    const int slot = blockIdx.x * 16 + (threadIdx.x >> 4), l = threadIdx.x & 15;
+    const bool in_range = slot < nfeatures;
     uint8_t* rec = records + (size_t)b * rec_bytes;
     float* kp = (float*)(rec + kps_off + (size_t)slot * 28);
-    float* dd = (float*)(rec + desc_off + (size_t)slot * 256);
-    const int src = slot_src[(size_t)b * nfeatures + slot];
-    if (src < 0) {
-        if (!write_padding) return;        // host-visible record (xfh_extract_submit): the host pads, nothing crosses PCIe
-        // default cv::KeyPoint(): pt (0,0), size 0, angle -1, response 0, octave 0, class_id -1
-        if (lane < 5) kp[lane] = (lane == 3) ? -1.f : 0.f;
-        else if (lane < 7) ((int*)kp)[lane] = (lane == 5) ? 0 : -1;
-        dd[lane] = 0.f;
-        return;
-    }
-    const u64 key = sel_key[(size_t)b * nfeatures + src];
+    float* dd = (float*)(rec + desc_off + (size_t)slot * 256) + l * 4;
+    const int src = in_range ? slot_src[(size_t)b * nfeatures + slot] : -1;
+    const bool live = src >= 0;
+    // the reduction below runs in every lane of the wave; slots without a keypoint carry zeros through it
+    u64 key = 0;
+    if (live) key = sel_key[(size_t)b * nfeatures + src];
     const float score = ord2f(~(unsigned)(key >> 32));
     const unsigned idx = (unsigned)(key & 0xFFFFFFFFull);
     const int x = (int)(idx % (unsigned)W), y = (int)(idx / (unsigned)W);
@@ -584,32 +616,41 @@ void k_desc(const float* __restrict__ feats, size_t m_stride, const int* __restr
     const float nw = e * so, ne = w * so, sw = e * n, se = w * n;
     const int x0 = (int)xw, y0 = (int)yn, x1 = x0 + 1, y1 = y0 + 1;
     const bool vx0 = x0 >= 0 && x0 < Wh, vx1 = x1 >= 0 && x1 < Wh, vy0 = y0 >= 0 && y0 < Hh, vy1 = y1 >= 0 && y1 < Hh;
-    // F::normalize(M1, dim=1) (XFextractor.cc:273) of the four feature pixels the sample touches: fp64 sum of squares over
-    // the 64 channels (lane = channel), fp32 sqrt / max(., 1e-12) / divide -- the same values a normalised copy would hold.
-    // The four sums are reduced together: a reduce-scatter over lane bits 5 and 4 leaves tap (lane >> 4) in each 16-lane
-    // group, four butterfly steps finish it (7 fp64 exchanges instead of 24), and the four norms are broadcast back.
-    const float* m = feats + (size_t)b * m_stride;
-    const float r0 = (vx0 && vy0) ? m[((size_t)y0 * Wh + x0) * 64 + lane] : 0.f, r1 = (vx1 && vy0) ? m[((size_t)y0 * Wh + x1) * 64 + lane] : 0.f;
-    const float r2 = (vx0 && vy1) ? m[((size_t)y1 * Wh + x0) * 64 + lane] : 0.f, r3 = (vx1 && vy1) ? m[((size_t)y1 * Wh + x1) * 64 + lane] : 0.f;
-    const double s0 = (double)r0 * (double)r0, s1 = (double)r1 * (double)r1, s2 = (double)r2 * (double)r2, s3 = (double)r3 * (double)r3;
-    const bool hi = lane & 32, b4 = lane & 16;
-    double kA = hi ? s2 : s0, kB = hi ? s3 : s1;
-    kA += __shfl_xor(hi ? s0 : s2, 32); kB += __shfl_xor(hi ? s1 : s3, 32);
-    double sst = b4 ? kB : kA;
-    sst += __shfl_xor(b4 ? kA : kB, 16);
-    sst += __shfl_xor(sst, 8); sst += __shfl_xor(sst, 4); sst += __shfl_xor(sst, 2); sst += __shfl_xor(sst, 1);
-    const float nrm_t = fmaxf((float)sqrt(sst), 1e-12f);          // of tap lane >> 4
-    const float a = r0 / __shfl(nrm_t, 0), bb = r1 / __shfl(nrm_t, 16), d = r2 / __shfl(nrm_t, 32), g = r3 / __shfl(nrm_t, 48);
-    const float v = ((a * nw + bb * ne) + d * sw) + g * se;
-    const double ss = wave_sum((double)v * (double)v);
-    const float nrm = fmaxf((float)sqrt(ss), 1e-12f);
-    dd[lane] = v / nrm;
-    if (lane < 7) {
+    // the four feature pixels the sample touches (zero outside the map: grid_sample padding_mode zeros), each divided by its
+    // norm (k_feat_norm): the values a normalised copy of the map would hold
+    const float* m = feats + (size_t)b * m_stride + l * 4;
+    const float* fn = fnorm + (size_t)b * n_stride;
+    const int cx0 = min(max(x0, 0), Wh - 1), cx1 = min(max(x1, 0), Wh - 1), cy0 = min(max(y0, 0), Hh - 1), cy1 = min(max(y1, 0), Hh - 1);
+    const size_t p00 = (size_t)cy0 * Wh + cx0, p01 = (size_t)cy0 * Wh + cx1, p10 = (size_t)cy1 * Wh + cx0, p11 = (size_t)cy1 * Wh + cx1;
+    f32x4 r0 = *(const f32x4*)(m + p00 * 64), r1 = *(const f32x4*)(m + p01 * 64), r2 = *(const f32x4*)(m + p10 * 64), r3 = *(const f32x4*)(m + p11 * 64);
+    const Recip k0 = recip_of(fn[p00]), k1 = recip_of(fn[p01]), k2 = recip_of(fn[p10]), k3 = recip_of(fn[p11]);
+    const bool t0 = live && vx0 && vy0, t1 = live && vx1 && vy0, t2 = live && vx0 && vy1, t3 = live && vx1 && vy1;
+    f32x4 v;
+    double ss = 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float a = t0 ? div_by(r0[q], k0) : 0.f, bb = t1 ? div_by(r1[q], k1) : 0.f, d = t2 ? div_by(r2[q], k2) : 0.f, g = t3 ? div_by(r3[q], k3) : 0.f;
+        v[q] = ((a * nw + bb * ne) + d * sw) + g * se;
+        ss = fma((double)v[q], (double)v[q], ss);
+    }
+    ss += __shfl_xor(ss, 8); ss += __shfl_xor(ss, 4); ss += __shfl_xor(ss, 2); ss += __shfl_xor(ss, 1);
+    if (!in_range) return;
+    if (!live) {
+        if (!write_padding) return;        // host-visible record (xfh_extract_submit): the host pads, nothing crosses PCIe
+        // default cv::KeyPoint(): pt (0,0), size 0, angle -1, response 0, octave 0, class_id -1
+        if (l < 5) kp[l] = (l == 3) ? -1.f : 0.f;
+        else if (l < 7) ((int*)kp)[l] = (l == 5) ? 0 : -1;
+        *(f32x4*)dd = f32x4{0.f, 0.f, 0.f, 0.f};
+        return;
+    }
+    const Recip kn = recip_of(fmaxf((float)sqrt(ss), 1e-12f));
+    *(f32x4*)dd = f32x4{div_by(v[0], kn), div_by(v[1], kn), div_by(v[2], kn), div_by(v[3], kn)};
+    if (l < 7) {
         // KeyPoint(x, y, 1, -1, score): octave 0, class_id -1 (XFextractor.cc:329); the Long rescale at :304-305
         // multiplies by 1: rw = rh = 1 unless XFH_FLAG_RESCALE_KEYPOINTS asks for input coordinates
-        const float val = lane == 0 ? (float)x * rw : lane == 1 ? (float)y * rh : lane == 2 ? 1.f : lane == 3 ? -1.f : score;
-        if (lane < 5) kp[lane] = val;
-        else ((int*)kp)[lane] = (lane == 5) ? 0 : -1;
+        const float val = l == 0 ? (float)x * rw : l == 1 ? (float)y * rh : l == 2 ? 1.f : l == 3 ? -1.f : score;
+        if (l < 5) kp[l] = val;
+        else ((int*)kp)[l] = (l == 5) ? 0 : -1;
     }
 }
 
@@ -719,7 +760,9 @@ hipError_t run_extract(xfh_ctx* c, const uint8_t* d_gray, int B, int H0, int W0,
                  lap0, lap1, rw, c->slot_src, c->sel_key, c->sel_n, d_records, rec);
     }
     CK(hipGetLastError());
-    launch_k(c, XFH_K_DESC, -1, k_desc, dim3((nf + 3) / 4, 1, B), dim3(256), 0, c->feats, c->raw_stride[17], c->slot_src, c->sel_key, H, W, nf, rw, rh,
+    hipLaunchKernelGGL(k_feat_norm, dim3((h8 * w8 + 255) / 256, 1, B), dim3(256), 0, s, (const float*)c->feats, c->raw_stride[17], h8 * w8, c->feat_nrm, xs / 64);
+    CK(hipGetLastError());
+    launch_k(c, XFH_K_DESC, -1, k_desc, dim3((nf + 15) / 16, 1, B), dim3(256), 0, c->feats, c->raw_stride[17], (const float*)c->feat_nrm, xs / 64, c->slot_src, c->sel_key, H, W, nf, rw, rh,
                        d_records, rec, xfh_record_kps_offset(), xfh_record_desc_offset(nf), write_padding ? 1 : 0);
     return hipGetLastError();
 }
