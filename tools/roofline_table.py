@@ -1,9 +1,10 @@
 #!/usr/bin/env python
-"""profiles/<tag>_roofline_table.md: every kernel of one default bench step (B frames, one stream) against its bound.
+"""profiles/<tag>_roofline_table.md: every kernel of one bench step (256 frames, one ctx, one stream) against its bound.
 
-Input: the rocprofv3 kernel trace of `XFH_AUX_STREAM=0 python bench.py` (gpurun_out/prof_serial/*kernel_trace.csv,
-tools/gpu_round.sh): with the keypoint branch on the main stream no two kernels overlap, so a launch's duration
-is the kernel's own speed (the product runs that branch on a second stream, which shortens the step by ~3 %).
+Input: the rocprofv3 kernel trace of `python bench.py --streams 1 --batch 256 --serial-branch` (gpurun_out/prof_serial/
+*kernel_trace.csv, tools/gpu_round.sh): one ctx with the keypoint branch on the main stream, so no two kernels overlap and a
+launch's duration is the kernel's own speed (the default bench runs four 64-frame ctx side by side, which is faster as a
+whole -- profiles/<tag>_bench_sweep.md -- but stretches every single launch).
 Launches are attributed to the batched steps by their grid (grid.z == B, or grid.x == B for the per-frame
 kernels); algorithmic flops / bytes per launch come from the layer table: a convolution
 reads its raw input map once, writes its raw output map once and does 2*H*W*Cout*Cin*k^2 flops per frame.
@@ -27,13 +28,14 @@ for r in csv.DictReader(open(f)):
     gz, gx = int(r["Grid_Size_Z"]), int(r["Grid_Size_X"]) // max(int(r["Workgroup_Size_X"]), 1)
     n = r["Kernel_Name"]
     batched = gz == B or (gx == B and any(k in n for k in ("k_bn_finalize", "k_select"))) or "k_conv_mfma_p" in n   # persistent kernels only run for B > 8
-    if batched or "k_mnn" in n or "k_rownorm" in n:
+    if batched or any(k in n for k in ("k_mnn", "k_rownorm", "k_dist_mfma", "k_best2_csr", "k_distinctive_csr")):
         agg[n].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 steps = len(agg[[k for k in agg if "k_preproc" in k][0]])
 rows = []
 for n, d in agg.items():
     us = sum(d) / len(d) / 1e3
-    per_step = len(d) / steps if "k_mnn" not in n and "k_rownorm" not in n else 1
+    MATCH = ("k_mnn", "k_rownorm", "k_dist_mfma", "k_best2_csr", "k_distinctive_csr")
+    per_step = len(d) / steps if not any(k in n for k in MATCH) else 1
     flops = bytes_ = None; bound = "latency"
     m = re.match(r"void k_conv_(mfma_p|mfma|direct)<(\d+), (\d+), (\d+), (\d+)(?:, (\d+), (\d+), (\d+), (\d+))?", n)
     if m:
@@ -47,9 +49,18 @@ for n, d in agg.items():
         ho, wo = L[key]
         flops = 2.0 * ho * wo * cout * cin * k * k * B
         bytes_ = 4.0 * B * (ho * st * wo * st * cin + ho * wo * cout)
+        if m.group(1) == "direct" and m.group(5) == "5":        # PRO_L0: block1.1 reads the 1-channel image and recomputes block1.0 (its 36 flops / pixel are counted here too)
+            bytes_ = 4.0 * B * (H * W + ho * wo * cout)
+            flops += 2.0 * H * W * 4 * 9 * B
         bound = "mfma" if m.group(1) != "direct" and flops / bytes_ > PEAK_TF / PEAK_TB else "hbm"
     elif "k_mnn_gemm" in n:
         flops, bytes_, bound = 2.0 * 4096 * 4096 * 64, 2 * 4096 * 256.0, "mfma"
+    elif "k_dist_mfma" in n:                         # 4096 x 4096 int32 distance table (DescriptorDistance of every pair): the 64 MB write bounds it
+        flops, bytes_, bound = 2.0 * 4096 * 4096 * 64, 4096.0 * 4096 * 4 + 2 * 4096 * 256.0, "hbm"
+    elif "k_best2_csr" in n: bytes_, bound = 4096.0 * 64 * (256 + 4) + 4096 * 256, "hbm"      # 64 gathered 256-byte rows per query (L2 resident table)
+    elif "k_distinctive_csr" in n: bytes_, bound = 4096.0 * 16 * (256 + 4), "hbm"
+    elif "k_block1_stats" in n: bytes_, bound = 4.0 * B * H * W, "hbm"
+    elif "k_feat_norm" in n: bytes_, bound = 4.0 * B * (H // 8) * (W // 8) * 65, "hbm"
     elif "k_heads_kp" in n:
         bytes_, bound = 4.0 * B * (H // 8 * (W // 8) * 64 + H * W), "valu"
         flops = 2.0 * B * (H // 8) * (W // 8) * 65 * 64
@@ -61,13 +72,15 @@ for n, d in agg.items():
     elif "k_heads_heat" in n: bytes_, bound = 4.0 * B * (H // 8) * (W // 8) * 65, "hbm"
     elif "k_nms_score" in n: bytes_, bound = 4.0 * B * H * W, "hbm"
     elif "k_desc" in n: bytes_, bound = B * 4096.0 * (4 * 256 + 284), "hbm"
+    elif "k_rownorm" in n: bytes_, bound = 2 * 4096 * 256.0 * 2, "hbm"
     rows.append((us * per_step, n, len(d), per_step, us, flops, bytes_, bound))
 rows.sort(key=lambda r: -r[0])
-tot = sum(r[0] for r in rows if "k_mnn" not in r[1] and "k_rownorm" not in r[1])
+MATCH = ("k_mnn", "k_rownorm", "k_dist_mfma", "k_best2_csr", "k_distinctive_csr")
+tot = sum(r[0] for r in rows if not any(k in r[1] for k in MATCH))
 out = os.path.join(ROOT, "profiles", f"{tag}_roofline_table.md")
 with open(out, "w") as o:
-    o.write(f"# Every kernel of the default bench step against its bound (B = {B} frames of {H}x{W}, one stream, 1 x MI355X)\n\n"
-            f"Source: rocprofv3 --kernel-trace of `XFH_AUX_STREAM=0 python bench.py` (all kernels serial on one stream; tools/gpu_round.sh), launches with the batched grid only; {steps} steps.\n"
+    o.write(f"# Every kernel of one bench step against its bound (B = {B} frames of {H}x{W}, one ctx, one stream, 1 x MI355X)\n\n"
+            f"Source: rocprofv3 --kernel-trace of `python bench.py --streams 1 --batch {B} --serial-branch` (all kernels serial on one stream; tools/gpu_round.sh), launches with the batched grid only; {steps} steps.  The matcher kernels (k_mnn_*, k_rownorm_img, k_dist_mfma, k_best2_csr, k_distinctive_csr) are the 4096 x 4096 legs of the same run.\n"
             f"`alg` = algorithmic flops / HBM bytes per launch (raw input map read once + raw output map written once; no halo, no weights);\n"
             f"achieved = alg / average duration; % of the bound's peak (f32 MFMA {PEAK_TF} TFLOP/s, HBM {PEAK_TB} TB/s).  `latency` = per-frame single\n"
             f"workgroup or dependent-launch bound kernels (no meaningful roofline).  Extraction kernels sum to {tot:.0f} us per step = {tot / B:.1f} us per frame.\n\n"

@@ -21,6 +21,22 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
+// IEEE a / d for several a and one d: the refined reciprocal and the quotient correction of the compiler's own division
+// expansion (v_rcp + Newton step, q = a*r, two residual corrections), with the reciprocal shared.  Bit-identical to a / d
+// whenever the expansion's scaling stage is the identity: d in [1e-12, 1e6], |a| <= 1e6 and either zero or above 1e-20
+// (k_desc: always; k_heads_kp: softmax terms below 1e-20 may differ in their last denormal bits).
+struct Recip { float d, r; };
+__device__ __forceinline__ Recip recip_of(float d) {
+    float r = __builtin_amdgcn_rcpf(d);
+    r = fmaf(fmaf(-d, r, 1.0f), r, r);
+    return Recip{d, r};
+}
+__device__ __forceinline__ float div_by(float a, const Recip& k) {
+    float q = a * k.r;
+    q = fmaf(fmaf(-k.d, q, a), k.r, q);
+    return fmaf(fmaf(-k.d, q, a), k.r, q);
+}
+
 // ATen upsample_bilinear2d (align_corners=false) source index / weights; see oracle lin_coeff
 __device__ __forceinline__ void lin_coeff(int in, int out, int d, int& i0, int& i1, float& l0, float& l1) {
     const float scale = (float)in / (float)out;
@@ -187,13 +203,14 @@ void k_heads_kp(const float* __restrict__ rawK, StatSrc sK,      // keypoint_hea
     float sum = 0.f;
 #pragma unroll
     for (int n = 0; n < 65; ++n) { acc[n] = expf(acc[n] - mx); sum += acc[n]; }
+    const Recip ks = recip_of(sum);                       // 64 softmax quotients share the divisor
     if (pix < npix) {
         const int y = pix / Wh, x = pix % Wh;
         float* o = K1h + (size_t)b * k1h_stride + (size_t)(8 * y) * (8 * Wh) + 8 * x;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            *(f32x4*)(o + (size_t)i * 8 * Wh) = f32x4{acc[i * 8] / sum, acc[i * 8 + 1] / sum, acc[i * 8 + 2] / sum, acc[i * 8 + 3] / sum};
-            *(f32x4*)(o + (size_t)i * 8 * Wh + 4) = f32x4{acc[i * 8 + 4] / sum, acc[i * 8 + 5] / sum, acc[i * 8 + 6] / sum, acc[i * 8 + 7] / sum};
+            *(f32x4*)(o + (size_t)i * 8 * Wh) = f32x4{div_by(acc[i * 8], ks), div_by(acc[i * 8 + 1], ks), div_by(acc[i * 8 + 2], ks), div_by(acc[i * 8 + 3], ks)};
+            *(f32x4*)(o + (size_t)i * 8 * Wh + 4) = f32x4{div_by(acc[i * 8 + 4], ks), div_by(acc[i * 8 + 5], ks), div_by(acc[i * 8 + 6], ks), div_by(acc[i * 8 + 7], ks)};
         }
     }
 }
@@ -572,22 +589,6 @@ void k_feat_norm(const float* __restrict__ feats, size_t m_stride, int npix, flo
         for (int q = 0; q < 4; ++q) ss = fma((double)v[q], (double)v[q], ss);
     }
     nrm[(size_t)b * n_stride + p] = fmaxf((float)sqrt(ss), 1e-12f);
-}
-
-// IEEE a / d for several a and one d: the refined reciprocal and the quotient correction of the compiler's own division
-// expansion (v_rcp + Newton step, q = a*r, two residual corrections), with the reciprocal shared.  Bit-identical to a / d
-// whenever the expansion's scaling stage is the identity, i.e. for all operands here: d in [1e-12, 1e6], |a| <= 1e6 and
-// either zero or above 1e-20.
-struct Recip { float d, r; };
-__device__ __forceinline__ Recip recip_of(float d) {
-    float r = __builtin_amdgcn_rcpf(d);
-    r = fmaf(fmaf(-d, r, 1.0f), r, r);
-    return Recip{d, r};
-}
-__device__ __forceinline__ float div_by(float a, const Recip& k) {
-    float q = a * k.r;
-    q = fmaf(fmaf(-k.d, q, a), k.r, q);
-    return fmaf(fmaf(-k.d, q, a), k.r, q);
 }
 
 // ---- k_desc: 16 lanes per output slot (4 slots per wave), a lane owns 4 descriptor channels -------
