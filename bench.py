@@ -103,6 +103,8 @@ def main():
     ap.add_argument("--gather", choices=["allgather", "root", "compact"], default="allgather")
     ap.add_argument("--force-comm", action="store_true", help="run the RCCL exchange also with one rank")
     ap.add_argument("--no-legs", action="store_true", help="timed region only (no host_api / match / aux / cpu legs)")
+    ap.add_argument("--only-match-leg", action="store_true", help="of the extra legs run the matcher ones only (short traces for the PMC passes)")
+    ap.add_argument("--no-bn-leg", action="store_true", help="skip the eval()-BatchNorm legs (their kernels share names with the headline's in a kernel trace)")
     ap.add_argument("--serial-branch", action="store_true", help="XFH_FLAG_SERIAL_BRANCH: no overlapping kernels (for per-kernel profiles)")
     ap.add_argument("--bn", choices=["batch", "running", "folded"], default="batch",
                     help="BatchNorm mode of the timed region: batch = the reference's per-frame statistics (the headline), running = upstream eval(), "
@@ -289,7 +291,7 @@ def legs(out, args, lib, capi, synth, Context, ctx, blob, frames, d_in, d_recb, 
         capi.check(lib.xfh_extract_batch_device(ctx.h, in_ptr, 1, H, W, 0, 0, rec_ptr), ctx.h)
     ctx.synchronize()
     t1 = time.perf_counter()
-    n_single = 300
+    n_single = 300 if not args.only_match_leg else 3
     for _ in range(n_single):
         capi.check(lib.xfh_extract_batch_device(ctx.h, in_ptr, 1, H, W, 0, 0, rec_ptr), ctx.h)
     ctx.synchronize()
@@ -300,7 +302,7 @@ def legs(out, args, lib, capi, synth, Context, ctx, blob, frames, d_in, d_recb, 
     ctx.synchronize()
 
     # ---- the same workload with upstream-XFeat eval() BatchNorm, exact (running) and folded into the weights
-    if args.bn == "batch":
+    if args.bn == "batch" and not args.no_bn_leg and not args.only_match_leg:
         bn = {}
         S = max(1, args.streams)
         for name in ("running", "folded"):
@@ -344,7 +346,7 @@ def legs(out, args, lib, capi, synth, Context, ctx, blob, frames, d_in, d_recb, 
 
     # ---- host API: the path the drop-in XFextractor::operator() takes (host image in, host keypoints / descriptors out)
     host = {}
-    for nfh in (4096, 1000):
+    for nfh in ((4096, 1000) if not args.only_match_leg else ()):
         hc = Context(nfeatures=nfh, max_height=H, max_width=W, max_batch=1, device=ctx.device)
         hc.load_weights(blob)
         k = np.zeros(nfh, capi.KP_DTYPE); d = np.zeros((nfh, 64), np.float32); nv, mono = C.c_int(), C.c_int()
@@ -374,8 +376,9 @@ def legs(out, args, lib, capi, synth, Context, ctx, blob, frames, d_in, d_recb, 
     host["note"] = ("xfh_extract / xfh_extract_submit+collect on one ctx: pageable host image -> pinned -> H2D -> kernels -> record written "
                     "to pinned host memory -> caller's buffers; everything inside the clock (SURVEY.md 8d 'host-visible')")
     out["host_api"] = host
-    out["host_visible"] = {"value": host["nfeatures_4096"]["pipelined_frames_per_s"], "unit": "frames/s",
-                           "note": "single ctx, one frame per call, 2 frames in flight, host memory in and out (nfeatures 4096)"}
+    if host.get("nfeatures_4096"):
+        out["host_visible"] = {"value": host["nfeatures_4096"]["pipelined_frames_per_s"], "unit": "frames/s",
+                               "note": "single ctx, one frame per call, 2 frames in flight, host memory in and out (nfeatures 4096)"}
 
     # ---- matching leg: 4096 x 4096 MNN on the descriptors of frame 0 vs frame 1 (device resident) ----------------------
     d1p = rec_ptr + ctx.desc_off
