@@ -281,7 +281,7 @@ int xfh_load_weights(xfh_ctx* c, const void* blob, size_t nbytes) {
         } else {
             const int coutp = (L.cout + 31) / 32 * 32;
             rc = upload(c, &c->w.mfma[i], pack_mfma(wp, L.cout, L.cin, L.ks, coutp));
-            if (rc == XFH_OK && L.ks == 3 && L.cin >= 64 && L.stride == 1 && i != 10 && i != 11)       // 7, 16, 17 and 13, 14: 32-channel chunks
+            if (rc == XFH_OK && L.ks == 3 && L.cin >= 64)                                                // every 3x3 layer with >= 64 input channels: 32-channel chunks
                 rc = upload(c, &c->w.alt[i], pack_mfma(wp, L.cout, L.cin, L.ks, coutp, 32));
             if (rc == XFH_OK && L.ks == 3 && L.cin == 64 && L.cout == 64 && L.stride == 1)                 // 7, 10, 11, 16, 17: three taps per chunk
                 rc = upload(c, &c->w.alt2[i], pack_mfma(wp, L.cout, L.cin, L.ks, coutp, 64, 3));

@@ -837,7 +837,7 @@ int conv_layer_npart(int li, int Hout, int Wout) {
     if (li < 3) return cdiv(Wout, 16) * cdiv(Hout, 16);
     switch (li) {
         case 7: case 16: case 17: return cdiv(Wout, 16) * cdiv(Hout, 2);     // 8x16 pixels; 2x16 in the small-batch configuration (the larger count sizes the buffers)
-        case 9: case 10: case 11: return cdiv(Wout, 8) * cdiv(Hout, 8);      // WM=2, WW=8
+        case 9: case 10: case 11: return cdiv(Wout, 8) * cdiv(Hout, 8);      // WM=2, WW=8 (10, 11 at B > 1: 16-row tiles, fewer partials)
         case 12: case 13: case 14: case 15: return cdiv(Wout, 8) * cdiv(Hout, 4);   // WM=1, WW=8
         default: return cdiv(Wout, 16) * cdiv(Hout, 8);                       // WM=4, WW=16
     }
@@ -910,7 +910,7 @@ static hipError_t launch_basic_layer_t(xfh_ctx* c, int li, const float* in, size
             if (persistent(B)) { a.w = c->w.alt[li]; e = conv_mfma_p_launch<24, 24, 3, 1, 4, 1, 1, 16, PRO_BN, EPI>(c, a, B, &np, li); }
             else e = conv_mfma_launch<24, 24, 3, 1, 4, 1, 1, 16, PRO_BN, EPI>(c, a, B, &np, li);
             break;
-        case 6: e = conv_mfma_launch<24, 64, 3, 2, 4, 1, 2, 16, PRO_BN, EPI>(c, a, B, &np, li); break;
+        case 6: e = conv_mfma_launch<24, 64, 3, 2, 4, 1, 2, 16, PRO_BN, EPI>(c, a, B, &np, li); break;      // 8x16 pixels; 8x8 pixels (46 KB, three workgroups per CU) measured 526 -> 757 us at B = 256
         case 7: case 17: case 16:
             // the dominant 3x3 64->64 instance: 8x16 pixels x 64 channels per workgroup, 8 waves (4 x 2), 32-channel weight
             // chunks (67 KB LDS -> 2 workgroups per CU); measured 70 us vs 77 us for the 4-wave / 64-channel-chunk form at
@@ -930,14 +930,19 @@ static hipError_t launch_basic_layer_t(xfh_ctx* c, int li, const float* in, size
             if (persistent(B)) e = conv_mfma_p_launch<64, 64, 1, 1, 4, 1, 2, 16, PRO_BN, EPI>(c, a, B, &np, li);
             else e = conv_mfma_launch<64, 64, 1, 1, 4, 1, 2, 16, PRO_BN, EPI>(c, a, B, &np, li);
             break;
-        case 9: e = conv_mfma_launch<64, 64, 3, 2, 2, 2, 1, 8, PRO_BN, EPI>(c, a, B, &np, li); break;
+        case 9:
+            // stride 2 (4.5 input pixels per output pixel): 113 KB of LDS = one workgroup per CU.  Measured alternative: 4x8 pixels with
+            // 32-channel chunks (60 KB, two workgroups per CU) 403 -> 558 us at B = 256 -- a workgroup streams the whole 147 KB weight
+            // matrix from L2 for its tile, so halving the tile doubles that traffic; the small maps are bound by it
+            e = conv_mfma_launch<64, 64, 3, 2, 2, 2, 1, 8, PRO_BN, EPI>(c, a, B, &np, li);
+            break;
         case 10: case 11:
             if (small_batch(B)) { a.w = c->w.alt2[li]; e = conv_mfma_launch<64, 64, 3, 1, 2, 2, 1, 8, PRO_BN, EPI, 64, 3>(c, a, B, &np, li); }   // three taps per chunk
-            else e = conv_mfma_launch<64, 64, 3, 1, 2, 2, 1, 8, PRO_BN, EPI>(c, a, B, &np, li);
+            else { a.w = c->w.alt[li]; e = conv_mfma_launch<64, 64, 3, 1, 4, 2, 1, 8, PRO_BN, EPI, 32>(c, a, B, &np, li); }   // 16x8 pixels, 8 waves, 32-channel chunks (67 KB): half the weight streaming per pixel of the 8x8 form
             break;
-        case 12: e = conv_mfma_launch<64, 128, 3, 2, 1, 4, 1, 8, PRO_BN, EPI>(c, a, B, &np, li); break;
+        case 12: a.w = c->w.alt[li]; e = conv_mfma_launch<64, 128, 3, 2, 1, 4, 1, 8, PRO_BN, EPI, 32>(c, a, B, &np, li); break;      // 32-channel chunks: 111 -> 78 KB of LDS, two workgroups per CU (212 -> 168 us at B = 256)
         case 13: case 14:       // 32-channel weight chunks: 69 KB LDS -> 2 workgroups per CU, 58 -> 50 us at B = 32
-            if (!small_batch(B)) { a.w = c->w.alt[li]; e = conv_mfma_launch<128, 128, 3, 1, 1, 4, 1, 8, PRO_BN, EPI, 32>(c, a, B, &np, li); }
+            if (!small_batch(B)) { a.w = c->w.alt[li]; e = conv_mfma_launch<128, 128, 3, 1, 4, 4, 1, 8, PRO_BN, EPI, 32>(c, a, B, &np, li); }   // 16x8 pixels x 128 channels, 16 waves (132 KB): the 590 KB weight matrix is streamed once per 128 pixels
             else e = conv_mfma_launch<128, 128, 3, 1, 1, 4, 1, 8, PRO_BN, EPI>(c, a, B, &np, li);
             break;
         case 15: e = conv_mfma_launch<128, 64, 1, 1, 1, 2, 1, 8, PRO_BN, EPI>(c, a, B, &np, li); break;
