@@ -444,6 +444,25 @@ void k_conv_mfma(ConvArgs a) {
         const int f = t + q * NTHR;
         if (f < WCH / 4) wreg[q] = *(const f32x4*)(a.w + (size_t)f * 4);
     }
+    // ---- the raw input tile: every load of a thread is issued here, before the statistics are staged and before the first use
+    // (clamped addresses, no branches around the loads: behind a per-item branch they run one memory round trip after the other,
+    // and with one or two workgroups per CU nothing else covers that).  PRO_FUSE gathers its taps per item below.
+    constexpr int NITEM = TIH * TIW * G;
+    constexpr int NIT = (NITEM + NTHR - 1) / NTHR;
+    constexpr bool BATCHED = PRO != PRO_FUSE;
+    f32x4 r0[BATCHED ? NIT : 1], r1[BATCHED ? NIT : 1];
+    float rp[PRO == PRO_B2IN ? NIT : 1];
+    if constexpr (BATCHED) {
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int item = t + k * NTHR, pix = item / G, g = item % G;
+            const int gy = min(max(ty0 * ST - PAD + pix / TIW, 0), a.Hin - 1), gx = min(max(tx0 * ST - PAD + pix % TIW, 0), a.Win - 1);
+            const float* p = in + ((size_t)gy * a.Win + gx) * CIN + g * 8;
+            r0[k] = *(const f32x4*)p;
+            r1[k] = *(const f32x4*)(p + 4);
+            if constexpr (PRO == PRO_B2IN) rp[k] = a.pool[(size_t)b * a.pool_stride + (size_t)gy * a.Win + gx];
+        }
+    }
     // producer statistics -> LDS (folded here for small batches; s_in is still free and serves as fp64 scratch)
     if constexpr (PRO == PRO_BN || PRO == PRO_B2IN || PRO == PRO_FUSE) stage_stat(a.st, b, CIN, tile == 0, s_stat, (double*)s_in, t, NTHR);
     if constexpr (PRO == PRO_B2IN) {
@@ -455,6 +474,38 @@ void k_conv_mfma(ConvArgs a) {
         stage_stat(a.st5, b, 64, tile == 0, s_stat + 256, (double*)s_in, t, NTHR);
     }
     // ---- stage the activated input tile (zero padding outside the image) ----------------
+    if constexpr (BATCHED) {
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int item = t + k * NTHR, pix = item / G, g = item % G;
+            const int gy = ty0 * ST - PAD + pix / TIW, gx = tx0 * ST - PAD + pix % TIW;
+            const bool ok = gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win;
+            if (NITEM % NTHR != 0 && item >= NITEM) continue;
+            f32x4 v0 = r0[k], v1 = r1[k];
+            if constexpr (PRO == PRO_BN || PRO == PRO_B2IN) {
+                const f32x4 m0 = *(const f32x4*)(s_stat + g * 8), m1 = *(const f32x4*)(s_stat + g * 8 + 4);
+                const f32x4 q0 = *(const f32x4*)(s_stat + CIN + g * 8), q1 = *(const f32x4*)(s_stat + CIN + g * 8 + 4);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    v0[q] = fmaxf((v0[q] - m0[q]) * q0[q], 0.f);
+                    v1[q] = fmaxf((v1[q] - m1[q]) * q1[q], 0.f);
+                }
+            }
+            if constexpr (PRO == PRO_B2IN) {            // x1 + skip1(x): AvgPool4 of the normalised image, 1x1 conv with bias (XFeat.cc:36-39,153)
+                const float pl = rp[k];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    v0[q] = v0[q] + (pl * s_stat[2 * CIN + g * 8 + q] + s_stat[3 * CIN + g * 8 + q]);
+                    v1[q] = v1[q] + (pl * s_stat[2 * CIN + g * 8 + 4 + q] + s_stat[3 * CIN + g * 8 + 4 + q]);
+                }
+            }
+            if (!ok) { v0 = f32x4{0.f, 0.f, 0.f, 0.f}; v1 = v0; }
+            // k permutation inside each group of 8: position 4*(k&1) + (k>>1)
+            float* d = s_in + pix * CP + g * 8;
+            *(f32x4*)d = f32x4{v0.x, v0.z, v1.x, v1.z};
+            *(f32x4*)(d + 4) = f32x4{v0.y, v0.w, v1.y, v1.w};
+        }
+    } else
     for (int item = t; item < TIH * TIW * G; item += NTHR) {
         const int pix = item / G, g = item % G;
         const int iy = pix / TIW, ix = pix % TIW;
@@ -464,28 +515,17 @@ void k_conv_mfma(ConvArgs a) {
             const float* p = in + ((size_t)gy * a.Win + gx) * CIN + g * 8;
             v0 = *(const f32x4*)p;
             v1 = *(const f32x4*)(p + 4);
-            if constexpr (PRO == PRO_BN || PRO == PRO_B2IN || PRO == PRO_FUSE) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    v0[q] = fmaxf((v0[q] - s_stat[g * 8 + q]) * s_stat[CIN + g * 8 + q], 0.f);
-                    v1[q] = fmaxf((v1[q] - s_stat[g * 8 + 4 + q]) * s_stat[CIN + g * 8 + 4 + q], 0.f);
-                }
+            for (int q = 0; q < 4; ++q) {
+                v0[q] = fmaxf((v0[q] - s_stat[g * 8 + q]) * s_stat[CIN + g * 8 + q], 0.f);
+                v1[q] = fmaxf((v1[q] - s_stat[g * 8 + 4 + q]) * s_stat[CIN + g * 8 + 4 + q], 0.f);
             }
-            if constexpr (PRO == PRO_B2IN) {            // x1 + skip1(x): AvgPool4 of the normalised image, 1x1 conv with bias (XFeat.cc:36-39,153)
-                const float pl = a.pool[(size_t)b * a.pool_stride + (size_t)gy * a.Win + gx];
+            // x3 + up2(x4) + up4(x5) with ATen's bilinear arithmetic (XFeat.cc:159-166)
+            f32x4 u0, u1, w0, w1;
+            up_bilinear8(a.r4 + (size_t)b * a.s4, s_stat + 128, a.H4, a.W4, a.Hin, a.Win, gy, gx, g, u0, u1);
+            up_bilinear8(a.r5 + (size_t)b * a.s5, s_stat + 256, a.H5, a.W5, a.Hin, a.Win, gy, gx, g, w0, w1);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    v0[q] = v0[q] + (pl * s_stat[2 * CIN + g * 8 + q] + s_stat[3 * CIN + g * 8 + q]);
-                    v1[q] = v1[q] + (pl * s_stat[2 * CIN + g * 8 + 4 + q] + s_stat[3 * CIN + g * 8 + 4 + q]);
-                }
-            }
-            if constexpr (PRO == PRO_FUSE) {            // x3 + up2(x4) + up4(x5) with ATen's bilinear arithmetic (XFeat.cc:159-166)
-                f32x4 u0, u1, w0, w1;
-                up_bilinear8(a.r4 + (size_t)b * a.s4, s_stat + 128, a.H4, a.W4, a.Hin, a.Win, gy, gx, g, u0, u1);
-                up_bilinear8(a.r5 + (size_t)b * a.s5, s_stat + 256, a.H5, a.W5, a.Hin, a.Win, gy, gx, g, w0, w1);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) { v0[q] = (v0[q] + u0[q]) + w0[q]; v1[q] = (v1[q] + u1[q]) + w1[q]; }
-            }
+            for (int q = 0; q < 4; ++q) { v0[q] = (v0[q] + u0[q]) + w0[q]; v1[q] = (v1[q] + u1[q]) + w1[q]; }
         }
         // k permutation inside each group of 8: position 4*(k&1) + (k>>1)
         float* d = s_in + pix * CP + g * 8;
