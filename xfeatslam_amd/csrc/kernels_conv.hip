@@ -676,9 +676,12 @@ void k_conv_mfma_p(ConvArgs a, int ntile, int total) {
     float pl[NIT];                                // PRO_B2IN: pooled image value of the item's pixel
     unsigned inside = 0u;
     auto load_tile = [&](int tile) {              // global -> registers (raw values), remembers which items lie inside the image
+        // branch-free: clamped addresses, every load issued; `inside` is what decides later.  (With a branch per item the compiler
+        // zero-fills the registers and nests two exec-mask regions around each pair of loads: ~30 instructions per item on the
+        // vector pipe the MFMAs of the current tile are waiting for.)
         const int b = tile / ntile, tl = tile - b * ntile;
         const int tx0 = (tl % a.tiles_x) * TW, ty0 = (tl / a.tiles_x) * TH;
-        const float* in = a.in + (size_t)b * a.in_stride;
+        const float* in = a.in + (size_t)b * a.in_stride + g * 8;
         inside = 0u;
 #pragma unroll
         for (int k = 0; k < NIT; ++k) {
@@ -686,12 +689,19 @@ void k_conv_mfma_p(ConvArgs a, int ntile, int total) {
             const int pix = item / G;
             const int iy = pix / TIW, ix = pix % TIW;
             const int gy = ty0 * ST - PAD + iy, gx = tx0 * ST - PAD + ix;
-            v0[k] = f32x4{0.f, 0.f, 0.f, 0.f}; v1[k] = v0[k];
-            if (t < NE && item < NITEM && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win) {
-                const float* p = in + ((size_t)gy * a.Win + gx) * CIN + g * 8;
+            if constexpr (KS == 1) {
+                const int cy = min(max(gy, 0), a.Hin - 1), cx = min(max(gx, 0), a.Win - 1);
+                const float* p = in + (cy * a.Win + cx) * CIN;
                 v0[k] = *(const f32x4*)p; v1[k] = *(const f32x4*)(p + 4);
-                if constexpr (PRO == PRO_B2IN) pl[k] = a.pool[(size_t)b * a.pool_stride + (size_t)gy * a.Win + gx];
-                inside |= 1u << k;
+                inside |= (gy == cy && gx == cx) ? (1u << k) : 0u;
+            } else {                              // 3x3 layers (24 -> 24, 8 -> 24): the branchy form measured 3-5 % faster there
+                v0[k] = f32x4{0.f, 0.f, 0.f, 0.f}; v1[k] = v0[k];
+                if (t < NE && item < NITEM && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win) {
+                    const float* p = in + (gy * a.Win + gx) * CIN;
+                    v0[k] = *(const f32x4*)p; v1[k] = *(const f32x4*)(p + 4);
+                    if constexpr (PRO == PRO_B2IN) pl[k] = a.pool[(size_t)b * a.pool_stride + (size_t)gy * a.Win + gx];
+                    inside |= 1u << k;
+                }
             }
         }
     };
@@ -711,8 +721,18 @@ void k_conv_mfma_p(ConvArgs a, int ntile, int total) {
             const int item = t + k * NE;
             if (t < NE && item < NITEM) {
                 f32x4 x0 = v0[k], x1 = v1[k];
-                if constexpr (PRO == PRO_BN || PRO == PRO_B2IN) {
-                    if (inside & (1u << k)) {
+                const bool in_img = inside & (1u << k);
+                if constexpr (KS == 1) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if constexpr (PRO == PRO_BN) {
+                            x0[q] = fmaxf((x0[q] - m0[q]) * r0[q], 0.f);
+                            x1[q] = fmaxf((x1[q] - m1[q]) * r1[q], 0.f);
+                        }
+                        x0[q] = in_img ? x0[q] : 0.f; x1[q] = in_img ? x1[q] : 0.f;      // tile overhang
+                    }
+                } else if constexpr (PRO == PRO_BN || PRO == PRO_B2IN) {
+                    if (in_img) {
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             x0[q] = fmaxf((x0[q] - m0[q]) * r0[q], 0.f);
