@@ -195,9 +195,13 @@ void k_conv_direct(ConvArgs a) {
     constexpr int SL = 256 / COUT;
     static_assert(PRO != PRO_L0 || (CIN == 4 && ST == 2 && COUT == 8), "PRO_L0 is block1.1");
     constexpr int XW = TI + 2, XS = XW + 1;      // PRO_L0: image window of the tile's block1.0 inputs, row stride
-    __shared__ __attribute__((aligned(16))) float s_in[TI * TI * CIN];
-    __shared__ __attribute__((aligned(16))) float s_out[(PRO == PRO_L0 && XW * XS > 256 * (COUT + 1)) ? XW * XS : 256 * (COUT + 1)];
-    __shared__ double s_red[(SL * COUT * 2 > 512) ? SL * COUT * 2 : 512];
+    // LDS: the input tile; the statistics transposition of the epilogue reuses it (one more barrier) -- at 22 KB (block1.1) / 11 KB
+    // (block1.2) a workgroup fits beside two workgroups of the dominant convolution (134 of 160 KB) when several ctx share the GPU
+    constexpr int SIN = TI * TI * CIN > 256 * (COUT + 1) ? TI * TI * CIN : 256 * (COUT + 1);
+    __shared__ __attribute__((aligned(16))) float s_in[SIN];
+    float* s_out = s_in;
+    __shared__ __attribute__((aligned(16))) float s_xwin[PRO == PRO_L0 ? XW * XS : 1];
+    __shared__ double s_red[FOLD ? 512 : 8 * COUT];
     const int t = threadIdx.x, b = blockIdx.z;
     const int tile = blockIdx.x, tx0 = (tile % a.tiles_x) * 16, ty0 = (tile / a.tiles_x) * 16;
     const float* in = a.in + (size_t)b * a.in_stride;
@@ -210,7 +214,7 @@ void k_conv_direct(ConvArgs a) {
     constexpr int G = CIN / VEC;
     if constexpr (PRO == PRO_L0) {
         // block1.0 recomputed: normalised image window -> conv 1->4 -> BatchNorm + ReLU -> s_in (see k_block1_stats)
-        float* s_x = s_out;                                                                       // free until the epilogue
+        float* s_x = s_xwin;
         const float xm = a.xstat[b * 2], xr = a.xstat[b * 2 + 1];
         // all loads of a thread are issued before the first use (clamped addresses, no branches around them)
         constexpr int NX = (XW * XW + 255) / 256;
@@ -332,6 +336,7 @@ void k_conv_direct(ConvArgs a) {
     if constexpr (EPI != EPI_STATS) return;
     // per-channel fp64 partial sums of this tile: thread (c, j) adds the pixels j, j + SL, ... of channel c, the slices
     // of a wave are folded with shuffles and the four waves through LDS -- a fixed order, and no serial chain
+    __syncthreads();                                      // every thread is done with the input tile: its memory becomes s_out
 #pragma unroll
     for (int co = 0; co < COUT; ++co) s_out[t * (COUT + 1) + co] = valid ? acc[co] : 0.f;
     __syncthreads();
