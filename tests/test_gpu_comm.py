@@ -67,3 +67,53 @@ def test_rccl_world1_gathers_match_records(gpu_lib):
     comm.close()
     assert L.xfh_allgather_records(ctx.h, d_rec[0].ptr, B, d_all.ptr, 0) == 1   # no communicator any more
     ctx.close()
+
+
+def test_several_ctx_feed_one_communicator(gpu_lib):
+    """bench.py's layout: sub-batches of a step on separate ctx write one record buffer, ctx 0 owns the communicator.
+    xfh_comm_wait_ctx orders the collective after the other ctx' streams, xfh_comm_fence_ctx keeps them from overwriting a
+    generation the collective is still reading -- no host synchronisation between the steps."""
+    from xfeatslam_amd.extractor import Context
+    L = capi.lib()
+    nf, H, W, B, S = 256, 96, 128, 6, 3
+    blob = WT.pack_blob(WT.make_synthetic(1234, 6.0))
+    ctxs = [Context(nfeatures=nf, max_height=H, max_width=W, max_batch=B) for _ in range(S)]
+    for c in ctxs:
+        c.load_weights(blob)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    comm = xd.Comm(ctxs[0], 0, 1, "127.0.0.1", port)
+    steps = 5
+    frames = synth.frames(steps * S * B, H, W, seed=21)
+    rec = ctxs[0].rec_bytes
+    d_in = capi.DeviceBuffer(frames.nbytes).upload(frames)
+    d_rec = [capi.DeviceBuffer(S * B * rec) for _ in range(2)]
+    d_all = [capi.DeviceBuffer(S * B * rec) for _ in range(steps)]          # one gather target per step, compared at the end
+    for step in range(steps):
+        g = step & 1
+        comm.fence(g)
+        for c in ctxs[1:]:
+            comm.fence_ctx(c, g)
+        for k, c in enumerate(ctxs):
+            off = (step * S + k) * B
+            capi.check(L.xfh_extract_batch_device(c.h, d_in.ptr + off * H * W, B, H, W, 0, 64, d_rec[g].ptr + k * B * rec), c.h)
+        for c in ctxs[1:]:
+            comm.wait_ctx(c)
+        comm.allgather_records(d_rec[g].ptr, S * B, d_all[step].ptr, g)
+    comm.synchronize()
+    for c in ctxs:
+        c.synchronize()
+    ref = Context(nfeatures=nf, max_height=H, max_width=W, max_batch=B, flags=capi.FLAG_SERIAL_BRANCH); ref.load_weights(blob)
+    for step in range(steps):
+        got = ctxs[0].parse_records(d_all[step].download(np.uint8, S * B * rec), S * B)
+        want = []
+        for k in range(S):
+            off = (step * S + k) * B
+            want += ref.extract_batch(frames[off:off + B], (0, 64))
+        for i, (a, b) in enumerate(zip(got, want)):
+            for x, y in zip(a, b):
+                assert np.array_equal(x, y), (step, i)
+    assert L.xfh_comm_wait_ctx(ctxs[1].h, ctxs[0].h) == 1                      # ctx 1 has no communicator
+    comm.close(); ref.close()
+    for c in ctxs:
+        c.close()
