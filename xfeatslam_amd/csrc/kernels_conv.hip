@@ -827,6 +827,189 @@ void k_conv_mfma_p(ConvArgs a, int ntile, int total) {
 }
 
 // ------------------------------------------------------------------------------------
+// k_chain1x1: consecutive 1x1 convolutions 64 -> 64 at 1/8 resolution in ONE pass over the pixels, wherever nothing but a bias
+// (and a ReLU) separates them.  In use: block_fusion.2 -> heatmap_head.0 (fusion.2 is a bare Conv2d, XFeat.cc:75) for B > 8 in
+// every BatchNorm mode; the template also covers three stages and bias+ReLU hand-overs (the folded-BatchNorm head chains), which
+// were measured and are not instantiated (launch_fusion_chain).  Persistent like k_conv_mfma_p (same tiles, same K order, hence
+// the same bits per layer); the output of a stage goes from the MFMA's C/D layout (lane = channel, registers = pixels) straight
+// back into the wave's own 32 pixel rows of the LDS tile in the A-operand layout (k-permuted channels) -- a 1x1 convolution needs
+// no other wave's pixels, so there is no barrier between the stages and the handed-on map is not read back from HBM.
+enum { MID_BIAS_STORE = 0 /* y = acc + bias, stored (fusion.2 -> feats) and handed on */, MID_BIAS_RELU = 1 /* folded BatchNorm + ReLU, handed on only */ };
+struct ChainArgs {
+    ConvArgs a;                               // input / prologue / geometry; a.w, a.bias: stage 0; a.out, a.part: the LAST stage
+    const float* w1; const float* bias1;      // stage 1
+    const float* w2; const float* bias2;      // stage 2 (NL == 3)
+    float* mid_out; size_t mid_stride;        // MID_BIAS_STORE: where stage 0's map is stored
+};
+template <int NL, int WM, int PRO, int MID0, int EPI>
+__global__ __launch_bounds__(64 * WM)
+void k_chain1x1(ChainArgs ca, int ntile, int total) {
+    constexpr int CIN = 64, COUT = 64, NT = 2, WW = 16, WH = 2, TH = WM * WH, TW = WW;
+    constexpr int NTHR = 64 * WM, COUTP = 64, CP = CIN + 4, WS = CIN + 4, G = CIN / 8;
+    constexpr int NITEM = TH * TW * G, NIT = (NITEM + NTHR - 1) / NTHR;
+    constexpr int IN_FLOATS = TH * TW * CP, W_FLOATS = COUTP * WS;
+    static_assert(NTHR % G == 0 && NIT <= 32, "staging");
+    const ConvArgs& a = ca.a;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_in = smem;
+    float* s_w = smem + IN_FLOATS;               // NL weight matrices
+    double* s_red = (double*)(s_w + NL * W_FLOATS);
+
+    const int t = threadIdx.x;
+    {
+        const float* ws[3] = {a.w, ca.w1, ca.w2};
+#pragma unroll
+        for (int l = 0; l < NL; ++l)
+            for (int f = t; f < COUTP * (CIN / 4); f += NTHR) {
+                const int n = f / (CIN / 4), c4 = f % (CIN / 4);
+                *(f32x4*)(s_w + l * W_FLOATS + n * WS + c4 * 4) = *(const f32x4*)(ws[l] + (size_t)f * 4);
+            }
+    }
+    const int g = t % G;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, i = lane & 31, h = lane >> 5;
+    const int wm = wave;
+
+    f32x4 v0[NIT], v1[NIT];
+    unsigned inside = 0u;
+    auto load_tile = [&](int tile) {
+        const int b = tile / ntile, tl = tile - b * ntile;
+        const int tx0 = (tl % a.tiles_x) * TW, ty0 = (tl / a.tiles_x) * TH;
+        const float* in = a.in + (size_t)b * a.in_stride + g * 8;
+        inside = 0u;
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int pix = (t + k * NTHR) / G;
+            const int gy = ty0 + pix / TW, gx = tx0 + pix % TW;
+            const int cy = min(gy, a.Hin - 1), cx = min(gx, a.Win - 1);
+            const float* p = in + (cy * a.Win + cx) * CIN;
+            v0[k] = *(const f32x4*)p; v1[k] = *(const f32x4*)(p + 4);
+            inside |= (gy == cy && gx == cx) ? (1u << k) : 0u;
+        }
+    };
+    auto store_tile = [&](int tile) {
+        f32x4 m0, m1, r0, r1;
+        if constexpr (PRO == PRO_BN) {
+            const float* st = a.st.stat + (size_t)(tile / ntile) * 2 * CIN + g * 8;
+            m0 = *(const f32x4*)st; m1 = *(const f32x4*)(st + 4); r0 = *(const f32x4*)(st + CIN); r1 = *(const f32x4*)(st + CIN + 4);
+        }
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int item = t + k * NTHR;
+            if (NITEM % NTHR != 0 && item >= NITEM) continue;
+            f32x4 x0 = v0[k], x1 = v1[k];
+            const bool in_img = inside & (1u << k);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if constexpr (PRO == PRO_BN) {
+                    x0[q] = fmaxf((x0[q] - m0[q]) * r0[q], 0.f);
+                    x1[q] = fmaxf((x1[q] - m1[q]) * r1[q], 0.f);
+                }
+                x0[q] = in_img ? x0[q] : 0.f; x1[q] = in_img ? x1[q] : 0.f;
+            }
+            float* d = s_in + (item / G) * CP + g * 8;
+            *(f32x4*)d = f32x4{x0.x, x0.z, x1.x, x1.z};
+            *(f32x4*)(d + 4) = f32x4{x0.y, x0.w, x1.y, x1.w};
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile >= total) return;
+    float bias0[NT], bias1[NT], biasl[NT];
+    conv_bias<COUT, NT, EPI_BIAS>(a.bias, i, bias0);
+    if constexpr (NL == 3) conv_bias<COUT, NT, EPI_BIAS>(ca.bias1, i, bias1);
+    conv_bias<COUT, NT, EPI>(NL == 3 ? ca.bias2 : ca.bias1, i, biasl);
+    load_tile(tile);
+    store_tile(tile);
+    __syncthreads();
+    const float* pa = s_in + (wm * 32 + i) * CP + 4 * h;         // this lane's pixel row as the A operand
+    float* const mid_row = s_in + (wm * 32 + 4 * h) * CP;        // C/D layout: register r holds pixel (r&3) + 8*(r>>2) + 4*h of the wave's block
+    while (true) {
+        const int next = tile + gridDim.x;
+        const bool has_next = next < total;
+        if (has_next) load_tile(next);
+        const int b = tile / ntile, tl = tile - b * ntile;
+        const int tx0 = (tl % a.tiles_x) * TW, ty0 = (tl / a.tiles_x) * TH, oy0 = ty0 + wm * WH;
+
+        f32x16 acc[NT];
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+            const float* pw = s_w + l * W_FLOATS + i * WS + 4 * h;
+#pragma unroll
+            for (int kk = 0; kk < CIN / 8; ++kk) {
+                const f32x4 av = *(const f32x4*)(pa + kk * 8);
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const f32x4 bv = *(const f32x4*)(pw + n * 32 * WS + kk * 8);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc[n], 0, 0, 0);
+                }
+            }
+            if (l == NL - 1) break;
+            // ---- hand the stage's output on as the next stage's A operand (this wave's own pixel rows)
+            const bool store_mid = l == 0 && MID0 == MID_BIAS_STORE;
+            if (store_mid) {
+                double dsum[NT], dsq[NT];
+                float* wave_out = ca.mid_out + (size_t)b * ca.mid_stride + ((size_t)oy0 * a.Wout + tx0) * COUT;
+                conv_epilogue<COUT, NT, WW, WH, EPI_BIAS>(acc, wave_out, a.Wout, a.Hout - oy0, a.Wout - tx0, i, h, bias0, dsum, dsq);
+            } else {
+                XFH_MFMA_SETTLE();
+            }
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int c = n * 32 + i;
+                const int pos = (c & ~7) + 4 * (c & 1) + ((c & 7) >> 1);      // k permutation inside each group of 8
+                const float bv = l == 0 ? bias0[n] : bias1[n];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[n][r] + bv;
+                    if (!store_mid) v = fmaxf(v, 0.f);
+                    mid_row[((r & 3) + 8 * (r >> 2)) * CP + pos] = v;
+                }
+            }
+        }
+
+        // ---- epilogue of the last stage (as k_conv_mfma_p)
+        double sum[NT], sq[NT];
+        {
+            float* wave_out = a.out + (size_t)b * a.out_stride + ((size_t)oy0 * a.Wout + tx0) * COUT;
+            conv_epilogue<COUT, NT, WW, WH, EPI>(acc, wave_out, a.Wout, a.Hout - oy0, a.Wout - tx0, i, h, biasl, sum, sq);
+        }
+        if constexpr (EPI == EPI_STATS) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                sum[n] += __shfl_xor(sum[n], 32);
+                sq[n] += __shfl_xor(sq[n], 32);
+                if (h == 0) {
+                    const int co = n * 32 + i;
+                    s_red[(wm * COUTP + co) * 2 + 0] = sum[n];
+                    s_red[(wm * COUTP + co) * 2 + 1] = sq[n];
+                }
+            }
+        }
+        __syncthreads();                          // every wave is done with s_in; s_red is complete
+        if constexpr (EPI == EPI_STATS) {
+            for (int co = t; co < COUT; co += NTHR) {
+                double S = 0.0, SS = 0.0;
+#pragma unroll
+                for (int m = 0; m < WM; ++m) { S += s_red[(m * COUTP + co) * 2 + 0]; SS += s_red[(m * COUTP + co) * 2 + 1]; }
+                double* p = a.part + (size_t)b * a.part_stride + ((size_t)tl * COUT + co) * 2;
+                p[0] = S; p[1] = SS;
+            }
+        }
+        if (!has_next) break;
+        store_tile(next);
+        __syncthreads();
+        tile = next;
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // host side: layer -> template instance
 template <int CIN, int COUT, int KS, int ST, int WM, int WN, int NT, int WW, int PRO, int EPI, int CBMAX = 64, int TPC = 1>
 static hipError_t conv_mfma_launch(xfh_ctx* c, const ConvArgs& a, int B, int* npart_out, int layer) {
@@ -1043,6 +1226,62 @@ hipError_t launch_fusion_out(xfh_ctx* c, int Hh, int Wh, int B) {
     a.part = nullptr; a.part_stride = 0;
     if (persistent(B)) return conv_mfma_p_launch<64, 64, 1, 1, 4, 1, 2, 16, PRO_BN, EPI_BIAS>(c, a, B, nullptr, 23);
     return conv_mfma_launch<64, 64, 1, 1, 4, 1, 2, 16, PRO_BN, EPI_BIAS>(c, a, B, nullptr, 23);
+}
+
+// ---- chains of 1x1 layers (k_chain1x1) ----------------------------------------------------------
+template <int NL, int WM, int PRO, int MID0, int EPI>
+static hipError_t chain_launch(xfh_ctx* c, const ChainArgs& ca, int B, int* npart_out, int layer) {
+    constexpr int TH = 2 * WM, TW = 16;
+    constexpr size_t LDS = sizeof(float) * ((size_t)TH * TW * 68 + (size_t)NL * 64 * 68) + sizeof(double) * WM * 64 * 2;
+    static_assert(LDS <= 160 * 1024, "LDS budget");
+    ChainArgs aa = ca;
+    aa.a.tiles_x = (ca.a.Wout + TW - 1) / TW;
+    const int ntile = aa.a.tiles_x * ((ca.a.Hout + TH - 1) / TH);
+    if (npart_out) *npart_out = ntile;
+    auto kern = k_chain1x1<NL, WM, PRO, MID0, EPI>;
+    XFH_SET_LDS_ATTR_ONCE(c, kern, LDS);
+    const int total = ntile * B;
+    const int per_cu = (int)((160 * 1024) / LDS);
+    const int grid = total < 256 * per_cu ? total : 256 * per_cu;
+    launch_k(c, XFH_K_CONV_MFMA, layer, kern, dim3(grid), dim3(64 * WM), LDS, aa, ntile, total);
+    return hipGetLastError();
+}
+
+// block_fusion.2 (-> feats) and the heatmap-head layers that follow it without a BatchNorm in between: heatmap_head.0 always
+// (fusion.2 is a bare Conv2d), heatmap_head.1 too when the BatchNorms are folded.  *done = number of head layers computed.
+hipError_t launch_fusion_chain(xfh_ctx* c, int Hh, int Wh, int B, int* done) {
+    *done = 0;
+    if (!persistent(B)) return launch_fusion_out(c, Hh, Wh, B);
+    const bool folded = c->cfg.bn_mode == XFH_BN_RUNNING_FOLDED;
+    ChainArgs ca{};
+    ConvArgs& a = ca.a;
+    a.in = c->raw[17]; a.st = stat_src(c, 17, B); a.in_stride = c->raw_stride[17]; a.Hin = Hh; a.Win = Wh; a.Hout = Hh; a.Wout = Wh;
+    a.w = c->w.fus2; a.bias = c->w.fus2_bias;
+    ca.mid_out = c->feats; ca.mid_stride = c->raw_stride[17];
+    ca.w1 = c->w.mfma[18];
+    int np = 0;
+    hipError_t e;
+    if (!folded) {
+        a.out = c->raw[18]; a.out_stride = c->raw_stride[18]; a.part = c->part[18]; a.part_stride = c->part_stride[18];
+        e = chain_launch<2, 4, PRO_BN, MID_BIAS_STORE, EPI_STATS>(c, ca, B, &np, 18);
+        if (e != hipSuccess) return e;
+        c->lh[18] = Hh; c->lw[18] = Wh; c->npart[18] = np;
+        *done = 1;
+        if (c->cfg.bn_mode == XFH_BN_BATCH_STATS)
+            hipLaunchKernelGGL(k_bn_finalize, dim3(B), dim3(256), 0, c->stream, (const double*)c->part[18], c->part_stride[18], np, 64, (double)Hh * (double)Wh, c->stat[18]);
+        return hipGetLastError();
+    }
+    // folded BatchNorms: more layers could follow in the same pass (heatmap_head.1 here; keypoint_head.0 -> .1 -> .2).  Measured at
+    // 256 frames: three stages (87 KB of LDS: 4 waves per CU, each stage waiting for the previous one's MFMAs and an LDS round trip)
+    // -3 % on the whole step, two-stage chains for both heads -0.3 % -- these layers are bound by the vector pipe (MFMA + the
+    // VALU work of staging / handing on), not by the 315 MB each intermediate map costs in HBM traffic, so only this one is kept
+    ca.bias1 = c->w.bn_bias[18];
+    a.out = c->raw[18]; a.out_stride = c->raw_stride[18];
+    e = chain_launch<2, 4, PRO_BN, MID_BIAS_STORE, EPI_BIAS_RELU>(c, ca, B, &np, 18);
+    if (e != hipSuccess) return e;
+    c->lh[18] = Hh; c->lw[18] = Wh; c->npart[18] = np;
+    *done = 1;
+    return hipSuccess;
 }
 
 // InstanceNorm statistics of the image reuse the finalize kernel with C = 1
