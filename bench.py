@@ -401,10 +401,28 @@ def legs(out, args, lib, capi, synth, Context, ctx, blob, frames, d_in, d_recb, 
     ctx.timing_enable(0)
     n_matches = int(mout.download(np.int32, 1, 12 * nf)[0])
     hm = (mout.download(np.int32, n_matches), mout.download(np.int32, n_matches, 4 * nf))
-    # prepared images (xfh_match_prepare_device once per frame, then two launches per pair)
-    img1 = capi.DeviceBuffer(int(lib.xfh_match_image_bytes(nf))); img2 = capi.DeviceBuffer(int(lib.xfh_match_image_bytes(nf)))
+    # the device-resident hand-off: xfh_extract_batch_device_images writes each frame's descriptors also as the matcher's prepared
+    # image (k_desc applies k_rownorm_img's function to the rows it has just produced), so a frame pair costs two launches
+    ib = int(lib.xfh_match_image_bytes(nf))
+    imgs = capi.DeviceBuffer(2 * ib)
+    img1 = capi.DeviceBuffer(ib); img2 = capi.DeviceBuffer(ib)
     capi.check(lib.xfh_match_prepare_device(ctx.h, d1p, nf, img1.ptr), ctx.h)
     capi.check(lib.xfh_match_prepare_device(ctx.h, d2p, nf, img2.ptr), ctx.h)
+    images_equal = None
+    if B > 1:
+        rec2 = capi.DeviceBuffer(2 * rec_bytes)
+        capi.check(lib.xfh_extract_batch_device_images(ctx.h, in_ptr, 2, H, W, 0, 0, rec2.ptr, imgs.ptr), ctx.h)
+        ctx.synchronize()
+        images_equal = bool(np.array_equal(imgs.download(np.uint8, ib), img1.download(np.uint8, ib)) and
+                            np.array_equal(imgs.download(np.uint8, ib, ib), img2.download(np.uint8, ib)))
+        hand1, hand2 = imgs.ptr, imgs.ptr + ib
+    else:
+        hand1, hand2 = img1.ptr, img2.ptr
+    c_prep, c_raw = C.c_double(0.0), C.c_double(0.0)
+    capi.check(lib.xfh_bench_match_prepared(ctx.h, hand1, nf, hand2, nf, -1.0, *mo, max(args.match_iters, 50), C.byref(c_prep)), ctx.h)
+    n_matches_h = int(mout.download(np.int32, 1, 12 * nf)[0])
+    hh = (mout.download(np.int32, n_matches_h), mout.download(np.int32, n_matches_h, 4 * nf))
+    capi.check(lib.xfh_bench_match_raw(ctx.h, d1p, nf, d2p, nf, -1.0, *mo, max(args.match_iters, 50), C.byref(c_raw)), ctx.h)
 
     def match_prepared():
         capi.check(lib.xfh_match_mnn_prepared_device(ctx.h, img1.ptr, nf, img2.ptr, nf, -1.0, *mo), ctx.h)
@@ -432,10 +450,16 @@ def legs(out, args, lib, capi, synth, Context, ctx, blob, frames, d_in, d_recb, 
     capi.check(lib.xfh_bench_mnn_gemm(ctx.h, img1.ptr, nf, img2.ptr, nf, 300, C.byref(gemm_b2b)), ctx.h)
     gemm_us = ms_gemm / max(n_gemm, 1) * 1e3
     gemm_tf = 2.0 * nf * nf * 64 / (gemm_us * 1e-6) / 1e12 if n_gemm else 0.0
-    out["match"] = {"pairs_per_s": nf * nf / match_dt, "us_per_call": match_dt * 1e6, "n1": nf, "n2": nf, "n_matches": n_matches,
-                    "call": "xfh_match_mnn_device on raw descriptor rows: k_rownorm_img + k_mnn_gemm_img + k_mnn_post, back to back from a ctypes loop",
+    out["match"] = {"pairs_per_s": nf * nf / (c_prep.value * 1e-6), "us_per_call": c_prep.value, "n1": nf, "n2": nf, "n_matches": n_matches_h,
+                    "call": "device-resident hand-off: the two frames' prepared images come out of xfh_extract_batch_device_images, the match is "
+                            "xfh_match_mnn_prepared_device (k_mnn_gemm_img + k_mnn_post), calls back to back from a C loop (xfh_bench_match_prepared: "
+                            "wall time between two stream events / calls)",
+                    "images_from_extraction_equal_prepare_device": images_equal,
+                    "pairs_equal_raw": bool(np.array_equal(hm[0], hh[0]) and np.array_equal(hm[1], hh[1])),
+                    "raw_rows": {"pairs_per_s": nf * nf / (c_raw.value * 1e-6), "us_per_call": c_raw.value, "ctypes_loop_us_per_call": match_dt * 1e6,
+                                 "call": "xfh_match_mnn_device on raw descriptor rows: k_rownorm_img + k_mnn_gemm_img + k_mnn_post (C loop / Python ctypes loop)"},
                     "prepared": {"pairs_per_s": nf * nf / prep_dt, "us_per_call": prep_dt * 1e6,
-                                 "call": "xfh_match_mnn_prepared_device on two panel images (xfh_match_prepare_device once per frame): k_mnn_gemm_img + k_mnn_post",
+                                 "call": "xfh_match_mnn_prepared_device on two images made by xfh_match_prepare_device, from a Python ctypes loop",
                                  "pairs_equal_raw": bool(np.array_equal(hm[0], hp[0]) and np.array_equal(hm[1], hp[1]))},
                     "host_api_us_per_call": host_match_dt * 1e6,
                     "roofline": {"kernel": "k_mnn_gemm_img", "bound": "mfma", "achieved": gemm_tf, "peak": PEAK_F32_MFMA_TFLOPS,

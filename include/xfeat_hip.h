@@ -132,6 +132,13 @@ int xfh_extract_batch(xfh_ctx* ctx, const uint8_t* gray, int B, int H, int W, in
  * an RCCL all-gather); asynchronous on the ctx stream -- call xfh_synchronize to wait. */
 int xfh_extract_batch_device(xfh_ctx* ctx, const uint8_t* d_gray, int B, int H, int W, int lap_x0,
                              int lap_x1, void* d_records_out);
+/* the same, and each frame's descriptor block is also written as the matcher's PREPARED IMAGE (see xfh_match_prepare_device):
+ * d_images_out holds B images of xfh_match_image_bytes(nfeatures) bytes, image b = what xfh_match_prepare_device makes of the
+ * nfeatures descriptor rows of record b, bit for bit (padding slots are rows of zeros).  The frame-to-frame match of the tracker
+ * (frame t against t-1) is then xfh_match_mnn_prepared_device on two of these images with n1 = n2 = nfeatures: two launches, no
+ * normalisation pass over descriptors that k_desc has only just written. */
+int xfh_extract_batch_device_images(xfh_ctx* ctx, const uint8_t* d_gray, int B, int H, int W, int lap_x0,
+                                    int lap_x1, void* d_records_out, void* d_images_out);
 
 /* ---- matching ----------------------------------------------------------------------
  * ORBmatcher::match (declared ORBmatcher.h:77; its definition is commented out at
@@ -264,6 +271,12 @@ int xfh_timing_read(xfh_ctx* ctx, int* launches, double* total_ms);
 /* `iters` launches of the match GEMM alone, back to back, on two prepared images: wall time per launch between two stream
  * events.  (Dispatch-attached timestamps of consecutive kernels in a busy stream overlap; this is the steady-state cost.) */
 int xfh_bench_mnn_gemm(xfh_ctx* ctx, const void* d_image1, int n1, const void* d_image2, int n2, int iters, double* us_per_launch);
+/* `iters` whole xfh_match_mnn_prepared_device calls (both launches; _raw: xfh_match_mnn_device, three) back to back from C: wall time per call between two stream
+ * events -- what a C++ caller's loop sees, without the per-call cost of a foreign-function binding. */
+int xfh_bench_match_prepared(xfh_ctx* ctx, const void* d_image1, int n1, const void* d_image2, int n2, float min_cossim,
+                             int* d_idx1, int* d_idx2, float* d_dist, int* d_n_matches, int iters, double* us_per_call);
+int xfh_bench_match_raw(xfh_ctx* ctx, const float* d_d1, int n1, const float* d_d2, int n2, float min_cossim,
+                        int* d_idx1, int* d_idx2, float* d_dist, int* d_n_matches, int iters, double* us_per_call);   /* the same for xfh_match_mnn_device */
 const char* xfh_kernel_name(int kernel_id);
 
 /* intermediate tensors of frame `frame` of the last extract call, copied to host as float

@@ -405,3 +405,46 @@ def test_random_sizes_all_batch_regimes(gpu_lib, oracle_mod):
             assert np.array_equal(hk["size"] == 0, ok["size"] == 0)
             dd, ds, n = joined_desc_diff(hk, hd, ok, od)
             assert n == onv and dd < DESC_TOL and ds < 1e-6
+
+
+@pytest.mark.parametrize("nf", [512, 300])
+def test_extraction_emits_prepared_match_images(gpu_lib, oracle_mod, nf):
+    """xfh_extract_batch_device_images: k_desc also writes each frame's descriptors as the matcher's prepared image.  The image
+    is bit for bit what xfh_match_prepare_device makes of the record's descriptor block (sparse frames: padding slots are rows of
+    zeros; nf = 300: the rows up to the panel boundary too), the record is unchanged, and the frame-to-frame match on the
+    images gives the oracle's pairs."""
+    from xfeatslam_amd.extractor import Context
+    L = capi.lib()
+    H, W, B = 96, 128, 3
+    blob = WT.pack_blob(WT.make_synthetic(1234, 2.0))                   # low gain: fewer candidates than slots -> padding rows
+    fr = synth.frames(B, H, W, seed=31)
+    fr[2] = np.roll(fr[1], 3, axis=1)                                   # a shifted copy: many mutual matches
+    ctx = Context(nfeatures=nf, max_height=H, max_width=W, max_batch=B); ctx.load_weights(blob)
+    rb, ib = ctx.rec_bytes, int(L.xfh_match_image_bytes(nf))
+    d_in = capi.DeviceBuffer(fr.nbytes).upload(fr)
+    d_rec, d_rec2 = capi.DeviceBuffer(B * rb), capi.DeviceBuffer(B * rb)
+    d_img = capi.DeviceBuffer(B * ib)
+    capi.check(L.xfh_extract_batch_device_images(ctx.h, d_in.ptr, B, H, W, 0, 64, d_rec.ptr, d_img.ptr), ctx.h)
+    capi.check(L.xfh_extract_batch_device(ctx.h, d_in.ptr, B, H, W, 0, 64, d_rec2.ptr), ctx.h)
+    ctx.synchronize()
+    raw = d_rec.download(np.uint8, B * rb)
+    assert np.array_equal(raw, d_rec2.download(np.uint8, B * rb))
+    recs = ctx.parse_records(raw, B)
+    assert any(r[2] < nf for r in recs)                                 # padding slots exist
+    imgs = d_img.download(np.uint8, B * ib).reshape(B, ib)
+    d_one = capi.DeviceBuffer(ib)
+    for b in range(B):
+        capi.check(L.xfh_match_prepare_device(ctx.h, d_rec.ptr + b * rb + ctx.desc_off, nf, d_one.ptr), ctx.h)
+        ctx.synchronize()
+        assert np.array_equal(imgs[b], d_one.download(np.uint8, ib)), b
+    class Img:                                                          # match_mnn_prepared takes (buffer-with-ptr, n)
+        def __init__(self, ptr): self.ptr = ptr
+    i1, i2, dist = ctx.match_mnn_prepared((Img(d_img.ptr + 1 * ib), nf), (Img(d_img.ptr + 2 * ib), nf))
+    a = oracle_mod.match_mnn(recs[1][1], recs[2][1])
+    assert np.array_equal(a[0], i1) and np.array_equal(a[1], i2) and len(i1) > 10
+    # the C-side timing loop runs the same call
+    us = C.c_double(0)
+    out = capi.DeviceBuffer(12 * nf + 64)
+    assert L.xfh_bench_match_prepared(ctx.h, d_img.ptr + ib, nf, d_img.ptr + 2 * ib, nf, -1.0, out.ptr, out.ptr + 4 * nf, out.ptr + 8 * nf, out.ptr + 12 * nf, 5, C.byref(us)) == 0
+    assert us.value > 0
+    ctx.close()

@@ -57,6 +57,7 @@ SYMBOLS = [
     ("xfh_record_desc_offset", _sz, [_i]),
     ("xfh_extract_batch", _i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     ("xfh_extract_batch_device", _i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    ("xfh_extract_batch_device_images", _i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     ("xfh_match_mnn", _i, [_vp, _vp, _i, _vp, _i, _f, _vp, _vp, _vp, _pi]),
     ("xfh_match_mnn_device", _i, [_vp, _vp, _i, _vp, _i, _f, _vp, _vp, _vp, _vp]),
     ("xfh_match_image_bytes", _sz, [_i]),
@@ -97,6 +98,8 @@ SYMBOLS = [
     ("xfh_timing_enable", _i, [_vp, _i, C.c_uint]),
     ("xfh_timing_read", _i, [_vp, _pi, C.POINTER(C.c_double)]),
     ("xfh_bench_mnn_gemm", _i, [_vp, _vp, _i, _vp, _i, _i, C.POINTER(C.c_double)]),
+    ("xfh_bench_match_prepared", _i, [_vp, _vp, _i, _vp, _i, C.c_float, _vp, _vp, _vp, _vp, _i, C.POINTER(C.c_double)]),
+    ("xfh_bench_match_raw", _i, [_vp, _vp, _i, _vp, _i, C.c_float, _vp, _vp, _vp, _vp, _i, C.POINTER(C.c_double)]),
     ("xfh_kernel_name", C.c_char_p, [_i]),
     ("xfh_debug_tensor", _i, [_vp, _i, _i, _vp, _sz, C.POINTER(_sz)]),
 ]

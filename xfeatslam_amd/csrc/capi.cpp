@@ -364,6 +364,15 @@ int xfh_extract_batch_device(xfh_ctx* c, const uint8_t* d_gray, int B, int H, in
     return XFH_OK;
 }
 
+int xfh_extract_batch_device_images(xfh_ctx* c, const uint8_t* d_gray, int B, int H, int W, int lap0, int lap1, void* d_records, void* d_images) {
+    int rc = check_extract(c, d_gray, B, H, W);
+    if (rc != XFH_OK) return rc;
+    if (!d_records || !d_images || (((uintptr_t)d_images) & 15)) return XFH_ERR_INVALID_ARG;
+    HIPCK(c, hipSetDevice(c->cfg.device));
+    HIPCK(c, run_extract(c, d_gray, B, H, W, lap0, lap1, (uint8_t*)d_records, true, (float*)d_images));
+    return XFH_OK;
+}
+
 int xfh_extract_batch(xfh_ctx* c, const uint8_t* gray, int B, int H, int W, int lap0, int lap1, void* records_out) {
     int rc = check_extract(c, gray, B, H, W);
     if (rc != XFH_OK) return rc;
@@ -696,6 +705,38 @@ int xfh_bench_mnn_gemm(xfh_ctx* c, const void* image1, int n1, const void* image
     HIPCK(c, hipSetDevice(c->cfg.device));
     HIPCK(c, bench_mnn_gemm(c, (const float*)image1, n1, (const float*)image2, n2, iters, us_per_launch));
     return XFH_OK;
+}
+static int bench_match(xfh_ctx* c, bool prepared, const void* a1, int n1, const void* a2, int n2, float min_cossim,
+                       int* idx1, int* idx2, float* dist, int* n_matches, int iters, double* us_per_call) {
+    if (!c || !a1 || !a2 || n1 < 1 || n2 < 1 || iters < 1 || !us_per_call || !idx1 || !idx2 || !dist || !n_matches) return XFH_ERR_INVALID_ARG;
+    HIPCK(c, hipSetDevice(c->cfg.device));
+    hipEvent_t e0, e1;
+    HIPCK(c, hipEventCreate(&e0));
+    if (hipEventCreate(&e1) != hipSuccess) { hipEventDestroy(e0); return XFH_ERR_HIP; }
+    auto call = [&]() {
+        return prepared ? launch_mnn_prepared(c, (const float*)a1, n1, (const float*)a2, n2, min_cossim, idx1, idx2, dist, n_matches)
+                        : launch_mnn(c, (const float*)a1, n1, (const float*)a2, n2, min_cossim, idx1, idx2, dist, n_matches);
+    };
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < 200 && e == hipSuccess; ++i) e = call();            // the clocks settle over a few hundred of these ~30 us calls
+    if (e == hipSuccess) e = hipEventRecord(e0, c->stream);
+    for (int i = 0; i < iters && e == hipSuccess; ++i) e = call();
+    if (e == hipSuccess) e = hipEventRecord(e1, c->stream);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    *us_per_call = (double)ms * 1e3 / iters;
+    HIPCK(c, e);
+    return XFH_OK;
+}
+int xfh_bench_match_prepared(xfh_ctx* c, const void* image1, int n1, const void* image2, int n2, float min_cossim,
+                             int* idx1, int* idx2, float* dist, int* n_matches, int iters, double* us_per_call) {
+    return bench_match(c, true, image1, n1, image2, n2, min_cossim, idx1, idx2, dist, n_matches, iters, us_per_call);
+}
+int xfh_bench_match_raw(xfh_ctx* c, const float* d1, int n1, const float* d2, int n2, float min_cossim,
+                        int* idx1, int* idx2, float* dist, int* n_matches, int iters, double* us_per_call) {
+    return bench_match(c, false, d1, n1, d2, n2, min_cossim, idx1, idx2, dist, n_matches, iters, us_per_call);
 }
 int xfh_timing_enable(xfh_ctx* c, int kernel_id, unsigned layer_mask) {
     if (!c || kernel_id < 0 || kernel_id >= XFH_K_COUNT) return XFH_ERR_INVALID_ARG;

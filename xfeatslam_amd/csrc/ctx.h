@@ -104,4 +104,5 @@ inline void launch_k(xfh_ctx* c, int kernel_id, int layer, K kern, dim3 grid, di
     } while (0)
 
 // launchers (kernels_*.hip)
-hipError_t run_extract(xfh_ctx* c, const uint8_t* d_gray, int B, int H0, int W0, int lap0, int lap1, uint8_t* d_records, bool write_padding = true);
+hipError_t run_extract(xfh_ctx* c, const uint8_t* d_gray, int B, int H0, int W0, int lap0, int lap1, uint8_t* d_records, bool write_padding = true,
+                       float* d_images = nullptr);

@@ -12,6 +12,7 @@
 //   k_desc         F::normalize of the sampled feature pixels (:273), bilinear descriptor sampling + L2 normalise + record packing (:298-301, 323-343)
 // Compiled with -ffp-contract=off: every fused multiply-add below is written as fmaf().
 #include "ctx.h"
+#include "mnn_layout.h"
 #include <stdlib.h>
 
 // ---- small helpers -----------------------------------------------------------------------
@@ -595,7 +596,8 @@ void k_feat_norm(const float* __restrict__ feats, size_t m_stride, int npix, flo
 __global__ __launch_bounds__(256)
 void k_desc(const float* __restrict__ feats, size_t m_stride, const float* __restrict__ fnorm, size_t n_stride,
             const int* __restrict__ slot_src, const u64* __restrict__ sel_key,
-            int H, int W, int nfeatures, float rw, float rh, uint8_t* __restrict__ records, size_t rec_bytes, size_t kps_off, size_t desc_off, int write_padding) {
+            int H, int W, int nfeatures, float rw, float rh, uint8_t* __restrict__ records, size_t rec_bytes, size_t kps_off, size_t desc_off, int write_padding,
+            float* __restrict__ images /* or null: one prepared match image per frame (mnn_layout.h) */, size_t image_floats) {
     const int b = blockIdx.z;
     const int slot = blockIdx.x * 16 + (threadIdx.x >> 4), l = threadIdx.x & 15;
     const bool in_range = slot < nfeatures;
@@ -635,6 +637,10 @@ void k_desc(const float* __restrict__ feats, size_t m_stride, const float* __res
         ss = fma((double)v[q], (double)v[q], ss);
     }
     ss += __shfl_xor(ss, 8); ss += __shfl_xor(ss, 4); ss += __shfl_xor(ss, 2); ss += __shfl_xor(ss, 1);
+    const Recip kn = recip_of(fmaxf((float)sqrt(ss), 1e-12f));
+    const f32x4 dsc = live ? f32x4{div_by(v[0], kn), div_by(v[1], kn), div_by(v[2], kn), div_by(v[3], kn)} : f32x4{0.f, 0.f, 0.f, 0.f};
+    // the matcher's prepared image of this frame: every slot up to the panel boundary, padding slots as rows of zeros
+    if (images) mnn_emit_row(dsc, slot, l, images + (size_t)b * image_floats);
     if (!in_range) return;
     if (!live) {
         if (!write_padding) return;        // host-visible record (xfh_extract_submit): the host pads, nothing crosses PCIe
@@ -644,8 +650,7 @@ void k_desc(const float* __restrict__ feats, size_t m_stride, const float* __res
         *(f32x4*)dd = f32x4{0.f, 0.f, 0.f, 0.f};
         return;
     }
-    const Recip kn = recip_of(fmaxf((float)sqrt(ss), 1e-12f));
-    *(f32x4*)dd = f32x4{div_by(v[0], kn), div_by(v[1], kn), div_by(v[2], kn), div_by(v[3], kn)};
+    *(f32x4*)dd = dsc;
     if (l < 7) {
         // KeyPoint(x, y, 1, -1, score): octave 0, class_id -1 (XFextractor.cc:329); the Long rescale at :304-305
         // multiplies by 1: rw = rh = 1 unless XFH_FLAG_RESCALE_KEYPOINTS asks for input coordinates
@@ -667,7 +672,7 @@ bool consumer_fold(int B);
 #define CK(x) do { hipError_t _e = (x); if (_e != hipSuccess) return _e; } while (0)
 enum { PRO_PLAIN = 0, PRO_BN = 1, PRO_IN = 2, PRO_B2IN = 3, PRO_FUSE = 4, PRO_L0 = 5 };
 
-hipError_t run_extract(xfh_ctx* c, const uint8_t* d_gray, int B, int H0, int W0, int lap0, int lap1, uint8_t* d_records, bool write_padding) {
+hipError_t run_extract(xfh_ctx* c, const uint8_t* d_gray, int B, int H0, int W0, int lap0, int lap1, uint8_t* d_records, bool write_padding, float* d_images) {
     const int H = (H0 / 32) * 32, W = (W0 / 32) * 32;
     c->B = B; c->H0 = H0; c->W0 = W0; c->H = H; c->W = W;
     const int h4 = H / 4, w4 = W / 4, h8 = H / 8, w8 = W / 8;
@@ -765,7 +770,9 @@ hipError_t run_extract(xfh_ctx* c, const uint8_t* d_gray, int B, int H0, int W0,
     CK(hipGetLastError());
     hipLaunchKernelGGL(k_feat_norm, dim3((h8 * w8 + 255) / 256, 1, B), dim3(256), 0, s, (const float*)c->feats, c->raw_stride[17], h8 * w8, c->feat_nrm, xs / 64);
     CK(hipGetLastError());
-    launch_k(c, XFH_K_DESC, -1, k_desc, dim3((nf + 15) / 16, 1, B), dim3(256), 0, c->feats, c->raw_stride[17], (const float*)c->feat_nrm, xs / 64, c->slot_src, c->sel_key, H, W, nf, rw, rh,
-                       d_records, rec, xfh_record_kps_offset(), xfh_record_desc_offset(nf), write_padding ? 1 : 0);
+    const int dslots = d_images ? (nf + MNN_PANEL - 1) / MNN_PANEL * MNN_PANEL : nf;      // image rows run to the panel boundary
+    launch_k(c, XFH_K_DESC, -1, k_desc, dim3((dslots + 15) / 16, 1, B), dim3(256), 0, c->feats, c->raw_stride[17], (const float*)c->feat_nrm, xs / 64, c->slot_src, c->sel_key, H, W, nf, rw, rh,
+                       d_records, rec, xfh_record_kps_offset(), xfh_record_desc_offset(nf), write_padding ? 1 : 0,
+             d_images, (size_t)(dslots / MNN_PANEL) * MNN_PANEL_FLOATS);
     return hipGetLastError();
 }

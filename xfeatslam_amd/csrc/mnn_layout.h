@@ -49,3 +49,22 @@ __device__ __forceinline__ u64 mnn_pack_key(float v, unsigned idx) {
 }
 __device__ __forceinline__ u64 mnn_umax64(u64 a, u64 b) { return a > b ? a : b; }
 
+
+// One descriptor row -> its normalised row in the panel image.  Sixteen lanes hold the row (lane `sub` the elements 4*sub .. 4*sub+3;
+// a row of zeros for padding).  F::normalize as the oracle states it: fp64 sum of squares, fp32 sqrt / max(., 1e-12) / divide.
+// Shared by k_rownorm_img (rows from a caller's descriptor array) and k_desc (the rows it has just produced: the extraction then
+// hands the matcher a prepared image and k_rownorm_img disappears from the frame-to-frame match) -- one function, the same bits.
+__device__ __forceinline__ void mnn_emit_row(const f32x4 v, int row, int sub, float* __restrict__ img) {
+    double ss = (double)v.x * (double)v.x + (double)v.y * (double)v.y + (double)v.z * (double)v.z + (double)v.w * (double)v.w;
+    ss += __shfl_xor(ss, 1); ss += __shfl_xor(ss, 2); ss += __shfl_xor(ss, 4); ss += __shfl_xor(ss, 8);
+    const float nrm = fmaxf((float)sqrt(ss), 1e-12f);
+    const float a = v.x / nrm, b = v.y / nrm, c = v.z / nrm, e = v.w / nrm;
+    // this lane holds elements 4*sub .. 4*sub+3; its pair lane (sub^1) holds the other half of the group of 8.
+    // even lane writes the piece of the even elements (e0 e2 e4 e6), odd lane the piece of the odd ones.
+    const bool odd = sub & 1;
+    const float sx = odd ? a : b, sy = odd ? c : e;            // what the partner needs from me
+    const float rx = __shfl_xor(sx, 1), ry = __shfl_xor(sy, 1);
+    const f32x4 outv = odd ? f32x4{rx, ry, b, e} : f32x4{a, c, rx, ry};
+    const int pos = mnn_pos(row & (MNN_PANEL - 1));
+    *(f32x4*)(img + (size_t)(row >> 8) * MNN_PANEL_FLOATS + mnn_piece(pos, sub >> 1, odd ? 1 : 0)) = outv;
+}

@@ -20,19 +20,7 @@ void k_rownorm_img(const float* __restrict__ d1, int n1, const float* __restrict
     float* img = second ? img2 : img1;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (row < n) v = *(const f32x4*)(d + (size_t)row * 64 + sub * 4);
-    double ss = (double)v.x * (double)v.x + (double)v.y * (double)v.y + (double)v.z * (double)v.z + (double)v.w * (double)v.w;
-    ss += __shfl_xor(ss, 1); ss += __shfl_xor(ss, 2); ss += __shfl_xor(ss, 4); ss += __shfl_xor(ss, 8);
-    const float nrm = fmaxf((float)sqrt(ss), 1e-12f);
-    const float a = v.x / nrm, b = v.y / nrm, c = v.z / nrm, e = v.w / nrm;
-    // this lane holds elements 4*sub .. 4*sub+3; its pair lane (sub^1) holds the other half of the group of 8.
-    // even lane writes the piece of the even elements (e0 e2 e4 e6), odd lane the piece of the odd ones.
-    const bool odd = sub & 1;
-    const float sx = odd ? a : b, sy = odd ? c : e;            // what the partner needs from me
-    const float rx = __shfl_xor(sx, 1), ry = __shfl_xor(sy, 1);
-    const f32x4 outv = odd ? f32x4{rx, ry, b, e} : f32x4{a, c, rx, ry};
-    const int r256 = row & (MNN_PANEL - 1);
-    const int pos = mnn_pos(r256);
-    *(f32x4*)(img + (size_t)(row >> 8) * MNN_PANEL_FLOATS + mnn_piece(pos, sub >> 1, odd ? 1 : 0)) = outv;
+    mnn_emit_row(v, row, sub, img);
 }
 
 // panel base + 16 * position of a row, and its swizzle term
