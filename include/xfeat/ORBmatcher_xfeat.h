@@ -62,6 +62,36 @@ public:
         for (int k = 0; k < n; ++k) _matches.emplace_back(DMatch(i1[k], i2[k], d[k]));   // :401
     }
 
+    // The same match on two PREPARED images in device memory (XFextractor::extractBatchDevice with d_images, or
+    // xfh_match_prepare_device): the tracker's frame-to-frame match without a normalisation pass, two kernel launches.  n1 / n2 =
+    // rows the images were made from (nfeatures for images written by the extraction).  Blocks until the result is on the host.
+    void matchPrepared(const void* d_image1, int n1, const void* d_image2, int n2, std::vector<DMatch>& _matches, float min_cossim = -1.f) {
+        _matches.clear();
+        if (n1 <= 0 || n2 <= 0) return;
+        const int nm = n1 < n2 ? n1 : n2;
+        const size_t bytes = (size_t)nm * 12 + 16;
+        if (bytes > d_out_bytes) {
+            if (d_out) xfh_dev_free(d_out);
+            d_out = nullptr; d_out_bytes = 0;
+            if (xfh_dev_alloc(&d_out, bytes) != XFH_OK) throw std::runtime_error("XFmatcher::matchPrepared: out of device memory");
+            d_out_bytes = bytes;
+        }
+        char* o = (char*)d_out;
+        int rc = xfh_match_mnn_prepared_device(ctx, d_image1, n1, d_image2, n2, min_cossim, (int*)o, (int*)(o + 4 * (size_t)nm), (float*)(o + 8 * (size_t)nm),
+                                               (int*)(o + 12 * (size_t)nm));
+        if (rc == XFH_OK) rc = xfh_synchronize(ctx);
+        if (rc != XFH_OK) throw std::runtime_error(std::string("XFmatcher::matchPrepared: ") + xfh_strerror(rc));
+        int n = 0;
+        xfh_memcpy_d2h(&n, o + 12 * (size_t)nm, 4);
+        i1.resize(nm); i2.resize(nm); d.resize(nm);
+        if (n > 0) { xfh_memcpy_d2h(i1.data(), o, 4 * (size_t)n); xfh_memcpy_d2h(i2.data(), o + 4 * (size_t)nm, 4 * (size_t)n); xfh_memcpy_d2h(d.data(), o + 8 * (size_t)nm, 4 * (size_t)n); }
+        _matches.reserve(n);
+        for (int k = 0; k < n; ++k) _matches.emplace_back(DMatch(i1[k], i2[k], d[k]));
+    }
+    ~XFmatcher() { if (d_out) xfh_dev_free(d_out); }
+    XFmatcher(const XFmatcher&) = delete;
+    XFmatcher& operator=(const XFmatcher&) = delete;
+
     // Guided matching: the inner loop of SearchByProjection / SearchByBoW / SearchForTriangulation / Fuse
     // (ORBmatcher.cc:75-119): best and second-best DescriptorDistance over per-query candidate lists
     // (CSR: offsets[nq+1], indices[]) with the reference's initial value 256 for both.
@@ -95,6 +125,7 @@ protected:
     xfh_ctx* ctx;
     std::vector<int> i1, i2;
     std::vector<float> d;
+    void* d_out = nullptr; size_t d_out_bytes = 0;          // device result buffer of matchPrepared
 };
 
 }  // namespace ORB_SLAM3

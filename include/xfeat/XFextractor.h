@@ -82,7 +82,7 @@ public:
 
     // reference: XFextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST)
     XFextractor(int _nfeatures, float _scaleFactor, int _nlevels, int _iniThFAST, int _minThFAST,
-                int max_height = 1088, int max_width = 1920, int device = 0, const char* weights_path = nullptr, int flags = 0)
+                int max_height = 1088, int max_width = 1920, int device = 0, const char* weights_path = nullptr, int flags = 0, int max_batch = 1)
         : nfeatures(_nfeatures), scaleFactor(_scaleFactor), nlevels(_nlevels), iniThFAST(_iniThFAST), minThFAST(_minThFAST) {
         // scale tables, XFextractor.cc:80-96
         mvScaleFactor.resize(nlevels); mvLevelSigma2.resize(nlevels);
@@ -110,7 +110,7 @@ public:
         mnFeaturesPerLevel[nlevels - 1] = std::max(nfeatures - sum, 0);
 
         xfh_config cfg; xfh_config_default(&cfg);
-        cfg.device = device; cfg.max_height = max_height; cfg.max_width = max_width; cfg.nfeatures = nfeatures; cfg.max_batch = 1; cfg.flags = flags;
+        cfg.device = device; cfg.max_height = max_height; cfg.max_width = max_width; cfg.nfeatures = nfeatures; cfg.max_batch = max_batch; cfg.flags = flags;
         int rc = xfh_create(&cfg, &ctx);
         if (rc != XFH_OK) throw std::runtime_error(std::string("XFextractor: xfh_create: ") + xfh_strerror(rc));
         std::string path = weights_path ? weights_path : getModelWeightsPath("weights/xfeat.xfhw");
@@ -191,7 +191,29 @@ public:
 
     xfh_ctx* context() { return ctx; }                       // for ORBmatcher::match on the same GPU
 
+    // ---- batch / multi-GPU use (not in the reference): frames and records stay in HBM ------------------------
+    // B frames [B][H][W] u8 at d_gray -> B records (xfh_record_bytes(nfeatures) each) at d_records, asynchronous on the object's
+    // stream; with d_images each frame's descriptors also come out as the matcher's prepared image (xfh_match_image_bytes(nfeatures)
+    // each) for XFmatcher::matchPrepared.  B <= the max_batch given to the constructor.
+    void extractBatchDevice(const uint8_t* d_gray, int B, int H, int W, int lap0, int lap1, void* d_records, void* d_images = nullptr) {
+        check(d_images ? xfh_extract_batch_device_images(ctx, d_gray, B, H, W, lap0, lap1, d_records, d_images)
+                       : xfh_extract_batch_device(ctx, d_gray, B, H, W, lap0, lap1, d_records), "extractBatchDevice");
+    }
+    void synchronize() { check(xfh_synchronize(ctx), "synchronize"); }
+    // frame i of a global batch is extracted on rank i % world; the records travel to the SLAM rank through RCCL, called by the
+    // library on this object's communication stream (the next extraction overlaps the exchange).  id: XFH_UNIQUE_ID_BYTES from
+    // commUniqueId() on rank 0, shipped to the other ranks by the caller.
+    static void commUniqueId(void* id) { if (xfh_comm_unique_id(id) != XFH_OK) throw std::runtime_error("XFextractor: xfh_comm_unique_id failed (librccl missing?)"); }
+    void commCreate(const void* id, int rank, int world) { check(xfh_comm_create(ctx, id, rank, world), "commCreate"); }
+    void commFence(int gen) { check(xfh_comm_fence(ctx, gen), "commFence"); }                 // before overwriting record buffer `gen`
+    void allgatherRecords(const void* d_records, int B, void* d_all, int gen) { check(xfh_allgather_records(ctx, d_records, B, d_all, gen), "allgatherRecords"); }
+    void gatherRecordsRoot(const void* d_records, int B, void* d_all, int root, int gen) { check(xfh_gather_records_root(ctx, d_records, B, d_all, root, gen), "gatherRecordsRoot"); }
+    void commSynchronize() { check(xfh_comm_synchronize(ctx), "commSynchronize"); }
+
 protected:
+    void check(int rc, const char* what) {
+        if (rc != XFH_OK) throw std::runtime_error(std::string("XFextractor::") + what + ": " + xfh_strerror(rc) + " " + xfh_last_hip_error(ctx));
+    }
     // reference getModelWeightsPath (:151-159): relative to this source file; $XFH_WEIGHTS overrides
     std::string getModelWeightsPath(std::string weights) {
         if (const char* e = std::getenv("XFH_WEIGHTS")) return e;

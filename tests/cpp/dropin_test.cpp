@@ -48,6 +48,40 @@ int main(int argc, char** argv) {
             matcher.distinctive(desc, off, ind, pos, med);
             if (pos.size() != 1 || pos[0] != 0 || med[0] != 0) return 6;
         }
+        // ---- batch / hand-off / multi-GPU methods of the wrappers: two device-resident frames, prepared images, the frame-to-frame
+        // match on the images (must equal match() on the host descriptors), and the record exchange with a communicator of one rank
+        {
+            XFextractor bx(nf, 1.2f, 8, 20, 7, H, W, 0, argv[1], 0, /*max_batch*/ 2);
+            const size_t fb = (size_t)H * W, rb = xfh_record_bytes(nf), ib = xfh_match_image_bytes(nf);
+            void *d_gray = nullptr, *d_rec = nullptr, *d_img = nullptr, *d_all = nullptr;
+            if (xfh_dev_alloc(&d_gray, 2 * fb) || xfh_dev_alloc(&d_rec, 2 * rb) || xfh_dev_alloc(&d_img, 2 * ib) || xfh_dev_alloc(&d_all, 2 * rb)) return 7;
+            std::vector<unsigned char> two(2 * fb);
+            memcpy(two.data(), im.data, fb);
+            for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x) two[fb + (size_t)y * W + x] = im.data[(size_t)y * W + (x + 2) % W];   // frame 1: shifted copy
+            xfh_memcpy_h2d(d_gray, two.data(), 2 * fb);
+            bx.extractBatchDevice((const uint8_t*)d_gray, 2, H, W, lap[0], lap[1], d_rec, d_img);
+            bx.synchronize();
+            std::vector<unsigned char> recs(2 * rb), all(2 * rb);
+            xfh_memcpy_d2h(recs.data(), d_rec, 2 * rb);
+            XFmatcher bm(bx.context());
+            std::vector<XFmatcher::DMatch> mp, mh;
+            bm.matchPrepared(d_img, nf, (char*)d_img + ib, nf, mp);
+            XFextractor::Mat da(nf, 64, 4), db(nf, 64, 4);
+            memcpy(da.data, recs.data() + xfh_record_desc_offset(nf), (size_t)nf * 256);
+            memcpy(db.data, recs.data() + rb + xfh_record_desc_offset(nf), (size_t)nf * 256);
+            bm.match(da, db, mh);
+            if (mp.size() != mh.size() || mp.empty()) return 8;
+            for (size_t k = 0; k < mp.size(); ++k) if (mp[k].queryIdx != mh[k].queryIdx || mp[k].trainIdx != mh[k].trainIdx) return 8;
+            char id[XFH_UNIQUE_ID_BYTES];
+            XFextractor::commUniqueId(id);
+            bx.commCreate(id, 0, 1);
+            bx.commFence(0);
+            bx.gatherRecordsRoot(d_rec, 2, d_all, 0, 0);
+            bx.commSynchronize();
+            xfh_memcpy_d2h(all.data(), d_all, 2 * rb);
+            if (memcmp(all.data(), recs.data(), 2 * rb) != 0) return 9;
+            xfh_dev_free(d_gray); xfh_dev_free(d_rec); xfh_dev_free(d_img); xfh_dev_free(d_all);
+        }
     } catch (const std::exception& e) {
         fprintf(stderr, "exception: %s\n", e.what());
         return 1;
