@@ -164,6 +164,14 @@ int xfh_match_prepare_device(xfh_ctx* ctx, const float* d_desc, int n, void* d_i
 int xfh_match_mnn_prepared_device(xfh_ctx* ctx, const void* d_image1, int n1, const void* d_image2, int n2,
                                   float min_cossim, int* d_idx1, int* d_idx2, float* d_dist, int* d_n_matches);
 
+/* n_valid-aware match of two extraction records (option).  ORBmatcher::match treats the zero rows that pad a record
+ * like descriptors (they have similarity 0 with everything and can end up in mutual pairs); here every pair that touches a padding
+ * slot is dropped.  d_record1/2: records of this ctx' nfeatures (only their headers are read: valid slots are [0, mono_index) and
+ * [nfeatures - (n_valid - mono_index), nfeatures)); d_image1/2: their prepared images (xfh_extract_batch_device_images).  Indices
+ * are slot numbers; everything else as xfh_match_mnn_prepared_device. */
+int xfh_match_records_device(xfh_ctx* ctx, const void* d_record1, const void* d_image1, const void* d_record2, const void* d_image2,
+                             float min_cossim, int* d_idx1, int* d_idx2, float* d_dist, int* d_n_matches);
+
 /* ORBmatcher::DescriptorDistance (ORBmatcher.cc:2242-2250), XFeat branch:
  * (int)(float(cv::norm(a, b, NORM_L2SQR)) * 512).  Scalar host version, stateless. */
 int xfh_descriptor_distance(const float* a, const float* b);
@@ -267,7 +275,8 @@ enum {
 /* layer_mask selects conv layers for XFH_K_CONV_*: 0 = every layer, else bit i = BasicLayer i
  * (0..22 in XFeatModel order) and bit 23 = block_fusion.2 */
 int xfh_timing_enable(xfh_ctx* ctx, int kernel_id, unsigned layer_mask);
-int xfh_timing_read(xfh_ctx* ctx, int* launches, double* total_ms);
+int xfh_timing_read(xfh_ctx* ctx, int* launches, double* total_ms);   /* XFH_ERR_BATCH_TOO_LARGE: more than 4096 launches matched since
+                                                                          * xfh_timing_enable; *launches / *total_ms cover the first 4096 */
 /* `iters` launches of the match GEMM alone, back to back, on two prepared images: wall time per launch between two stream
  * events.  (Dispatch-attached timestamps of consecutive kernels in a busy stream overlap; this is the steady-state cost.) */
 int xfh_bench_mnn_gemm(xfh_ctx* ctx, const void* d_image1, int n1, const void* d_image2, int n2, int iters, double* us_per_launch);

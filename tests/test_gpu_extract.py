@@ -448,3 +448,35 @@ def test_extraction_emits_prepared_match_images(gpu_lib, oracle_mod, nf):
     assert L.xfh_bench_match_prepared(ctx.h, d_img.ptr + ib, nf, d_img.ptr + 2 * ib, nf, -1.0, out.ptr, out.ptr + 4 * nf, out.ptr + 8 * nf, out.ptr + 12 * nf, 5, C.byref(us)) == 0
     assert us.value > 0
     ctx.close()
+
+
+def test_match_records_drops_padding_pairs(gpu_lib, oracle_mod):
+    """xfh_match_records_device (n_valid-aware option): the reference's match() lets the zero rows that pad a record
+    take part; this form reports the same pairs minus those that touch a padding slot.  Frames with few keypoints, one lapping
+    area that puts some of them into the back segment."""
+    from xfeatslam_amd.extractor import Context
+    L = capi.lib()
+    H, W, nf = 96, 128, 512
+    blob = WT.pack_blob(WT.make_synthetic(1234, 2.0))
+    fr = synth.frames(2, H, W, seed=31)
+    fr[1] = np.roll(fr[0], 2, axis=1)
+    ctx = Context(nfeatures=nf, max_height=H, max_width=W, max_batch=2); ctx.load_weights(blob)
+    rb, ib = ctx.rec_bytes, int(L.xfh_match_image_bytes(nf))
+    d_in = capi.DeviceBuffer(fr.nbytes).upload(fr)
+    d_rec, d_img = capi.DeviceBuffer(2 * rb), capi.DeviceBuffer(2 * ib)
+    capi.check(L.xfh_extract_batch_device_images(ctx.h, d_in.ptr, 2, H, W, 40, 90, d_rec.ptr, d_img.ptr), ctx.h)
+    out = capi.DeviceBuffer(12 * nf + 64)
+    capi.check(L.xfh_match_records_device(ctx.h, d_rec.ptr, d_img.ptr, d_rec.ptr + rb, d_img.ptr + ib, -1.0, out.ptr, out.ptr + 4 * nf, out.ptr + 8 * nf, out.ptr + 12 * nf), ctx.h)
+    ctx.synchronize()
+    n = int(out.download(np.int32, 1, 12 * nf)[0])
+    got = set(zip(out.download(np.int32, n).tolist(), out.download(np.int32, n, 4 * nf).tolist()))
+    recs = ctx.parse_records(d_rec.download(np.uint8, 2 * rb), 2)
+    (k1, d1, nv1, mo1, _), (k2, d2, nv2, mo2, _) = recs
+    assert 0 < nv1 < nf and 0 < mo1 < nv1                                 # padding exists, and a back segment
+    a = oracle_mod.match_mnn(d1, d2)                                      # the reference's semantics: padding rows take part
+    valid1 = lambda i: i < mo1 or i >= nf - (nv1 - mo1)
+    valid2 = lambda j: j < mo2 or j >= nf - (nv2 - mo2)
+    want = {(int(i), int(j)) for i, j in zip(a[0], a[1]) if valid1(i) and valid2(j)}
+    assert got == want and len(want) > 10
+    assert all(k1["size"][i] > 0 and k2["size"][j] > 0 for i, j in got)
+    ctx.close()

@@ -105,8 +105,8 @@ int main(int argc, char** argv) {
         };
         auto post = [&](hipEvent_t a, hipEvent_t b) {
             const int nb = (n1 + 15) / 16, ncoll = mnn_ncoll(n1); const dim3 g(nb + ncoll);
-            if (a) hipExtLaunchKernelGGL(k_mnn_post<0>, g, dim3(256), MNN_POST_LDS, s, a, b, 0, (const float*)img1, n1, (const float*)img2, n2, (const u64*)bR, ldr, P2, (const u64*)bC, ldc, P1, -1.0f, pairs, nb, ncoll, idx1, idx2, dist, nm, (long long*)nullptr);
-            else hipLaunchKernelGGL(k_mnn_post<0>, g, dim3(256), MNN_POST_LDS, s, (const float*)img1, n1, (const float*)img2, n2, (const u64*)bR, ldr, P2, (const u64*)bC, ldc, P1, -1.0f, pairs, nb, ncoll, idx1, idx2, dist, nm, (long long*)nullptr);
+            if (a) hipExtLaunchKernelGGL(k_mnn_post<0>, g, dim3(256), MNN_POST_LDS, s, a, b, 0, (const float*)img1, n1, (const float*)img2, n2, (const u64*)bR, ldr, P2, (const u64*)bC, ldc, P1, -1.0f, pairs, nb, ncoll, idx1, idx2, dist, nm, (long long*)nullptr, (const int*)nullptr, (const int*)nullptr);
+            else hipLaunchKernelGGL(k_mnn_post<0>, g, dim3(256), MNN_POST_LDS, s, (const float*)img1, n1, (const float*)img2, n2, (const u64*)bR, ldr, P2, (const u64*)bC, ldc, P1, -1.0f, pairs, nb, ncoll, idx1, idx2, dist, nm, (long long*)nullptr, (const int*)nullptr, (const int*)nullptr);
         };
         for (int v = 0; v < NV; ++v) {
             rownorm(nullptr, nullptr);
@@ -160,7 +160,7 @@ int main(int argc, char** argv) {
                 for (int rep = 0; rep < 3; ++rep) {
                     CK(hipMemset(st, 0, 64 * 8));
                     rownorm(nullptr, nullptr); probe_gemm(1, s, nullptr, nullptr, img1, n1, img2, n2, bR, ldr, bC, ldc, pairs);
-                    hipLaunchKernelGGL(k_mnn_post<1>, dim3((n1 + 15) / 16 + mnn_ncoll(n1)), dim3(256), MNN_POST_LDS, s, (const float*)img1, n1, (const float*)img2, n2, (const u64*)bR, ldr, P2, (const u64*)bC, ldc, P1, -1.0f, pairs, (n1 + 15) / 16, mnn_ncoll(n1), idx1, idx2, dist, nm, st);
+                    hipLaunchKernelGGL(k_mnn_post<1>, dim3((n1 + 15) / 16 + mnn_ncoll(n1)), dim3(256), MNN_POST_LDS, s, (const float*)img1, n1, (const float*)img2, n2, (const u64*)bR, ldr, P2, (const u64*)bC, ldc, P1, -1.0f, pairs, (n1 + 15) / 16, mnn_ncoll(n1), idx1, idx2, dist, nm, st, (const int*)nullptr, (const int*)nullptr);
                     CK(hipStreamSynchronize(s));
                     long long h[64]; CK(hipMemcpy(h, st, 64 * 8, hipMemcpyDeviceToHost));
                     printf("  post stamps (us after block 0 start): block0 loads %.2f chain %.2f second %.2f stored %.2f | collector start %.2f", (h[1] - h[0]) / 100.0, (h[2] - h[0]) / 100.0, (h[3] - h[0]) / 100.0, (h[4] - h[0]) / 100.0, (h[16] - h[0]) / 100.0);

@@ -63,6 +63,7 @@ SYMBOLS = [
     ("xfh_match_image_bytes", _sz, [_i]),
     ("xfh_match_prepare_device", _i, [_vp, _vp, _i, _vp]),
     ("xfh_match_mnn_prepared_device", _i, [_vp, _vp, _i, _vp, _i, _f, _vp, _vp, _vp, _vp]),
+    ("xfh_match_records_device", _i, [_vp, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp, _vp]),
     ("xfh_descriptor_distance", _i, [_vp, _vp]),
     ("xfh_distance_i32", _i, [_vp, _vp, _i, _vp, _i, _vp]),
     ("xfh_distance_i32_device", _i, [_vp, _vp, _i, _vp, _i, _vp]),

@@ -529,6 +529,20 @@ int xfh_match_mnn_prepared_device(xfh_ctx* c, const void* image1, int n1, const 
     return XFH_OK;
 }
 
+// n_valid-aware form: the two sets are the nfeatures slots of two extraction records whose prepared images came
+// out of xfh_extract_batch_device_images; pairs that touch a padding slot are not reported (the reference's match() would report
+// them: zero rows have similarity 0 with everything, ORBmatcher.cc:358-372).  Otherwise xfh_match_mnn_prepared_device.
+int xfh_match_records_device(xfh_ctx* c, const void* d_record1, const void* image1, const void* d_record2, const void* image2, float min_cossim,
+                             int* idx1, int* idx2, float* dist, int* n_matches) {
+    if (!c || !d_record1 || !d_record2 || !image1 || !image2 || !idx1 || !idx2 || !dist || !n_matches) return XFH_ERR_INVALID_ARG;
+    if ((((uintptr_t)image1) | ((uintptr_t)image2)) & 15) return XFH_ERR_INVALID_ARG;
+    HIPCK(c, hipSetDevice(c->cfg.device));
+    const int nf = c->cfg.nfeatures;
+    HIPCK(c, launch_mnn_prepared(c, (const float*)image1, nf, (const float*)image2, nf, min_cossim, idx1, idx2, dist, n_matches,
+                                 (const int*)d_record1, (const int*)d_record2));
+    return XFH_OK;
+}
+
 int xfh_match_mnn(xfh_ctx* c, const float* d1, int n1, const float* d2, int n2, float min_cossim,
                   int* idx1, int* idx2, float* dist, int* n_matches) {
     if (!c || n1 < 0 || n2 < 0 || !n_matches) return XFH_ERR_INVALID_ARG;
@@ -745,7 +759,7 @@ int xfh_timing_enable(xfh_ctx* c, int kernel_id, unsigned layer_mask) {
         t.ev = (hipEvent_t*)calloc(2 * KTimer::MAXEV, sizeof(hipEvent_t));
         for (int i = 0; i < 2 * KTimer::MAXEV; ++i) HIPCK(c, hipEventCreate(&t.ev[i]));
     }
-    t.kernel_id = kernel_id; t.layer_mask = layer_mask; t.nev = 0; t.launches = 0;
+    t.kernel_id = kernel_id; t.layer_mask = layer_mask; t.nev = 0; t.launches = 0; t.dropped = 0;
     return XFH_OK;
 }
 int xfh_timing_read(xfh_ctx* c, int* launches, double* total_ms) {
@@ -760,8 +774,9 @@ int xfh_timing_read(xfh_ctx* c, int* launches, double* total_ms) {
     }
     if (launches) *launches = t.nev;
     if (total_ms) *total_ms = tot;
-    t.nev = 0;
-    return XFH_OK;
+    const bool overflow = t.dropped > 0;
+    t.nev = 0; t.dropped = 0;
+    return overflow ? XFH_ERR_BATCH_TOO_LARGE : XFH_OK;       // more than 4096 matching launches since xfh_timing_enable: the sums cover the first 4096 only
 }
 
 // ------------------------------------------------------------------------- debug tensors
@@ -815,7 +830,8 @@ bool ktimer_slot(xfh_ctx* c, int kernel_id, int layer, hipEvent_t* e0, hipEvent_
     KTimer& t = c->timer;
     if (t.kernel_id == XFH_K_NONE || t.kernel_id != kernel_id) return false;
     if (t.layer_mask != 0 && layer >= 0 && !((t.layer_mask >> layer) & 1u)) return false;
-    if (t.nev >= KTimer::MAXEV || !t.ev) return false;
+    if (!t.ev) return false;
+    if (t.nev >= KTimer::MAXEV) { ++t.dropped; return false; }      // reported by xfh_timing_read: never silently
     *e0 = t.ev[2 * t.nev]; *e1 = t.ev[2 * t.nev + 1];
     ++t.nev;
     return true;

@@ -116,8 +116,9 @@ struct KTimer {
     int kernel_id = 0;
     unsigned layer_mask = 0;
     int launches = 0;
-    static const int MAXEV = 4096;
+    static const int MAXEV = 4096;   // launches recorded between xfh_timing_enable and xfh_timing_read; later ones are counted in `dropped`
     hipEvent_t* ev = nullptr;   // 2*MAXEV events, lazily created
+    int dropped = 0;
     int nev = 0;
 };
 
@@ -140,7 +141,7 @@ hipError_t launch_mnn(xfh_ctx* c, const float* d1, int n1, const float* d2, int 
 hipError_t launch_match_prepare(xfh_ctx* c, const float* d, int n, float* img);
 hipError_t bench_mnn_gemm(xfh_ctx* c, const float* img1, int n1, const float* img2, int n2, int iters, double* us_per_launch);
 hipError_t launch_mnn_prepared(xfh_ctx* c, const float* img1, int n1, const float* img2, int n2, float min_cossim,
-                               int* idx1, int* idx2, float* dist, int* n_matches);
+                               int* idx1, int* idx2, float* dist, int* n_matches, const int* hdr1 = nullptr, const int* hdr2 = nullptr);
 hipError_t launch_mnn_gemm(xfh_ctx* c, const float* img1, int n1, const float* img2, int n2, u64* partR, size_t ldr, u64* partC, size_t ldc, u64* pairs);   // kernels_mnn_gemm.hip
 hipError_t launch_dist_i32(xfh_ctx* c, const float* d1, int n1, const float* d2, int n2, int32_t* out);
 hipError_t launch_distinctive(xfh_ctx* c, const float* table, const int* offsets, const int* indices, int n_groups, int max_group,

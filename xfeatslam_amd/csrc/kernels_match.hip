@@ -279,7 +279,7 @@ hipError_t match_ws_reserve(xfh_ctx* c, int n1, int n2) {
 
 // GEMM + post on two panel images: the keys of block (by, bx) go to plane bx of partR / plane by of partC
 static hipError_t launch_gemm_post(xfh_ctx* c, const float* img1, int n1, const float* img2, int n2, float min_cossim,
-                                   int* idx1, int* idx2, float* dist, int* n_matches) {
+                                   int* idx1, int* idx2, float* dist, int* n_matches, const int* hdr1 = nullptr, const int* hdr2 = nullptr) {
     MatchWs& w = c->mws;
     hipError_t e;
     const int P1 = (n1 + MNN_PANEL - 1) / MNN_PANEL, P2 = (n2 + MNN_PANEL - 1) / MNN_PANEL;
@@ -288,7 +288,7 @@ static hipError_t launch_gemm_post(xfh_ctx* c, const float* img1, int n1, const 
     XFH_SET_LDS_ATTR_ONCE(c, k_mnn_post<0>, MNN_POST_LDS);
     const int nb = (n1 + 15) / 16, ncoll = mnn_ncoll(n1);
     hipLaunchKernelGGL(k_mnn_post<0>, dim3(nb + ncoll), dim3(256), MNN_POST_LDS, c->stream, img1, n1, img2, n2, (const u64*)w.partR, ldr, P2,
-                       (const u64*)w.partC, ldc, P1, min_cossim, w.pairs, nb, ncoll, idx1, idx2, dist, n_matches, (long long*)nullptr);
+                       (const u64*)w.partC, ldc, P1, min_cossim, w.pairs, nb, ncoll, idx1, idx2, dist, n_matches, (long long*)nullptr, hdr1, hdr2);
     return hipGetLastError();
 }
 
@@ -339,11 +339,11 @@ hipError_t launch_match_prepare(xfh_ctx* c, const float* d, int n, float* img) {
 
 // ORBmatcher::match on two prepared images: GEMM + post (two launches)
 hipError_t launch_mnn_prepared(xfh_ctx* c, const float* img1, int n1, const float* img2, int n2, float min_cossim,
-                               int* idx1, int* idx2, float* dist, int* n_matches) {
+                               int* idx1, int* idx2, float* dist, int* n_matches, const int* hdr1, const int* hdr2) {
     hipError_t e;
     if (n1 <= 0 || n2 <= 0) return hipMemsetAsync(n_matches, 0, sizeof(int), c->stream);
     if ((e = match_ws_reserve(c, n1, n2)) != hipSuccess) return e;
-    return launch_gemm_post(c, img1, n1, img2, n2, min_cossim, idx1, idx2, dist, n_matches);
+    return launch_gemm_post(c, img1, n1, img2, n2, min_cossim, idx1, idx2, dist, n_matches, hdr1, hdr2);
 }
 
 hipError_t launch_dist_i32(xfh_ctx* c, const float* d1, int n1, const float* d2, int n2, int32_t* out) {

@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256)
 void k_mnn_post(const float* __restrict__ img1, int n1, const float* __restrict__ img2, int n2,
                 const u64* __restrict__ partR, size_t ldr, int npr, const u64* __restrict__ partC, size_t ldc, int npc, float min_cossim,
                 u64* __restrict__ pairs, int nb, int ncoll, int* __restrict__ idx1, int* __restrict__ idx2, float* __restrict__ dist, int* __restrict__ n_matches,
-                long long* __restrict__ stamps) {
+                long long* __restrict__ stamps, const int* __restrict__ hdr1, const int* __restrict__ hdr2) {
     extern __shared__ __attribute__((aligned(16))) float spost[];
     const int t = threadIdx.x;
 #define MNN_STAMP(k) do { if (TS && t == 0 && (blockIdx.x == 0 || blockIdx.x + 1 == gridDim.x)) stamps[(blockIdx.x ? 16 : 0) + (k)] = wall_clock64(); } while (0)
@@ -148,6 +148,12 @@ void k_mnn_post(const float* __restrict__ img1, int n1, const float* __restrict_
         }
         MNN_STAMP(3);
         if (min_cossim > 0.f) mutual = mutual && (M > min_cossim);
+        // n_valid-aware option: the rows are the nfeatures slots of two extraction records; a pair that touches a padding
+        // slot is not reported.  Valid slots of a record: [0, mono_index) and [n - (n_valid - mono_index), n) (header: n_valid, mono_index).
+        if (hdr1) {
+            const int nv1 = hdr1[0], mo1 = hdr1[1], nv2 = hdr2[0], mo2 = hdr2[1];
+            mutual = mutual && (row < mo1 || row >= n1 - (nv1 - mo1)) && (cstar < mo2 || cstar >= n2 - (nv2 - mo2));
+        }
         if (c == 0 && row < n1) {
             const u64 pr = ((u64)(unsigned)(mutual ? cstar : -1) << 32) | (u64)__builtin_bit_cast(unsigned, M);
             __hip_atomic_store(pairs + row, pr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
