@@ -276,6 +276,7 @@ def main():
         comm.close()
     sys.stdout.flush()
     if saved_stdout is not None:
+        C.CDLL(None).fflush(None)                          # RCCL's banner sits in the C stdio buffer of fd 1: out to stderr with it
         os.dup2(saved_stdout, 1)
     print(json.dumps(out), flush=True)
 
