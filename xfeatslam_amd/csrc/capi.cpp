@@ -171,7 +171,7 @@ int xfh_destroy(xfh_ctx* c) {
     F(c->d_gray); F(c->X); F(c->pre_part); F(c->xstat);
     for (int i = 0; i < XFH_NUM_LAYERS; ++i) { F(c->raw[i]); F(c->part[i]); F(c->stat[i]); }
     if (!c->is_twin) {                                   // a twin borrows the weights of its parent
-        for (int i = 0; i < XFH_NUM_LAYERS; ++i) { F(c->w.mfma[i]); F(c->w.alt[i]); F(c->w.alt2[i]); F(c->w.bn_bias[i]); }
+        for (int i = 0; i < XFH_NUM_LAYERS; ++i) { F(c->w.mfma[i]); F(c->w.alt[i]); F(c->w.alt2[i]); F(c->w.m16[i]); F(c->w.bn_bias[i]); }
         for (int i = 0; i < 3; ++i) F(c->w.direct[i]);
         F(c->w.fus2); F(c->w.fus2_bias); F(c->w.skip_w); F(c->w.skip_b); F(c->w.heat2_w); F(c->w.heat2_b); F(c->w.kp3_w); F(c->w.kp3_b);
     }
@@ -231,12 +231,13 @@ static int upload(xfh_ctx* c, float** dst, const std::vector<float>& v) {
 // channels, channel e sits at position 4*(e&1) + (e>>1).  A chunk holds CB = min(cin, cbmax) channels of
 // tpc consecutive taps (tpc > 1 only when CB == cin): chunk = (tap / tpc) * NCB + cb, KC = tpc * CB,
 // position inside the chunk row = (tap % tpc) * CB + pos.
-static std::vector<float> pack_mfma(const float* w, int cout, int cin, int ks, int coutp, int cbmax = 64, int tpc = 1) {
+static std::vector<float> pack_mfma(const float* w, int cout, int cin, int ks, int coutp, int cbmax = 64, int tpc = 1, bool perm16 = false) {
     const int CB = cin > cbmax ? cbmax : cin, NCB = cin / CB, KC = tpc * CB;
     std::vector<float> o((size_t)ks * ks * NCB * coutp * CB, 0.f);
     for (int ky = 0; ky < ks; ++ky) for (int kx = 0; kx < ks; ++kx) for (int cb = 0; cb < NCB; ++cb)
         for (int n = 0; n < cout; ++n) for (int lc = 0; lc < CB; ++lc) {
-            const int g = lc / 8, e = lc % 8, pos = g * 8 + 4 * (e & 1) + (e >> 1);
+            // 32x32x2 kernels: k = 8g + e at 8g + 4(e & 1) + (e >> 1); 16x16x4 (k_conv_mfma16): k = 16g + e at 16g + 4(e & 3) + (e >> 2)
+            const int g = lc / 8, e = lc % 8, pos = perm16 ? (lc / 16) * 16 + 4 * (lc % 16 & 3) + (lc % 16 >> 2) : g * 8 + 4 * (e & 1) + (e >> 1);
             const int ci = cb * CB + lc, tap = ky * ks + kx;
             const size_t chunk = (size_t)(tap / tpc) * NCB + cb;
             o[(chunk * coutp + n) * KC + (tap % tpc) * CB + pos] = w[(((size_t)n * cin + ci) * ks + ky) * ks + kx];
@@ -285,6 +286,8 @@ int xfh_load_weights(xfh_ctx* c, const void* blob, size_t nbytes) {
                 rc = upload(c, &c->w.alt[i], pack_mfma(wp, L.cout, L.cin, L.ks, coutp, 32));
             if (rc == XFH_OK && L.ks == 3 && L.cin == 64 && L.cout == 64 && L.stride == 1)                 // 7, 10, 11, 16, 17: three taps per chunk
                 rc = upload(c, &c->w.alt2[i], pack_mfma(wp, L.cout, L.cin, L.ks, coutp, 64, 3));
+            if (rc == XFH_OK && L.ks == 3 && L.cin >= 64)                                                // 7, 9-14, 16, 17: single-frame form
+                rc = upload(c, &c->w.m16[i], pack_mfma(wp, L.cout, L.cin, L.ks, L.cout, 64, 1, true));
             if (rc == XFH_OK && L.ks == 3 && L.cin <= 24 && L.cout == 24)                              // 3, 4, 5: all nine taps in one chunk (persistent kernels, block1.3)
                 rc = upload(c, &c->w.alt[i], pack_mfma(wp, L.cout, L.cin, L.ks, coutp, 64, 9));
         }

@@ -827,6 +827,162 @@ void k_conv_mfma_p(ConvArgs a, int ntile, int total) {
 }
 
 // ------------------------------------------------------------------------------------
+// k_conv_mfma16: the SINGLE-FRAME form of the 3x3 stride-1 layers with >= 64 channels, on v_mfma_f32_16x16x4_f32.
+// One frame gives a layer 40-150 workgroups; with 32x32x2 tiles a wave then walks an accumulation chain of 288-576 dependent
+// MFMAs of 64 cycles each (7.7-15 us of pure chain per layer) on a mostly idle GPU.  The 16x16x4 instruction is the same exact
+// fp32 fma chain in k order (tools/probes/mfma16_probe.hip: 0 mismatches in 51 200 outputs) with a dependent latency of 20 ns per
+// four k: a wave owns 16 pixels x 16 channels, four times as many waves share the work and the chain shrinks 2.6x -- same bits.
+//   lane (p = l & 15, q = l >> 4): A = pixel p of the wave's pixel group, B = channel p of its channel group, k = k0 + q;
+//   LDS rows (pixels / weight rows) keep their channels permuted inside each group of 16 (channel 4j + q at position 4q + j), so one
+//   ds_read_b128 per operand feeds four consecutive MFMAs; D: register r = pixel 4q + r, lane column p = channel.
+// Workgroup = PGY pixel groups (GW x 16/GW pixels each, stacked vertically) x COUT/16 channel groups; staging, weight streaming
+// (one tap x 64 channels per chunk, double buffered) and statistics partials as in k_conv_mfma.
+template <int CIN, int COUT, int ST, int GW, int PGY, int PRO, int EPI>
+__global__ __launch_bounds__(64 * PGY * (COUT / 16))
+void k_conv_mfma16(ConvArgs a) {
+    static_assert(PRO == PRO_BN || PRO == PRO_FUSE, "3x3 layers behind a BatchNorm (block_fusion.0: + the pyramid sum)");
+    constexpr int GH = 16 / GW, CG = COUT / 16, NW = PGY * CG, NTHR = 64 * NW;
+    constexpr int TH = GH * PGY, TW = GW, TIH = (TH - 1) * ST + 3, TIW = (TW - 1) * ST + 3, CP = CIN + 4;
+    constexpr int CB = 64, NCB = CIN / CB, NCHUNK = 9 * NCB, KC = CB, WS = KC + 4;
+    constexpr int WCH = COUT * KC, NWLD = (WCH / 4 + NTHR - 1) / NTHR;
+    constexpr int G = CIN / 8, NITEM = TIH * TIW * G, NIT = (NITEM + NTHR - 1) / NTHR;
+    constexpr int IN_FLOATS = TIH * TIW * CP, W_FLOATS = COUT * WS;
+    static_assert(sizeof(double) * 512 <= sizeof(float) * IN_FLOATS, "bn_fold scratch in the input tile");
+    static_assert(sizeof(double) * PGY * COUT * 2 <= sizeof(float) * IN_FLOATS, "statistics scratch in the input tile");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_in = smem;
+    float* s_w = smem + IN_FLOATS;               // two buffers of W_FLOATS
+    float* s_stat = s_w + 2 * W_FLOATS;          // 2 * CIN (PRO_FUSE: 3 * 128)
+
+    const int t = threadIdx.x, b = blockIdx.z;
+    const int tile = blockIdx.x, tx0 = (tile % a.tiles_x) * TW, ty0 = (tile / a.tiles_x) * TH;
+    const float* in = a.in + (size_t)b * a.in_stride;
+
+    f32x4 wreg[NWLD];
+#pragma unroll
+    for (int q = 0; q < NWLD; ++q) {
+        const int f = t + q * NTHR;
+        if (f < WCH / 4) wreg[q] = *(const f32x4*)(a.w + (size_t)f * 4);
+    }
+    f32x4 r0[NIT], r1[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+        const int item = t + k * NTHR, pix = item / G, g = item % G;
+        const int gy = min(max(ty0 * ST - 1 + pix / TIW, 0), a.Hin - 1), gx = min(max(tx0 * ST - 1 + pix % TIW, 0), a.Win - 1);
+        const float* p = in + ((size_t)gy * a.Win + gx) * CIN + g * 8;
+        r0[k] = *(const f32x4*)p;
+        r1[k] = *(const f32x4*)(p + 4);
+    }
+    stage_stat(a.st, b, CIN, tile == 0, s_stat, (double*)s_in, t, NTHR);
+    if constexpr (PRO == PRO_FUSE) {
+        stage_stat(a.st4, b, 64, tile == 0, s_stat + 128, (double*)s_in, t, NTHR);
+        stage_stat(a.st5, b, 64, tile == 0, s_stat + 256, (double*)s_in, t, NTHR);
+    }
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+        const int item = t + k * NTHR, pix = item / G, g = item % G;
+        const int gy = ty0 * ST - 1 + pix / TIW, gx = tx0 * ST - 1 + pix % TIW;
+        const bool ok = gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win;
+        if (NITEM % NTHR != 0 && item >= NITEM) continue;
+        f32x4 v0 = r0[k], v1 = r1[k];
+        const f32x4 m0 = *(const f32x4*)(s_stat + g * 8), m1 = *(const f32x4*)(s_stat + g * 8 + 4);
+        const f32x4 q0 = *(const f32x4*)(s_stat + CIN + g * 8), q1 = *(const f32x4*)(s_stat + CIN + g * 8 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v0[e] = fmaxf((v0[e] - m0[e]) * q0[e], 0.f);
+            v1[e] = fmaxf((v1[e] - m1[e]) * q1[e], 0.f);
+        }
+        if constexpr (PRO == PRO_FUSE) {                // x3 + up2(x4) + up4(x5) with ATen's bilinear arithmetic (XFeat.cc:159-166)
+            if (ok) {
+                f32x4 u0, u1, w0, w1;
+                up_bilinear8(a.r4 + (size_t)b * a.s4, s_stat + 128, a.H4, a.W4, a.Hin, a.Win, gy, gx, g, u0, u1);
+                up_bilinear8(a.r5 + (size_t)b * a.s5, s_stat + 256, a.H5, a.W5, a.Hin, a.Win, gy, gx, g, w0, w1);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v0[e] = (v0[e] + u0[e]) + w0[e]; v1[e] = (v1[e] + u1[e]) + w1[e]; }
+            }
+        }
+        if (!ok) { v0 = f32x4{0.f, 0.f, 0.f, 0.f}; v1 = v0; }
+        // channels 8g + e and 8g + 4 + e sit next to each other in the group-of-16 permutation: position 4e + 2(g & 1) (+ 1)
+        float* d = s_in + pix * CP + (g >> 1) * 16 + 2 * (g & 1);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) *(f32x2*)(d + 4 * e) = f32x2{v0[e], v1[e]};
+    }
+#pragma unroll
+    for (int q = 0; q < NWLD; ++q) {
+        const int f = t + q * NTHR;
+        if (f < WCH / 4) { const int n = f / (KC / 4), c4 = f % (KC / 4); *(f32x4*)(s_w + n * WS + c4 * 4) = wreg[q]; }
+    }
+    __syncthreads();
+
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, p = lane & 15, q = lane >> 4;
+    const int pg = wave / CG, cg = wave % CG;
+    const int ly = pg * GH + p / GW, lx = p % GW;               // this lane's output pixel inside the tile (A operand row)
+    float biasv = 0.f;
+    if constexpr (EPI != EPI_STATS) biasv = a.bias[cg * 16 + p];
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int ch = 0; ch < NCHUNK; ++ch) {
+        if (ch + 1 < NCHUNK) {
+            const float* wsrc = a.w + (size_t)(ch + 1) * WCH;
+#pragma unroll
+            for (int u = 0; u < NWLD; ++u) {
+                const int f = t + u * NTHR;
+                if (f < WCH / 4) wreg[u] = *(const f32x4*)(wsrc + (size_t)f * 4);
+            }
+        }
+        {
+            const int tap = ch / NCB, cb = ch % NCB, ky = tap / 3, kx = tap % 3;
+            const float* pa = s_in + ((ly * ST + ky) * TIW + lx * ST + kx) * CP + cb * CB + 4 * q;
+            const float* pw = s_w + (ch & 1) * W_FLOATS + (cg * 16 + p) * WS + 4 * q;
+#pragma unroll
+            for (int kb = 0; kb < CB / 16; ++kb) {
+                const f32x4 av = *(const f32x4*)(pa + kb * 16), bv = *(const f32x4*)(pw + kb * 16);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[j], acc, 0, 0, 0);
+            }
+        }
+        if (ch + 1 < NCHUNK) {
+            float* wd = s_w + ((ch + 1) & 1) * W_FLOATS;
+#pragma unroll
+            for (int u = 0; u < NWLD; ++u) {
+                const int f = t + u * NTHR;
+                if (f < WCH / 4) { const int n = f / (KC / 4), c4 = f % (KC / 4); *(f32x4*)(wd + n * WS + c4 * 4) = wreg[u]; }
+            }
+        }
+        __syncthreads();
+    }
+    XFH_MFMA_SETTLE();
+    // ---- epilogue: register r = pixel 4q + r of the group, lane column p = channel cg*16 + p
+    double sum = 0.0, sq = 0.0;
+    float* out = a.out + (size_t)b * a.out_stride + cg * 16 + p;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int pi = 4 * q + r, oy = ty0 + pg * GH + pi / GW, ox = tx0 + pi % GW;
+        if (oy < a.Hout && ox < a.Wout) {
+            float v = acc[r];
+            if constexpr (EPI != EPI_STATS) v += biasv;
+            if constexpr (EPI == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
+            out[((size_t)oy * a.Wout + ox) * COUT] = v;
+            if constexpr (EPI == EPI_STATS) { const double dv = (double)v; sum += dv; sq = fma(dv, dv, sq); }
+        }
+    }
+    if constexpr (EPI == EPI_STATS) {
+        sum += __shfl_xor(sum, 16); sq += __shfl_xor(sq, 16);
+        sum += __shfl_xor(sum, 32); sq += __shfl_xor(sq, 32);
+        double* s_red = (double*)smem;                 // the tiles are no longer needed (all waves passed the last barrier)
+        if (q == 0) { s_red[(pg * COUT + cg * 16 + p) * 2] = sum; s_red[(pg * COUT + cg * 16 + p) * 2 + 1] = sq; }
+        __syncthreads();
+        for (int co = t; co < COUT; co += NTHR) {
+            double S = 0.0, SS = 0.0;
+#pragma unroll
+            for (int m = 0; m < PGY; ++m) { S += s_red[(m * COUT + co) * 2]; SS += s_red[(m * COUT + co) * 2 + 1]; }
+            double* pp = a.part + (size_t)b * a.part_stride + ((size_t)tile * COUT + co) * 2;
+            pp[0] = S; pp[1] = SS;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // k_chain1x1: consecutive 1x1 convolutions 64 -> 64 at 1/8 resolution in ONE pass over the pixels, wherever nothing but a bias
 // (and a ReLU) separates them.  In use: block_fusion.2 -> heatmap_head.0 (fusion.2 is a bare Conv2d, XFeat.cc:75) for B > 8 in
 // every BatchNorm mode; the template also covers three stages and bias+ReLU hand-overs (the folded-BatchNorm head chains), which
@@ -1034,6 +1190,21 @@ static hipError_t conv_mfma_launch(xfh_ctx* c, const ConvArgs& a, int B, int* np
     return hipGetLastError();
 }
 
+template <int CIN, int COUT, int ST, int GW, int PGY, int PRO, int EPI>
+static hipError_t conv_mfma16_launch(xfh_ctx* c, const ConvArgs& a, int B, int* npart_out, int layer) {
+    constexpr int GH = 16 / GW, TH = GH * PGY, TW = GW, NW = PGY * (COUT / 16);
+    constexpr size_t LDS = sizeof(float) * ((size_t)((TH - 1) * ST + 3) * ((TW - 1) * ST + 3) * (CIN + 4) + 2 * (size_t)COUT * 68 + (PRO == PRO_FUSE ? 384 : 2 * CIN));
+    static_assert(LDS <= 160 * 1024, "LDS budget");
+    ConvArgs aa = a;
+    aa.tiles_x = (a.Wout + TW - 1) / TW;
+    const int ntile = aa.tiles_x * ((a.Hout + TH - 1) / TH);
+    if (npart_out) *npart_out = ntile;
+    auto kern = k_conv_mfma16<CIN, COUT, ST, GW, PGY, PRO, EPI>;
+    XFH_SET_LDS_ATTR_ONCE(c, kern, LDS);
+    launch_k(c, XFH_K_CONV_MFMA, layer, kern, dim3(ntile, 1, B), dim3(64 * NW), LDS, aa);
+    return hipGetLastError();
+}
+
 template <int CIN, int COUT, int KS, int ST, int WM, int WN, int NT, int WW, int PRO, int EPI>
 static hipError_t conv_mfma_p_launch(xfh_ctx* c, const ConvArgs& a, int B, int* npart_out, int layer) {
     constexpr int WH = 32 / WW, TH = WM * WH, TW = WW;
@@ -1085,8 +1256,9 @@ int conv_layer_npart(int li, int Hout, int Wout) {
     if (li < 3) return cdiv(Wout, 16) * cdiv(Hout, 16);
     switch (li) {
         case 7: case 16: case 17: return cdiv(Wout, 16) * cdiv(Hout, 2);     // 8x16 pixels; 2x16 in the small-batch configuration (the larger count sizes the buffers)
-        case 9: case 10: case 11: return cdiv(Wout, 8) * cdiv(Hout, 8);      // WM=2, WW=8 (10, 11 at B > 1: 16-row tiles, fewer partials)
-        case 12: case 13: case 14: case 15: return cdiv(Wout, 8) * cdiv(Hout, 4);   // WM=1, WW=8
+        case 9: case 10: case 11: return cdiv(Wout, 8) * cdiv(Hout, 4);              // single frame: 4x8-pixel tiles (k_conv_mfma16); batches: 16x8
+        case 12: case 13: case 14: return cdiv(Wout, 4) * cdiv(Hout, 4);     // single frame: 4x4-pixel tiles; batches: 16x8 / 4x8
+        case 15: return cdiv(Wout, 8) * cdiv(Hout, 4);                       // WM=1, WW=8
         default: return cdiv(Wout, 16) * cdiv(Hout, 8);                       // WM=4, WW=16
     }
 }
@@ -1165,9 +1337,8 @@ static hipError_t launch_basic_layer_t(xfh_ctx* c, int li, const float* in, size
             // B = 16 (profiles/r01_conv_cfg.log).  Single frame: 2x16 pixels per workgroup, 2 waves, three taps per chunk.
             // block_fusion.0 (16) builds its input x3 + up2(x4) + up4(x5) while staging.
             if (small_batch(B)) {
-                a.w = c->w.alt2[li];
-                if (li == 16) e = conv_mfma_launch<64, 64, 3, 1, 1, 2, 1, 16, PRO_FUSE, EPI, 64, 3>(c, a, B, &np, li);
-                else e = conv_mfma_launch<64, 64, 3, 1, 1, 2, 1, 16, PRO_BN, EPI, 64, 3>(c, a, B, &np, li);
+                if (li == 16) { a.w = c->w.m16[li]; e = conv_mfma16_launch<64, 64, 1, 16, 2, PRO_FUSE, EPI>(c, a, B, &np, li); }
+                else { a.w = c->w.m16[li]; e = conv_mfma16_launch<64, 64, 1, 16, 2, PRO_BN, EPI>(c, a, B, &np, li); }      // 2x16 pixels, 8 waves of 16 x 16
             } else {
                 a.w = c->w.alt[li];
                 if (li == 16) e = conv_mfma_launch<64, 64, 3, 1, 4, 2, 1, 16, PRO_FUSE, EPI, 32>(c, a, B, &np, li);
@@ -1182,16 +1353,19 @@ static hipError_t launch_basic_layer_t(xfh_ctx* c, int li, const float* in, size
             // stride 2 (4.5 input pixels per output pixel): 113 KB of LDS = one workgroup per CU.  Measured alternative: 4x8 pixels with
             // 32-channel chunks (60 KB, two workgroups per CU) 403 -> 558 us at B = 256 -- a workgroup streams the whole 147 KB weight
             // matrix from L2 for its tile, so halving the tile doubles that traffic; the small maps are bound by it
-            e = conv_mfma_launch<64, 64, 3, 2, 2, 2, 1, 8, PRO_BN, EPI>(c, a, B, &np, li);
+            if (small_batch(B)) { a.w = c->w.m16[li]; e = conv_mfma16_launch<64, 64, 2, 8, 2, PRO_BN, EPI>(c, a, B, &np, li); }     // single frame: 4x8 pixels, 8 waves of 16 x 16
+            else e = conv_mfma_launch<64, 64, 3, 2, 2, 2, 1, 8, PRO_BN, EPI>(c, a, B, &np, li);
             break;
         case 10: case 11:
-            if (small_batch(B)) { a.w = c->w.alt2[li]; e = conv_mfma_launch<64, 64, 3, 1, 2, 2, 1, 8, PRO_BN, EPI, 64, 3>(c, a, B, &np, li); }   // three taps per chunk
+            if (small_batch(B)) { a.w = c->w.m16[li]; e = conv_mfma16_launch<64, 64, 1, 8, 2, PRO_BN, EPI>(c, a, B, &np, li); }                    // 4x8 pixels, 8 waves of 16 x 16
             else { a.w = c->w.alt[li]; e = conv_mfma_launch<64, 64, 3, 1, 4, 2, 1, 8, PRO_BN, EPI, 32>(c, a, B, &np, li); }   // 16x8 pixels, 8 waves, 32-channel chunks (67 KB): half the weight streaming per pixel of the 8x8 form
             break;
-        case 12: a.w = c->w.alt[li]; e = conv_mfma_launch<64, 128, 3, 2, 1, 4, 1, 8, PRO_BN, EPI, 32>(c, a, B, &np, li); break;      // 32-channel chunks: 111 -> 78 KB of LDS, two workgroups per CU (212 -> 168 us at B = 256)
+        case 12:
+            if (small_batch(B)) { a.w = c->w.m16[li]; e = conv_mfma16_launch<64, 128, 2, 4, 1, PRO_BN, EPI>(c, a, B, &np, li); break; }     // single frame: 4x4 pixels, 8 waves of 16 x 16
+            a.w = c->w.alt[li]; e = conv_mfma_launch<64, 128, 3, 2, 1, 4, 1, 8, PRO_BN, EPI, 32>(c, a, B, &np, li); break;      // 32-channel chunks: 111 -> 78 KB of LDS, two workgroups per CU (212 -> 168 us at B = 256)
         case 13: case 14:       // 32-channel weight chunks: 69 KB LDS -> 2 workgroups per CU, 58 -> 50 us at B = 32
             if (!small_batch(B)) { a.w = c->w.alt[li]; e = conv_mfma_launch<128, 128, 3, 1, 4, 4, 1, 8, PRO_BN, EPI, 32>(c, a, B, &np, li); }   // 16x8 pixels x 128 channels, 16 waves (132 KB): the 590 KB weight matrix is streamed once per 128 pixels
-            else e = conv_mfma_launch<128, 128, 3, 1, 1, 4, 1, 8, PRO_BN, EPI>(c, a, B, &np, li);
+            else { a.w = c->w.m16[li]; e = conv_mfma16_launch<128, 128, 1, 4, 1, PRO_BN, EPI>(c, a, B, &np, li); }                                   // 4x4 pixels, 8 waves of 16 x 16
             break;
         case 15: e = conv_mfma_launch<128, 64, 1, 1, 1, 2, 1, 8, PRO_BN, EPI>(c, a, B, &np, li); break;
         case 18: case 20:                                                                                      // inputs: feats / unfold(xhat)
