@@ -138,19 +138,24 @@ def test_stage_tensors_match_oracle(gpu_lib, oracle_mod, weights_std):
     _, blob = weights_std
     img = synth.image(160, 224, 9)
     orc = oracle_mod.Oracle(blob); orc.extract(img, 512, (0, 0))
-    ctx = _ctx(512, 160, 224, B=12); ctx.load_weights(blob)
+    ctx = _ctx(512, 160, 224, B=40); ctx.load_weights(blob)
     T, OT = capi.T, oracle_mod.T
-    # B = 12: statistics finalised by k_bn_finalize, persistent short-K kernels; then B = 1 (everything folded by the consumers)
-    ctx.extract_batch(np.stack([img] * 12))
     # block1.0's map is never written (block1.1 recomputes what it consumes, k_block1_stats makes the statistics pass): its
     # statistics and the map of block1.1 cover it
     raw = lambda i, fr=0: ctx.debug_tensor(T["RAW0"] + i, fr) if i else np.zeros(0, np.float32)
     with pytest.raises(Exception):
         ctx.debug_tensor(T["RAW0"])
-    big = {i: (raw(i, 11), ctx.debug_tensor(T["STAT0"] + i, 11)) for i in range(23)}
+    # three regimes must agree bit for bit: B = 40 (statistics finalised by k_bn_finalize, persistent short-K kernels, 32x32x2 tiles
+    # for every layer), B = 12 (the same, but k_conv_mfma16 = 16x16x4 tiles for the 3x3 layers with >= 64 input channels) and
+    # B = 1 (k_conv_mfma16, everything folded by the consumers)
+    snaps = []
+    for nb in (40, 12):
+        ctx.extract_batch(np.stack([img] * nb))
+        snaps.append({i: (raw(i, nb - 1), ctx.debug_tensor(T["STAT0"] + i, nb - 1)) for i in range(23)})
     ctx.extract_batch(img[None])
-    for i in range(23):
-        assert np.array_equal(big[i][0], raw(i)) and np.array_equal(big[i][1], ctx.debug_tensor(T["STAT0"] + i)), f"regimes differ at layer {i}"
+    for big in snaps:
+        for i in range(23):
+            assert np.array_equal(big[i][0], raw(i)) and np.array_equal(big[i][1], ctx.debug_tensor(T["STAT0"] + i)), f"regimes differ at layer {i}"
     # x1 + skip1(x), the fusion input and the normalised features are never materialised on the GPU (they are computed while the
     # consuming kernels stage their inputs); raw maps 4 (block2.0) and 16 (block_fusion.0) and the descriptors cover them
     for nm in ["X", "XSTAT", "SKIP_POOL", "XUNFOLD", "FEATS"]:
@@ -167,12 +172,13 @@ def test_stage_tensors_match_oracle(gpu_lib, oracle_mod, weights_std):
     ctx.close()
 
 
-@pytest.mark.parametrize("nb", [5, 12])
+@pytest.mark.parametrize("nb", [5, 12, 40])
 def test_batch_is_per_frame(gpu_lib, oracle_mod, weights_dense, nb):
     """frames in one batch are normalised with their OWN statistics (the reference is always B=1):
-    a batched call equals single-frame calls bit for bit, and is deterministic run to run.  The three
-    batch regimes use different kernels / tilings (B = 1: single-frame tiles; B <= 8: statistics folded
-    by the consuming convolution; B > 8: k_bn_finalize) and must agree bit for bit."""
+    a batched call equals single-frame calls bit for bit, and is deterministic run to run.  The batch regimes use
+    different kernels / tilings (B <= 8: statistics folded by the consuming convolution; B > 8: k_bn_finalize and
+    persistent short-K kernels; B <= 32: 16x16x4 MFMA tiles for the wide 3x3 layers, above: 32x32x2) and must agree bit
+    for bit."""
     _, blob = weights_dense
     fr = synth.frames(nb, 96, 160, seed=11)
     fr[3] = 200                                              # a constant frame in the middle of the batch
@@ -183,8 +189,9 @@ def test_batch_is_per_frame(gpu_lib, oracle_mod, weights_dense, nb):
         single, = ctx.extract_batch(fr[b:b + 1], (0, 50))
         for x, y, z in zip(batch[b], single, again[b]):
             assert np.array_equal(x, y) and np.array_equal(x, z)
-        ok, od, onv, omono = oracle_mod.Oracle(blob).extract(fr[b], 200, (0, 50))
-        assert (batch[b][2], batch[b][3]) == (onv, omono) and kp_set(batch[b][0]) == kp_set(ok)
+        if b < 6:
+            ok, od, onv, omono = oracle_mod.Oracle(blob).extract(fr[b], 200, (0, 50))
+            assert (batch[b][2], batch[b][3]) == (onv, omono) and kp_set(batch[b][0]) == kp_set(ok)
     assert batch[3][2] == 0 and np.all(batch[3][1] == 0)     # constant frame: no keypoints, all padding
     ctx.close()
 

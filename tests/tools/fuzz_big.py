@@ -10,7 +10,7 @@ for gain in (1.0, 4.0):
     blob = WT.pack_blob(WT.make_synthetic(1234, gain)); orc = O.Oracle(blob)
     for trial in range(14):
         H, W = int(rng.randint(32, 500)), int(rng.randint(32, 700))
-        nf = int(rng.choice([1, 64, 300, 1000, 4096, 5000])); B = int(rng.choice([1, 2, 8, 9, 16]))
+        nf = int(rng.choice([1, 64, 300, 1000, 4096, 5000])); B = int(rng.choice([1, 2, 8, 9, 16, 40]))
         x0 = int(rng.randint(0, W)); lap = (x0, int(x0 + rng.randint(0, W)))
         fr = synth.frames(B, H, W, seed=1000 + trial)
         if trial % 5 == 0: fr[0] = 0
