@@ -132,13 +132,6 @@ void k_norm_aux(const float* __restrict__ X, size_t x_stride, StatSrc xs, int H,
 }
 
 // relu(bn(raw)) of 4 channels (group g) at one pixel; st: mean[C], rstd[C]
-__device__ __forceinline__ f32x4 ld_act4(const float* raw, const float* st, int C, size_t pix, int g) {
-    f32x4 v = *(const f32x4*)(raw + pix * C + g * 4);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = fmaxf((v[j] - st[g * 4 + j]) * st[C + g * 4 + j], 0.f);
-    return v;
-}
-
 // ---- k_heads_heat / k_heads_kp: 128 pixels per workgroup, one pixel per lane -----------------------------
 #define HF_PX 128
 #define HF_LD 129
@@ -152,13 +145,24 @@ void k_heads_heat(const float* __restrict__ rawH, StatSrc sH,     // heatmap_hea
     const int t = threadIdx.x, b = blockIdx.z;
     const int p0 = blockIdx.x * HF_PX;
     const int pix = p0 + t;
-    stage_stat(sH, b, 64, blockIdx.x == 0, st, (double*)sA, t, HF_PX);
-    for (int item = t; item < HF_PX * 16; item += HF_PX) {
-        const int lp = item >> 4, g = item & 15;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (p0 + lp < npix) v = ld_act4(rawH + (size_t)b * raw_stride, st, 64, (size_t)(p0 + lp), g);
+    // the workgroup's 128 x 64 raw values: all sixteen loads of a thread are issued up front (clamped addresses, no branch around
+    // them -- behind a branch they ran as sixteen dependent round trips: 36 us of this kernel's single-frame time), the statistics
+    // are staged while they fly
+    f32x4 rv[16];
+    {
+        const float* rp = rawH + (size_t)b * raw_stride;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) sA[(g * 4 + j) * HF_LD + lp] = v[j];
+        for (int k = 0; k < 16; ++k) {
+            const int item = t + k * HF_PX, lp = item >> 4, g = item & 15;
+            rv[k] = *(const f32x4*)(rp + (size_t)min(p0 + lp, npix - 1) * 64 + g * 4);
+        }
+    }
+    stage_stat(sH, b, 64, blockIdx.x == 0, st, (double*)sA, t, HF_PX);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int item = t + k * HF_PX, lp = item >> 4, g = item & 15;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sA[(g * 4 + j) * HF_LD + lp] = fmaxf((rv[k][j] - st[g * 4 + j]) * st[64 + g * 4 + j], 0.f);
     }
     __syncthreads();
     float acc = 0.f;
@@ -179,13 +183,24 @@ void k_heads_kp(const float* __restrict__ rawK, StatSrc sK,      // keypoint_hea
     const int t = threadIdx.x, b = blockIdx.z;
     const int npix = Hh * Wh, p0 = blockIdx.x * HF_PX;
     const int pix = p0 + t;
-    stage_stat(sK, b, 64, blockIdx.x == 0, st, (double*)sA, t, HF_PX);
-    for (int item = t; item < HF_PX * 16; item += HF_PX) {
-        const int lp = item >> 4, g = item & 15;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (p0 + lp < npix) v = ld_act4(rawK + (size_t)b * raw_stride, st, 64, (size_t)(p0 + lp), g);
+    // the workgroup's 128 x 64 raw values: all sixteen loads of a thread are issued up front (clamped addresses, no branch around
+    // them -- behind a branch they ran as sixteen dependent round trips: 36 us of this kernel's single-frame time), the statistics
+    // are staged while they fly
+    f32x4 rv[16];
+    {
+        const float* rp = rawK + (size_t)b * raw_stride;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) sA[(g * 4 + j) * HF_LD + lp] = v[j];
+        for (int k = 0; k < 16; ++k) {
+            const int item = t + k * HF_PX, lp = item >> 4, g = item & 15;
+            rv[k] = *(const f32x4*)(rp + (size_t)min(p0 + lp, npix - 1) * 64 + g * 4);
+        }
+    }
+    stage_stat(sK, b, 64, blockIdx.x == 0, st, (double*)sA, t, HF_PX);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int item = t + k * HF_PX, lp = item >> 4, g = item & 15;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sA[(g * 4 + j) * HF_LD + lp] = fmaxf((rv[k][j] - st[g * 4 + j]) * st[64 + g * 4 + j], 0.f);
     }
     __syncthreads();
     float acc[65];
