@@ -264,7 +264,7 @@ def main():
     out["step_roofline"] = {"what": "all convolutions of the network (algorithmic flops per frame) x frames/s per GPU of the timed region, against the f32 MFMA peak: "
                                     "the whole step, every non-convolution kernel and every gap included",
                             "flops_per_frame": net_flops(H, W), "achieved": step_tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": step_tf / PEAK_F32_MFMA_TFLOPS}
-    kname = "k_conv_mfma<64,64,3,...> (block3.1, block_fusion.1: 3x3 64->64 at 1/8 res)" + ("" if args.bn != "folded" else ", bias+ReLU epilogue")
+    kname = ("k_conv_mfma<64,64,3,...>" if B > 32 else "k_conv_mfma16<64,64,1,16,2,...> (16x16x4 tiles, the form for batches <= 32)") + " (block3.1, block_fusion.1: 3x3 64->64 at 1/8 res)" + ("" if args.bn != "folded" else ", bias+ReLU epilogue")
     out["roofline"] = {"kernel": kname,
                        "measured": "HIP events attached to every dispatch of the kernel inside the timed region (all ctx)" + ("; the launches share the CUs with the other sub-batches' kernels" if S > 1 else ""),
                        "bound": "mfma", "achieved": conv_tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": conv_tf / PEAK_F32_MFMA_TFLOPS,
