@@ -11,7 +11,7 @@ script imports no torch: device memory, streams and the RCCL exchange all go thr
 A "step" is one pass of the extraction hot path (XFextractor::operator(), reference src/XFextractor.cc:250-356) over
 one batch of B distinct synthetic VGA frames per GPU, with the frames already resident in HBM and the 4096-row
 (keypoints, descriptors) records left in HBM; with N > 1 the step also moves the records with RCCL (frame i -> GPU
-i mod N; xfh_gather_records_root by default -- only rank 0 consumes them --, --gather allgather|compact for the other forms) on the ctx's
+i mod N; xfh_allgather_records by default, --gather root|compact for the cheaper forms) on the ctx's
 communication stream, overlapped with the next step.  `value` = frames/s over all GPUs.  Rank 0 then reports, in the
 same JSON line:
   roofline      dominant extraction kernel (3x3 64->64 at 1/8 resolution): algorithmic flops / average launch duration,
@@ -102,9 +102,10 @@ def main():
     ap.add_argument("--streams", type=int, default=4, help="sub-batches in flight per GPU (one ctx with its own HIP streams each)")
     ap.add_argument("--match-iters", type=int, default=300)
     ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the bounded all-core CPU-baseline sample (0 = skip)")
-    ap.add_argument("--gather", choices=["allgather", "root", "compact"], default="root",
-                    help="how the records reach the SLAM rank with N > 1: root = send/recv group into rank 0 only (default: rank 0 is the only consumer; an "
-                         "all-gather lands N x 298 MB per step in EVERY GPU), allgather = ncclAllGather, compact = header + valid rows to rank 0")
+    ap.add_argument("--gather", choices=["allgather", "root", "compact"], default="allgather",
+                    help="how the records reach the SLAM rank with N > 1: allgather = ncclAllGather (default: the collective BASELINE.json / SURVEY.md 8e name), "
+                         "root = send/recv group into rank 0 only (rank 0 is the only consumer; an all-gather lands N x 298 MB per step in EVERY GPU), "
+                         "compact = header + valid rows to rank 0")
     ap.add_argument("--force-comm", action="store_true", help="run the RCCL exchange also with one rank")
     ap.add_argument("--no-legs", action="store_true", help="timed region only (no host_api / match / aux / cpu legs)")
     ap.add_argument("--only-match-leg", action="store_true", help="of the extra legs run the matcher ones only (short traces for the PMC passes)")
