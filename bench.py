@@ -265,6 +265,14 @@ def main():
     out["step_roofline"] = {"what": "all convolutions of the network (algorithmic flops per frame) x frames/s per GPU of the timed region, against the f32 MFMA peak: "
                                     "the whole step, every non-convolution kernel and every gap included",
                             "flops_per_frame": net_flops(H, W), "achieved": step_tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": step_tf / PEAK_F32_MFMA_TFLOPS}
+    # the other roofline of SURVEY.md 8d, for completeness: bytes against the 8 TB/s of HBM.  Compulsory traffic (frame in, record out)
+    # is 1.47 MB per frame; the PMC counters (profiles/pmc_traffic.json, separate --pmc passes) see every inter-layer map as well.
+    comp = H * W + 4096 * (28 + 256)
+    meas = traffic.get("extract_hbm_bytes_per_frame") if traffic else None
+    out["step_roofline"]["hbm"] = {"peak_GBps": 8000.0, "compulsory_bytes_per_frame": comp, "compulsory_frac": comp * frames_per_s / N / 8e12,
+                                   "measured_bytes_per_frame": meas, "measured_GBps": (meas * frames_per_s / N / 1e9) if meas else None,
+                                   "measured_frac": (meas * frames_per_s / N / 8e12) if meas else None,
+                                   "note": "the step is bound by the vector / matrix pipe (frac above), not by HBM"}
     kname = ("k_conv_mfma<64,64,3,...>" if B > 32 else "k_conv_mfma16<64,64,1,16,2,...> (16x16x4 tiles, the form for batches <= 32)") + " (block3.1, block_fusion.1: 3x3 64->64 at 1/8 res)" + ("" if args.bn != "folded" else ", bias+ReLU epilogue")
     out["roofline"] = {"kernel": kname,
                        "measured": "HIP events attached to every dispatch of the kernel inside the timed region (all ctx)" + ("; the launches share the CUs with the other sub-batches' kernels" if S > 1 else ""),

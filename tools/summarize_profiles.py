@@ -53,7 +53,24 @@ if fetch or write:
         B = cfg["frames_per_gpu_per_step"] // cfg["sub_batches_in_flight"]
     except Exception:
         pass
-    js = {"method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch "
+    # whole-step HBM traffic of the extraction: every kernel of the run except the matcher's, over the frames the run processed
+    # (k_preproc launches 300 workgroups of 256 threads per VGA frame)
+    def grid_frames(d):
+        f = glob.glob(os.path.join(G, d, "*counter_collection.csv"))
+        n = 0
+        if f:
+            seen = set()
+            for r in csv.DictReader(open(f[0])):
+                if "k_preproc" in r["Kernel_Name"] and r["Dispatch_Id"] not in seen:
+                    seen.add(r["Dispatch_Id"]); n += int(r["Grid_Size"]) // 76800
+        return n
+    MATCH = ("k_mnn", "k_rownorm", "k_dist", "k_best2", "k_distinctive", "copyBuffer")
+    ff, fw = grid_frames("pmc_fetch"), grid_frames("pmc_write")
+    tot_f = sum(sum(v) for k, v in fetch.items() if not any(m in k for m in MATCH))
+    tot_w = sum(sum(v) for k, v in write.items() if not any(m in k for m in MATCH))
+    per_frame = (2.0 * tot_f / ff + tot_w / fw) * 1024.0 if ff and fw else None
+    js = {"extract_hbm_bytes_per_frame": per_frame, "extract_frames_counted": [ff, fw],
+          "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch "
                     "(gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md §HBM; WRITE_SIZE uncalibrated)",
           "conv_batch": B, "conv_bytes_per_launch": pick("k_conv_mfma<64, 64, 3, 1, 4, 2, 1, 16, 1, 0, 32"),
           "gemm_bytes_per_launch": pick("k_mnn_gemm"), "per_kernel": per}
