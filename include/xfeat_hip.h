@@ -291,7 +291,7 @@ const char* xfh_kernel_name(int kernel_id);
 /* intermediate tensors of frame `frame` of the last extract call, copied to host as float
  * (ids match oracle/xfeat_oracle.h; image-like tensors are NHWC).  count_out = floats. */
 enum {
-    XFH_T_X = 0, XFH_T_XSTAT = 1, XFH_T_SKIP_POOL = 2, XFH_T_XUNFOLD = 3,           /* 4, 5, 7 (x1 + skip, fusion input, normalised features) */
+    XFH_T_X = 0, XFH_T_XSTAT = 1, XFH_T_SKIP_POOL = 2,                               /* 3, 4, 5, 7 (unfold2d(x), x1 + skip, fusion input, normalised features) */
     XFH_T_FEATS = 6, XFH_T_H1 = 8, XFH_T_K1H = 9,                                   /* are never materialised on the GPU: fused into consumers */
     XFH_T_RAW0 = 16, XFH_T_STAT0 = 48, XFH_T_SEL = 80                               /* RAW0 + 0 (block1.0) likewise: recomputed inside block1.1 */
 };

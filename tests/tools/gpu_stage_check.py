@@ -119,7 +119,7 @@ def extract_checks(H, W, gain, nf=4096, lap=(0, 0), seed=42):
     recs = ctx.extract_batch(np.stack([img, img[::-1].copy()]), lap)
     hk, hd, hnv, hmono, hnc = recs[0]
     P(f"  {H}x{W} gain={gain} lap={lap}: oracle n_valid={onv} mono={omono} cand={len(orc.tensor(O.T['CAND'])) // 3} | hip n_valid={hnv} mono={hmono} cand={hnc}")
-    for nm in ["X", "XSTAT", "SKIP_POOL", "XUNFOLD"]:
+    for nm in ["X", "XSTAT", "SKIP_POOL"]:
         cmp(nm, ctx.debug_tensor(capi.T[nm]), orc.tensor(O.T[nm]))
     for i in range(23):
         if i:                                                            # block1.0 is never materialised on the GPU

@@ -26,7 +26,7 @@ ERR_EMPTY_IMAGE = 2
 ERR_NO_DEVICE = 7
 
 K = dict(NONE=0, MNN_GEMM=1, CONV_MFMA=2, CONV_DIRECT=3, NMS=4, SELECT=5, DESC=6, HEADS=7, DIST_I32=8, PREPROC=9, BEST2=10, DISTINCTIVE=11)
-T = dict(X=0, XSTAT=1, SKIP_POOL=2, XUNFOLD=3, FEATS=6, H1=8, K1H=9, RAW0=16, STAT0=48, SEL=80)
+T = dict(X=0, XSTAT=1, SKIP_POOL=2, FEATS=6, H1=8, K1H=9, RAW0=16, STAT0=48, SEL=80)
 
 
 class Config(C.Structure):

@@ -117,7 +117,6 @@ int xfh_create(const xfh_config* cfg, xfh_ctx** out) {
         A(c->stat[i], sizeof(float) * B * 2 * C);
     }
     A(c->skip_pool, sizeof(float) * B * (xs / 16));
-    A(c->xunfold, sizeof(float) * B * xs);
     A(c->feats, sizeof(float) * B * c->raw_stride[17]);
     A(c->feat_nrm, sizeof(float) * B * (xs / 64));
     A(c->H1, sizeof(float) * B * (xs / 64));
@@ -175,7 +174,7 @@ int xfh_destroy(xfh_ctx* c) {
         for (int i = 0; i < 3; ++i) F(c->w.direct[i]);
         F(c->w.fus2); F(c->w.fus2_bias); F(c->w.skip_w); F(c->w.skip_b); F(c->w.heat2_w); F(c->w.heat2_b); F(c->w.kp3_w); F(c->w.kp3_b);
     }
-    F(c->skip_pool); F(c->xunfold); F(c->feats); F(c->feat_nrm); F(c->H1); F(c->K1h);
+    F(c->skip_pool); F(c->feats); F(c->feat_nrm); F(c->H1); F(c->K1h);
     F(c->cand); F(c->cand_count); F(c->slot_src); F(c->sel_key); F(c->sel_n); F(c->d_records);
     if (c->h_records) hipHostFree(c->h_records);
     if (c->h_gray) hipHostFree(c->h_gray);
@@ -793,7 +792,6 @@ int xfh_debug_tensor(xfh_ctx* c, int id, int frame, float* out, size_t cap, size
         case XFH_T_X: src = c->X + frame * xs; n = (size_t)H * W; break;
         case XFH_T_XSTAT: src = c->xstat + frame * 2; n = 2; break;
         case XFH_T_SKIP_POOL: src = c->skip_pool + frame * (xs / 16); n = (size_t)h4 * w4; break;
-        case XFH_T_XUNFOLD: src = c->xunfold + frame * xs; n = (size_t)h8 * w8 * 64; break;
         case XFH_T_FEATS: src = c->feats + frame * c->raw_stride[17]; n = (size_t)h8 * w8 * 64; break;
         case XFH_T_H1: src = c->H1 + frame * (xs / 64); n = (size_t)h8 * w8; break;
         case XFH_T_K1H: src = c->K1h + frame * xs; n = (size_t)H * W; break;

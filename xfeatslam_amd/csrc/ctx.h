@@ -50,7 +50,7 @@ struct xfh_ctx {
     float* stat[XFH_NUM_LAYERS] = {};           // [B][2*C]
     size_t raw_stride[XFH_NUM_LAYERS] = {};     // floats per frame (at max size)
     size_t part_stride[XFH_NUM_LAYERS] = {};    // doubles per frame
-    float* skip_pool = nullptr; float* xunfold = nullptr; float* feats = nullptr;
+    float* skip_pool = nullptr; float* feats = nullptr;
     float* H1 = nullptr; float* K1h = nullptr;
     float* feat_nrm = nullptr;                  // [h8*w8] L2 norm of every feature pixel (k_feat_norm)
     u64* cand = nullptr; size_t cand_cap = 0;   // keys per frame (power of two >= Hmax*Wmax)

@@ -47,7 +47,9 @@ struct ConvArgs {
 
 // PRO_PLAIN: input used as is; PRO_BN: relu((x - mean) * rstd) of the producer; PRO_IN: InstanceNorm of the image;
 // PRO_B2IN / PRO_FUSE: the two element-wise glue steps of the backbone computed while staging (no intermediate tensor)
-enum { PRO_PLAIN = 0, PRO_BN = 1, PRO_IN = 2, PRO_B2IN = 3, PRO_FUSE = 4, PRO_L0 = 5 };
+// PRO_UNFOLD (keypoint_head.0): the input is unfold2d(x-hat, 8) (XFeat.cc:124-133) read straight from the image: channel 8*dy + dx of
+// cell (cy, cx) is pixel (8*cy + dy, 8*cx + dx), InstanceNorm applied while staging; `in` = image X, a.xstat = its statistics
+enum { PRO_PLAIN = 0, PRO_BN = 1, PRO_IN = 2, PRO_B2IN = 3, PRO_FUSE = 4, PRO_L0 = 5, PRO_UNFOLD = 6 };
 // EPI_STATS: raw map + fp64 statistic partials (BasicLayer in batch-statistics mode); EPI_BIAS: + bias, no statistics
 // (block_fusion.2); EPI_BIAS_RELU: relu(. + bias) -- a BasicLayer whose BatchNorm was folded into weights and bias at load
 // (XFH_BN_RUNNING_FOLDED): the stored map is already activated and its consumers see identity statistics
@@ -462,7 +464,7 @@ void k_conv_mfma(ConvArgs a) {
         for (int k = 0; k < NIT; ++k) {
             const int item = t + k * NTHR, pix = item / G, g = item % G;
             const int gy = min(max(ty0 * ST - PAD + pix / TIW, 0), a.Hin - 1), gx = min(max(tx0 * ST - PAD + pix % TIW, 0), a.Win - 1);
-            const float* p = in + ((size_t)gy * a.Win + gx) * CIN + g * 8;
+            const float* p = PRO == PRO_UNFOLD ? in + ((size_t)(gy * 8 + g) * (a.Win * 8) + gx * 8) : in + ((size_t)gy * a.Win + gx) * CIN + g * 8;
             r0[k] = *(const f32x4*)p;
             r1[k] = *(const f32x4*)(p + 4);
             if constexpr (PRO == PRO_B2IN) rp[k] = a.pool[(size_t)b * a.pool_stride + (size_t)gy * a.Win + gx];
@@ -487,6 +489,11 @@ void k_conv_mfma(ConvArgs a) {
             const bool ok = gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win;
             if (NITEM % NTHR != 0 && item >= NITEM) continue;
             f32x4 v0 = r0[k], v1 = r1[k];
+            if constexpr (PRO == PRO_UNFOLD) {
+                const float xm = a.xstat[b * 2], xr = a.xstat[b * 2 + 1];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { v0[q] = (v0[q] - xm) * xr; v1[q] = (v1[q] - xm) * xr; }
+            }
             if constexpr (PRO == PRO_BN || PRO == PRO_B2IN) {
                 const f32x4 m0 = *(const f32x4*)(s_stat + g * 8), m1 = *(const f32x4*)(s_stat + g * 8 + 4);
                 const f32x4 q0 = *(const f32x4*)(s_stat + CIN + g * 8), q1 = *(const f32x4*)(s_stat + CIN + g * 8 + 4);
@@ -686,7 +693,7 @@ void k_conv_mfma_p(ConvArgs a, int ntile, int total) {
         // vector pipe the MFMAs of the current tile are waiting for.)
         const int b = tile / ntile, tl = tile - b * ntile;
         const int tx0 = (tl % a.tiles_x) * TW, ty0 = (tl / a.tiles_x) * TH;
-        const float* in = a.in + (size_t)b * a.in_stride + g * 8;
+        const float* in = a.in + (size_t)b * a.in_stride + (PRO == PRO_UNFOLD ? 0 : g * 8);
         inside = 0u;
 #pragma unroll
         for (int k = 0; k < NIT; ++k) {
@@ -696,7 +703,7 @@ void k_conv_mfma_p(ConvArgs a, int ntile, int total) {
             const int gy = ty0 * ST - PAD + iy, gx = tx0 * ST - PAD + ix;
             if constexpr (KS == 1) {
                 const int cy = min(max(gy, 0), a.Hin - 1), cx = min(max(gx, 0), a.Win - 1);
-                const float* p = in + (cy * a.Win + cx) * CIN;
+                const float* p = PRO == PRO_UNFOLD ? in + ((cy * 8 + g) * (a.Win * 8) + cx * 8) : in + (cy * a.Win + cx) * CIN;
                 v0[k] = *(const f32x4*)p; v1[k] = *(const f32x4*)(p + 4);
                 inside |= (gy == cy && gx == cx) ? (1u << k) : 0u;
             } else {                              // 3x3 layers (24 -> 24, 8 -> 24): the branchy form measured 3-5 % faster there
@@ -728,8 +735,11 @@ void k_conv_mfma_p(ConvArgs a, int ntile, int total) {
                 f32x4 x0 = v0[k], x1 = v1[k];
                 const bool in_img = inside & (1u << k);
                 if constexpr (KS == 1) {
+                    float xm = 0.f, xr = 1.f;
+                    if constexpr (PRO == PRO_UNFOLD) { const int fb = tile / ntile; xm = a.xstat[fb * 2]; xr = a.xstat[fb * 2 + 1]; }
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
+                        if constexpr (PRO == PRO_UNFOLD) { x0[q] = (x0[q] - xm) * xr; x1[q] = (x1[q] - xm) * xr; }
                         if constexpr (PRO == PRO_BN) {
                             x0[q] = fmaxf((x0[q] - m0[q]) * r0[q], 0.f);
                             x1[q] = fmaxf((x1[q] - m1[q]) * r1[q], 0.f);
@@ -1368,9 +1378,14 @@ static hipError_t launch_basic_layer_t(xfh_ctx* c, int li, const float* in, size
             else { a.w = c->w.m16[li]; e = conv_mfma16_launch<128, 128, 1, 4, 1, PRO_BN, EPI>(c, a, B, &np, li); }                                   // 4x4 pixels, 8 waves of 16 x 16
             break;
         case 15: e = conv_mfma_launch<128, 64, 1, 1, 1, 2, 1, 8, PRO_BN, EPI>(c, a, B, &np, li); break;
-        case 18: case 20:                                                                                      // inputs: feats / unfold(xhat)
+        case 18:                                                                                               // input: feats
             if (persistent(B)) e = conv_mfma_p_launch<64, 64, 1, 1, 4, 1, 2, 16, PRO_PLAIN, EPI>(c, a, B, &np, li);
             else e = conv_mfma_launch<64, 64, 1, 1, 4, 1, 2, 16, PRO_PLAIN, EPI>(c, a, B, &np, li);
+            break;
+        case 20:                                                                                               // input: unfold2d(x-hat), read from the image while staging
+            a.xstat = c->xstat;
+            if (persistent(B)) e = conv_mfma_p_launch<64, 64, 1, 1, 4, 1, 2, 16, PRO_UNFOLD, EPI>(c, a, B, &np, li);
+            else e = conv_mfma_launch<64, 64, 1, 1, 4, 1, 2, 16, PRO_UNFOLD, EPI>(c, a, B, &np, li);
             break;
         case 19: case 21: case 22:
             if (persistent(B)) e = conv_mfma_p_launch<64, 64, 1, 1, 4, 1, 2, 16, PRO_BN, EPI>(c, a, B, &np, li);

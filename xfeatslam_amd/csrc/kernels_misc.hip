@@ -106,7 +106,7 @@ void k_preproc(const uint8_t* __restrict__ gray, size_t gray_stride, int H0, int
 // (workgroup 0 publishes them for block1.0), which saves the finalize launch
 __global__ __launch_bounds__(256)
 void k_norm_aux(const float* __restrict__ X, size_t x_stride, StatSrc xs, int H, int W,
-                float* __restrict__ xunfold, size_t xu_stride, float* __restrict__ pool, size_t pool_stride) {
+                float* __restrict__ pool, size_t pool_stride) {
     __shared__ double red[512];
     __shared__ float s_stat[2];
     const int b = blockIdx.z;
@@ -117,7 +117,6 @@ void k_norm_aux(const float* __restrict__ X, size_t x_stride, StatSrc xs, int H,
     const int by = q / w4, bx = q % w4;
     const float m = s_stat[0], r = s_stat[1];
     const float* x = X + (size_t)b * x_stride;
-    float* xu = xunfold + (size_t)b * xu_stride;
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -125,13 +124,10 @@ void k_norm_aux(const float* __restrict__ X, size_t x_stride, StatSrc xs, int H,
         f32x4 v = *(const f32x4*)(x + (size_t)y * W + xx);
 #pragma unroll
         for (int j = 0; j < 4; ++j) { v[j] = (v[j] - m) * r; s += v[j]; }
-        // unfold2d: cell (y/8, x/8), channel (y%8)*8 + (x%8)
-        *(f32x4*)(xu + ((size_t)(y >> 3) * (W >> 3) + (xx >> 3)) * 64 + (y & 7) * 8 + (xx & 7)) = v;
     }
     pool[(size_t)b * pool_stride + q] = s / 16.0f;
 }
 
-// relu(bn(raw)) of 4 channels (group g) at one pixel; st: mean[C], rstd[C]
 // ---- k_heads_heat / k_heads_kp: 128 pixels per workgroup, one pixel per lane -----------------------------
 #define HF_PX 128
 #define HF_LD 129
@@ -685,7 +681,7 @@ StatSrc stat_src(xfh_ctx* c, int j, int B);
 bool consumer_fold(int B);
 
 #define CK(x) do { hipError_t _e = (x); if (_e != hipSuccess) return _e; } while (0)
-enum { PRO_PLAIN = 0, PRO_BN = 1, PRO_IN = 2, PRO_B2IN = 3, PRO_FUSE = 4, PRO_L0 = 5 };
+enum { PRO_PLAIN = 0, PRO_BN = 1, PRO_IN = 2, PRO_B2IN = 3, PRO_FUSE = 4, PRO_L0 = 5, PRO_UNFOLD = 6 };
 
 hipError_t run_extract(xfh_ctx* c, const uint8_t* d_gray, int B, int H0, int W0, int lap0, int lap1, uint8_t* d_records, bool write_padding, float* d_images) {
     const int H = (H0 / 32) * 32, W = (W0 / 32) * 32;
@@ -706,7 +702,7 @@ hipError_t run_extract(xfh_ctx* c, const uint8_t* d_gray, int B, int H0, int W0,
     xsrc.stat = c->xstat;
     if (consumer_fold(B)) { xsrc.part = c->pre_part; xsrc.part_stride = (size_t)c->pre_npart * 2; xsrc.npart = npre; xsrc.count = (double)H * (double)W; xsrc.stat_out = c->xstat; }
     else CK(launch_finalize_image(c, B, npre, (double)H * (double)W));
-    hipLaunchKernelGGL(k_norm_aux, dim3((h4 * w4 + 255) / 256, 1, B), dim3(256), 0, s, c->X, xs, xsrc, H, W, c->xunfold, xs, c->skip_pool, xs / 16);
+    hipLaunchKernelGGL(k_norm_aux, dim3((h4 * w4 + 255) / 256, 1, B), dim3(256), 0, s, c->X, xs, xsrc, H, W, c->skip_pool, xs / 16);
     CK(hipGetLastError());
     // keypoint branch (keypoint_head.0-3 on unfold2d(x), softmax, depth-to-space) on the second stream: it only needs
     // the normalised image, so it runs beside the backbone (memory-bound 1x1 layers next to MFMA-bound 3x3 layers)
@@ -717,7 +713,7 @@ hipError_t run_extract(xfh_ctx* c, const uint8_t* d_gray, int B, int H0, int W0,
         if (e == hipSuccess) e = hipStreamWaitEvent(branch, c->ev_fork, 0);
         CK(e);
         c->stream = branch;
-        e = launch_basic_layer(c, 20, c->xunfold, xs, -1, PRO_PLAIN, h8, w8, B);
+        e = launch_basic_layer(c, 20, c->X, xs, -1, PRO_UNFOLD, h8, w8, B);          // unfold2d(x-hat) is never materialised
         if (e == hipSuccess) e = launch_basic_layer(c, 21, c->raw[20], c->raw_stride[20], 20, PRO_BN, h8, w8, B);
         if (e == hipSuccess) e = launch_basic_layer(c, 22, c->raw[21], c->raw_stride[21], 21, PRO_BN, h8, w8, B);
         if (e == hipSuccess) {
