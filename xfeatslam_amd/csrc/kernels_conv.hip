@@ -133,14 +133,19 @@ __device__ __forceinline__ void l0_conv(const float (&win)[9], const float* __re
 // 3 x 6 register window down it; the image comes straight from global memory (one 16-byte load + the two halo pixels per
 // row, the overlap between neighbours is served by the vector L1) -- no LDS staging, one barrier for the 4-wave fold.
 constexpr int L0S_TW = 128, L0S_TH = 32, L0S_R = 4;
+// The thread's 4 x 4 block is also one cell of skip1's AvgPool2d(4) (XFeat.cc:36-39): its mean of the normalised pixels goes to `pool`
+// (same summation order as a row-major loop over the block), and for small batches the kernel folds and publishes the image
+// statistics it normalises with (stage_stat) -- so no other kernel has to read the image between k_preproc and block1.
 __global__ __launch_bounds__(256)
-void k_block1_stats(const float* __restrict__ X, size_t x_stride, const float* __restrict__ xstat, int H, int W, int tiles_x,
-                    const float* __restrict__ w0, double* __restrict__ part, size_t part_stride) {
-    __shared__ double s_red[4 * 8];
+void k_block1_stats(const float* __restrict__ X, size_t x_stride, StatSrc xs, int H, int W, int tiles_x,
+                    const float* __restrict__ w0, double* __restrict__ part, size_t part_stride, float* __restrict__ pool, size_t pool_stride) {
+    __shared__ double s_red[512];
+    __shared__ float s_xst[2];
     const int t = threadIdx.x, b = blockIdx.z, tile = blockIdx.x;
+    stage_stat(xs, b, 1, tile == 0, s_xst, s_red, t, 256);
     const int gx = (tile % tiles_x) * L0S_TW + (t & 31) * 4, gy0 = (tile / tiles_x) * L0S_TH + (t >> 5) * L0S_R;
     const float* x = X + (size_t)b * x_stride;
-    const float m = xstat[b * 2], r = xstat[b * 2 + 1];
+    const float m = s_xst[0], r = s_xst[1];
     // row gy of the normalised, zero-padded image at columns gx-1 .. gx+4 (W % 4 == 0: the 16-byte load is all in or all out)
     auto load_row = [&](int gy, float (&row)[6]) {
 #pragma unroll
@@ -159,10 +164,13 @@ void k_block1_stats(const float* __restrict__ X, size_t x_stride, const float* _
     load_row(gy0 - 1, win[0]);
     load_row(gy0, win[1]);
     double sum[4] = {0.0, 0.0, 0.0, 0.0}, sq[4] = {0.0, 0.0, 0.0, 0.0};
+    float ps = 0.f;
 #pragma unroll
     for (int i = 0; i < L0S_R; ++i) {
         load_row(gy0 + i + 1, win[(i + 2) % 3]);
         const float (&r0)[6] = win[i % 3], (&r1)[6] = win[(i + 1) % 3], (&r2)[6] = win[(i + 2) % 3];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ps += r1[q + 1];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float wq[9] = {r0[q], r0[q + 1], r0[q + 2], r1[q], r1[q + 1], r1[q + 2], r2[q], r2[q + 1], r2[q + 2]};
@@ -176,6 +184,7 @@ void k_block1_stats(const float* __restrict__ X, size_t x_stride, const float* _
     }
 #pragma unroll
     for (int co = 0; co < 4; ++co) { sum[co] = wave_sum_f64(sum[co]); sq[co] = wave_sum_f64(sq[co]); }
+    if (gy0 < H && gx < W) pool[(size_t)b * pool_stride + (size_t)(gy0 >> 2) * (W >> 2) + (gx >> 2)] = ps / 16.0f;
     if ((t & 63) == 0) {
 #pragma unroll
         for (int co = 0; co < 4; ++co) { s_red[(t >> 6) * 8 + co * 2] = sum[co]; s_red[(t >> 6) * 8 + co * 2 + 1] = sq[co]; }
@@ -1313,13 +1322,6 @@ static hipError_t launch_basic_layer_t(xfh_ctx* c, int li, const float* in, size
     int np = 0;
     hipError_t e = hipSuccess;
     switch (li) {
-        case 0:
-            // statistics only (k_block1_stats); nothing to do when they come from the weight file
-            np = conv_layer_npart(0, Hout, Wout);
-            if (!running)
-                launch_k(c, XFH_K_CONV_DIRECT, li, k_block1_stats, dim3(np, 1, B), dim3(256), 0, in, in_stride, (const float*)c->xstat, Hin, Win,
-                         (Wout + L0S_TW - 1) / L0S_TW, (const float*)c->w.direct[0], c->part[0], c->part_stride[0]);
-            break;
         case 1:
             a.xstat = c->xstat; a.w0 = c->w.direct[0]; a.bias0 = (EPI == EPI_BIAS_RELU) ? c->w.bn_bias[0] : nullptr;
             e = conv_direct_launch<4, 8, 2, PRO_L0>(c, a, B, &np, li);
@@ -1404,6 +1406,20 @@ static hipError_t launch_basic_layer_t(xfh_ctx* c, int li, const float* in, size
 hipError_t launch_basic_layer(xfh_ctx* c, int li, const float* in, size_t in_stride, int src, int pro, int Hin, int Win, int B) {
     if (c->cfg.bn_mode == XFH_BN_RUNNING_FOLDED) return launch_basic_layer_t<EPI_BIAS_RELU>(c, li, in, in_stride, src, pro, Hin, Win, B);
     return launch_basic_layer_t<EPI_STATS>(c, li, in, in_stride, src, pro, Hin, Win, B);
+}
+
+// block1.0 in the batch-statistics mode: its BatchNorm statistics (the map itself is recomputed inside block1.1) + skip1's AvgPool4 +,
+// for B <= 8, the fold of the image statistics (xs.part != null) that every later kernel reads from c->xstat
+hipError_t launch_block1_stats(xfh_ctx* c, const StatSrc& xs, int H, int W, int B) {
+    const int np = conv_layer_npart(0, H, W);
+    c->lh[0] = H; c->lw[0] = W; c->npart[0] = np;
+    const size_t xsz = (size_t)c->Hmax * c->Wmax;
+    launch_k(c, XFH_K_CONV_DIRECT, 0, k_block1_stats, dim3(np, 1, B), dim3(256), 0, (const float*)c->X, xsz, xs, H, W,
+             (W + L0S_TW - 1) / L0S_TW, (const float*)c->w.direct[0], c->part[0], c->part_stride[0], c->skip_pool, xsz / 16);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || consumer_fold(B)) return e;
+    hipLaunchKernelGGL(k_bn_finalize, dim3(B), dim3(256), 0, c->stream, (const double*)c->part[0], c->part_stride[0], np, 4, (double)H * (double)W, c->stat[0]);
+    return hipGetLastError();
 }
 
 // block_fusion.2: Conv2d(64,64,1) with bias, no BN (src/XFeat.cc:75) -> feats

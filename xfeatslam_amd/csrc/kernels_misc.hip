@@ -675,6 +675,7 @@ void k_desc(const float* __restrict__ feats, size_t m_stride, const float* __res
 // pipeline
 hipError_t launch_basic_layer(xfh_ctx* c, int li, const float* in, size_t in_stride, int src, int pro, int Hin, int Win, int B);
 hipError_t launch_fusion_out(xfh_ctx* c, int Hh, int Wh, int B);
+hipError_t launch_block1_stats(xfh_ctx* c, const StatSrc& xs, int H, int W, int B);
 hipError_t launch_fusion_chain(xfh_ctx* c, int Hh, int Wh, int B, int* done);
 hipError_t launch_finalize_image(xfh_ctx* c, int B, int npart, double count);
 StatSrc stat_src(xfh_ctx* c, int j, int B);
@@ -702,8 +703,14 @@ hipError_t run_extract(xfh_ctx* c, const uint8_t* d_gray, int B, int H0, int W0,
     xsrc.stat = c->xstat;
     if (consumer_fold(B)) { xsrc.part = c->pre_part; xsrc.part_stride = (size_t)c->pre_npart * 2; xsrc.npart = npre; xsrc.count = (double)H * (double)W; xsrc.stat_out = c->xstat; }
     else CK(launch_finalize_image(c, B, npre, (double)H * (double)W));
-    hipLaunchKernelGGL(k_norm_aux, dim3((h4 * w4 + 255) / 256, 1, B), dim3(256), 0, s, c->X, xs, xsrc, H, W, c->skip_pool, xs / 16);
-    CK(hipGetLastError());
+    // skip1's AvgPool4 of the normalised image (and, for B <= 8, the published image statistics): in the reference's batch-statistics
+    // mode k_block1_stats produces both on its one pass over the image; with eval() statistics that kernel is not needed and
+    // k_norm_aux does it
+    if (c->cfg.bn_mode == XFH_BN_BATCH_STATS) CK(launch_block1_stats(c, xsrc, H, W, B));
+    else {
+        hipLaunchKernelGGL(k_norm_aux, dim3((h4 * w4 + 255) / 256, 1, B), dim3(256), 0, s, c->X, xs, xsrc, H, W, c->skip_pool, xs / 16);
+        CK(hipGetLastError());
+    }
     // keypoint branch (keypoint_head.0-3 on unfold2d(x), softmax, depth-to-space) on the second stream: it only needs
     // the normalised image, so it runs beside the backbone (memory-bound 1x1 layers next to MFMA-bound 3x3 layers)
     {
@@ -730,7 +737,6 @@ hipError_t run_extract(xfh_ctx* c, const uint8_t* d_gray, int B, int H0, int W0,
     // and the main stream must never run ahead of, or be destroyed before, the second stream)
     auto backbone = [&]() -> hipError_t {
     // block1
-    CK(launch_basic_layer(c, 0, c->X, xs, -2, PRO_IN, H, W, B));
     CK(launch_basic_layer(c, 1, c->X, xs, 0, PRO_L0, H, W, B));               // block1.0 is recomputed from the image while staging
     CK(launch_basic_layer(c, 2, c->raw[1], c->raw_stride[1], 1, PRO_BN, c->lh[1], c->lw[1], B));
     CK(launch_basic_layer(c, 3, c->raw[2], c->raw_stride[2], 2, PRO_BN, c->lh[2], c->lw[2], B));
