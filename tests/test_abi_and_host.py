@@ -12,6 +12,14 @@ from conftest import ROOT
 from xfeatslam_amd import capi, synth, weights as WT
 
 
+@pytest.fixture(scope="module", autouse=True)
+def _built_library():
+    """the C-ABI library is a build product (git-ignored): on a checkout where __graft_entry__.build() has not run yet, build it
+    here (hipcc cross-compiles for gfx950 without a GPU) -- the product itself never falls back, it just fails to load"""
+    if not os.path.exists(capi.LIB_PATH):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "xfeatslam_amd", "csrc"), "-s", "-j8"])
+
+
 def test_header_symbols_exported_and_bound():
     hdr = open(os.path.join(ROOT, "include", "xfeat_hip.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
