@@ -125,9 +125,36 @@ size_t xfh_record_bytes(int nfeatures);
 size_t xfh_record_kps_offset(void);
 size_t xfh_record_desc_offset(int nfeatures);
 
-/* B dense frames [B][H][W] u8 in HOST memory -> B records in HOST memory */
+/* B dense frames [B][H][W] u8 in HOST memory -> B records in HOST memory: the batched form of operator()'s contract (host image
+ * in, host keypoints / descriptors out, XFextractor.cc:250-356; SURVEY.md 8d "host-visible").  B is NOT limited by cfg.max_batch:
+ * the call is cut into sub-batches of cfg.max_batch frames that rotate over up to xfh_pipeline_lanes (default 4) internal lanes
+ * (own activations and HIP streams, shared weights, built at the first call that needs them), with the H2D copy of a sub-batch,
+ * the kernels of others and the D2H copy of finished records overlapping on separate streams.  gray / records_out should be
+ * pinned (xfh_host_alloc, or the caller's own buffers through xfh_host_register): pageable memory works, but the runtime then
+ * stages every copy and the stages serialise.
+ *   xfh_extract_batch_submit  returns when everything is queued; both buffers must stay untouched until the batch is complete.
+ *                             Up to XFH_MAX_BATCHES_INFLIGHT submits may be outstanding (one more: XFH_ERR_INVALID_ARG); their
+ *                             sub-batches simply queue up on the lanes, so a consumer that double-buffers records_out keeps
+ *                             the GPU busy across calls: submit(t + 1); wait() -> batch t is complete; ...
+ *   xfh_extract_batch_wait    the OLDEST outstanding submit is complete in its records_out (XFH_ERR_INVALID_ARG if none is)
+ *   xfh_extract_batch_drain   every submit so far is complete
+ *   xfh_extract_batch         = submit + drain.
+ * These calls and the single-frame ring (xfh_extract_submit) share the ctx' first frame buffer: a batch call while a
+ * single-frame submission is outstanding returns XFH_ERR_INVALID_ARG, and so does xfh_extract (it would collect the OLDER
+ * submission's result). */
+#define XFH_MAX_BATCHES_INFLIGHT 8
 int xfh_extract_batch(xfh_ctx* ctx, const uint8_t* gray, int B, int H, int W, int lap_x0, int lap_x1,
                       void* records_out);
+int xfh_extract_batch_submit(xfh_ctx* ctx, const uint8_t* gray, int B, int H, int W, int lap_x0, int lap_x1,
+                             void* records_out);
+int xfh_extract_batch_wait(xfh_ctx* ctx);
+int xfh_extract_batch_drain(xfh_ctx* ctx);
+int xfh_pipeline_lanes(xfh_ctx* ctx, int lanes);      /* 1 .. 8; sub-batches in flight side by side */
+/* pinned host memory for the calls above (hipHostMalloc / hipHostRegister behind the ABI, for host languages without a HIP binding) */
+int xfh_host_alloc(void** p, size_t nbytes);
+int xfh_host_free(void* p);
+int xfh_host_register(void* p, size_t nbytes);
+int xfh_host_unregister(void* p);
 /* same with DEVICE pointers (frames resident in HBM, records stay in HBM for the matcher or
  * an RCCL all-gather); asynchronous on the ctx stream -- call xfh_synchronize to wait. */
 int xfh_extract_batch_device(xfh_ctx* ctx, const uint8_t* d_gray, int B, int H, int W, int lap_x0,
@@ -263,39 +290,9 @@ int xfh_dev_free(void* dptr);
 int xfh_memcpy_h2d(void* dst, const void* src, size_t nbytes);
 int xfh_memcpy_d2h(void* dst, const void* src, size_t nbytes);
 
-/* ---- measurement and debugging -------------------------------------------------------
- * Kernel timing: while enabled, every launch of the kernel family `kernel_id` on the ctx
- * stream is bracketed by hipEvents; xfh_timing_read returns launches and total ms since
- * the last reset.  bench.py uses it for the roofline line. */
-enum {
-    XFH_K_NONE = 0, XFH_K_MNN_GEMM = 1, XFH_K_CONV_MFMA = 2, XFH_K_CONV_DIRECT = 3,
-    XFH_K_NMS = 4, XFH_K_SELECT = 5, XFH_K_DESC = 6, XFH_K_HEADS = 7, XFH_K_DIST_I32 = 8,
-    XFH_K_PREPROC = 9, XFH_K_BEST2 = 10, XFH_K_DISTINCTIVE = 11, XFH_K_COUNT = 12
-};
-/* layer_mask selects conv layers for XFH_K_CONV_*: 0 = every layer, else bit i = BasicLayer i
- * (0..22 in XFeatModel order) and bit 23 = block_fusion.2 */
-int xfh_timing_enable(xfh_ctx* ctx, int kernel_id, unsigned layer_mask);
-int xfh_timing_read(xfh_ctx* ctx, int* launches, double* total_ms);   /* XFH_ERR_BATCH_TOO_LARGE: more than 4096 launches matched since
-                                                                          * xfh_timing_enable; *launches / *total_ms cover the first 4096 */
-/* `iters` launches of the match GEMM alone, back to back, on two prepared images: wall time per launch between two stream
- * events.  (Dispatch-attached timestamps of consecutive kernels in a busy stream overlap; this is the steady-state cost.) */
-int xfh_bench_mnn_gemm(xfh_ctx* ctx, const void* d_image1, int n1, const void* d_image2, int n2, int iters, double* us_per_launch);
-/* `iters` whole xfh_match_mnn_prepared_device calls (both launches; _raw: xfh_match_mnn_device, three) back to back from C: wall time per call between two stream
- * events -- what a C++ caller's loop sees, without the per-call cost of a foreign-function binding. */
-int xfh_bench_match_prepared(xfh_ctx* ctx, const void* d_image1, int n1, const void* d_image2, int n2, float min_cossim,
-                             int* d_idx1, int* d_idx2, float* d_dist, int* d_n_matches, int iters, double* us_per_call);
-int xfh_bench_match_raw(xfh_ctx* ctx, const float* d_d1, int n1, const float* d_d2, int n2, float min_cossim,
-                        int* d_idx1, int* d_idx2, float* d_dist, int* d_n_matches, int iters, double* us_per_call);   /* the same for xfh_match_mnn_device */
-const char* xfh_kernel_name(int kernel_id);
-
-/* intermediate tensors of frame `frame` of the last extract call, copied to host as float
- * (ids match oracle/xfeat_oracle.h; image-like tensors are NHWC).  count_out = floats. */
-enum {
-    XFH_T_X = 0, XFH_T_XSTAT = 1, XFH_T_SKIP_POOL = 2,                               /* 3, 4, 5, 7 (unfold2d(x), x1 + skip, fusion input, normalised features) */
-    XFH_T_FEATS = 6, XFH_T_H1 = 8, XFH_T_K1H = 9,                                   /* are never materialised on the GPU: fused into consumers */
-    XFH_T_RAW0 = 16, XFH_T_STAT0 = 48, XFH_T_SEL = 80                               /* RAW0 + 0 (block1.0) likewise: recomputed inside block1.1 */
-};
-int xfh_debug_tensor(xfh_ctx* ctx, int id, int frame, float* out, size_t capacity, size_t* count_out);
+/* Measurement and debugging entry points (kernel timers, back-to-back timing loops, intermediate tensors, counter
+ * calibration kernels) are declared in xfeat_hip_bench.h: they are exported by the same library but are not part of the
+ * drop-in surface. */
 
 #ifdef __cplusplus
 }

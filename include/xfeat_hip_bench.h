@@ -1,0 +1,60 @@
+/*
+ * xfeat_hip_bench.h -- measurement and debugging entry points of libxfeat_hip.so.  NOT part of the drop-in boundary
+ * (include/xfeat_hip.h): nothing a SLAM consumer calls lives here.  bench.py, tools/ and tests/ use these through ctypes.
+ */
+#ifndef XFEAT_HIP_BENCH_H
+#define XFEAT_HIP_BENCH_H
+
+#include "xfeat_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- kernel timers --------------------------------------------------------------------
+ * Kernel timing: while enabled, every launch of the kernel family `kernel_id` on the ctx
+ * stream is bracketed by hipEvents; xfh_timing_read returns launches and total ms since
+ * the last reset.  bench.py uses it for the roofline line. */
+enum {
+    XFH_K_NONE = 0, XFH_K_MNN_GEMM = 1, XFH_K_CONV_MFMA = 2, XFH_K_CONV_DIRECT = 3,
+    XFH_K_NMS = 4, XFH_K_SELECT = 5, XFH_K_DESC = 6, XFH_K_HEADS = 7, XFH_K_DIST_I32 = 8,
+    XFH_K_PREPROC = 9, XFH_K_BEST2 = 10, XFH_K_DISTINCTIVE = 11, XFH_K_COUNT = 12
+};
+/* layer_mask selects conv layers for XFH_K_CONV_*: 0 = every layer, else bit i = BasicLayer i
+ * (0..22 in XFeatModel order) and bit 23 = block_fusion.2 */
+int xfh_timing_enable(xfh_ctx* ctx, int kernel_id, unsigned layer_mask);
+int xfh_timing_read(xfh_ctx* ctx, int* launches, double* total_ms);   /* XFH_ERR_BATCH_TOO_LARGE: more than 4096 launches matched since
+                                                                          * xfh_timing_enable; *launches / *total_ms cover the first 4096 */
+/* `iters` launches of the match GEMM alone, back to back, on two prepared images: wall time per launch between two stream
+ * events.  (Dispatch-attached timestamps of consecutive kernels in a busy stream overlap; this is the steady-state cost.) */
+int xfh_bench_mnn_gemm(xfh_ctx* ctx, const void* d_image1, int n1, const void* d_image2, int n2, int iters, double* us_per_launch);
+/* `iters` whole xfh_match_mnn_prepared_device calls (both launches; _raw: xfh_match_mnn_device, three) back to back from C: wall time per call between two stream
+ * events -- what a C++ caller's loop sees, without the per-call cost of a foreign-function binding. */
+int xfh_bench_match_prepared(xfh_ctx* ctx, const void* d_image1, int n1, const void* d_image2, int n2, float min_cossim,
+                             int* d_idx1, int* d_idx2, float* d_dist, int* d_n_matches, int iters, double* us_per_call);
+int xfh_bench_match_raw(xfh_ctx* ctx, const float* d_d1, int n1, const float* d_d2, int n2, float min_cossim,
+                        int* d_idx1, int* d_idx2, float* d_dist, int* d_n_matches, int iters, double* us_per_call);   /* the same for xfh_match_mnn_device */
+const char* xfh_kernel_name(int kernel_id);
+
+/* intermediate tensors of frame `frame` of the last extract call, copied to host as float
+ * (ids match oracle/xfeat_oracle.h; image-like tensors are NHWC).  count_out = floats. */
+enum {
+    XFH_T_X = 0, XFH_T_XSTAT = 1, XFH_T_SKIP_POOL = 2,                               /* 3, 4, 5, 7 (unfold2d(x), x1 + skip, fusion input, normalised features) */
+    XFH_T_FEATS = 6, XFH_T_H1 = 8, XFH_T_K1H = 9,                                   /* are never materialised on the GPU: fused into consumers */
+    XFH_T_RAW0 = 16, XFH_T_STAT0 = 48, XFH_T_SEL = 80                               /* RAW0 + 0 (block1.0) likewise: recomputed inside block1.1 */
+};
+int xfh_debug_tensor(xfh_ctx* ctx, int id, int frame, float* out, size_t capacity, size_t* count_out);
+
+
+/* Counter calibration (MI355X_MICROARCH.md, HBM section: "calibrate on a known byte count in your own access pattern before
+ * trusting an absolute"): `iters` launches of a kernel that moves exactly `nbytes` per launch (a buffer far larger than the
+ * 256 MB Infinity Cache: use >= 1 GiB), named k_calib<mode> in a kernel trace.  mode 0 / 1 / 4 = read with 4 / 16 / 32 bytes per
+ * lane, 2 / 3 / 5 = write with 4 / 16 / 32 bytes per lane -- the access widths of the extraction kernels.  tools/pmc_calib.sh runs
+ * them under rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE; tools/summarize_profiles.py turns counter / nbytes into the
+ * correction factors of profiles/pmc_traffic.json. */
+int xfh_bench_calib(xfh_ctx* ctx, int mode, size_t nbytes, int iters);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XFEAT_HIP_BENCH_H */

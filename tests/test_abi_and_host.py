@@ -21,9 +21,13 @@ def _built_library():
 
 
 def test_header_symbols_exported_and_bound():
-    hdr = open(os.path.join(ROOT, "include", "xfeat_hip.h")).read()
-    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    declared = set(re.findall(r"\b(xfh_[a-z0-9_]+)\s*\(", hdr))
+    declared = set()
+    for name in ("xfeat_hip.h", "xfeat_hip_bench.h"):              # the drop-in surface, and the measurement / debugging entry points
+        hdr = open(os.path.join(ROOT, "include", name)).read()
+        hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+        found = set(re.findall(r"\b(xfh_[a-z0-9_]+)\s*\(", hdr))
+        assert (name == "xfeat_hip_bench.h") == any(f.startswith(("xfh_bench_", "xfh_timing_", "xfh_debug_")) for f in found), name
+        declared |= found
     bound = {s[0] for s in capi.SYMBOLS}
     assert declared == bound, (declared ^ bound)
     L = capi.lib()

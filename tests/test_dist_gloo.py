@@ -1,7 +1,8 @@
-"""CPU test of the multi-GPU path (xfeatslam_amd/dist.py) with world_size 2 over gloo: frames
-shard i -> rank i mod R, one all-gather of fixed-size records, rank order restored.  The
-extractor is replaced by the CPU oracle (test infrastructure) packed into the same record
-layout the HIP library writes, so the gather/unshard logic is exercised with real records."""
+"""CPU test of the multi-GPU partitioning (xfeatslam_amd/dist.py: ShardPlan, the TCP bootstrap; xfh_unpack_compact) with
+world sizes 2 and 3 over gloo: frame i -> rank i mod R, one all-gather of fixed-size records in the rank-major layout of
+xfh_allgather_records, global frame order restored.  The extractor is replaced by the CPU oracle (test infrastructure) packed
+into the record layout the HIP library writes.  The RCCL calls themselves (csrc/comm.cpp) run with 2 and 3 ranks in
+tests/test_gpu_comm_world2.py."""
 import os
 import socket
 
@@ -31,31 +32,38 @@ def _pack(kps, desc, nv, mono, rec, koff, doff):
 
 
 def _worker(rank, world, port, nframes, out_dir):
+    """one rank: ShardPlan (the product's index arithmetic, xfeatslam_amd/dist.py) decides which frames this rank extracts
+    and where each record lands; the bytes move with a gloo all-gather here (RCCL through xfh_comm_* on the GPU,
+    tests/test_gpu_comm_world2.py) in the same rank-major [world][slots] layout xfh_allgather_records produces"""
     import sys
     sys.path.insert(0, ROOT)
+    import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     from oracle import oracle as O
     O.set_threads(1)
-    d = xd.init_process_group(device_is_gpu=False)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
     rec, koff, doff = _rec_layout()
     orc = O.Oracle(WT.pack_blob(WT.make_synthetic(1234, 3.0)))
-
-    def extract_fn(fr):
-        return torch.from_numpy(np.concatenate([_pack(*orc.extract(f, NF, (0, 0)), rec, koff, doff) for f in fr]))
     frames = synth.frames(nframes, 64, 96, seed=5)
-    recs = xd.ShardedFrontEnd(extract_fn, rec).run(frames)
-    np.save(os.path.join(out_dir, f"r{rank}.npy"), torch.stack(recs).numpy())
-    d.barrier()
-    d.destroy_process_group()
+    plan = xd.ShardPlan(nframes, rank, world)
+    local = torch.from_numpy(np.concatenate([_pack(*orc.extract(frames[i], NF, (0, 0)), rec, koff, doff) for i in plan.local]))
+    assert local.numel() == plan.slots * rec
+    gathered = torch.empty(world * local.numel(), dtype=torch.uint8)
+    dist.all_gather_into_tensor(gathered, local)
+    recs = plan.unshard_bytes(gathered.numpy(), rec)
+    np.save(os.path.join(out_dir, f"r{rank}.npy"), np.stack(recs))
+    dist.barrier()
+    dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("nframes", [4, 5])
-def test_shard_and_all_gather_world2(tmp_path, oracle_mod, nframes):
+@pytest.mark.parametrize("world,nframes", [(2, 4), (2, 5), (3, 2)])
+def test_shard_and_all_gather_world_n(tmp_path, oracle_mod, world, nframes):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
-    mp.spawn(_worker, args=(2, port, nframes, str(tmp_path)), nprocs=2, join=True)
-    a = np.load(tmp_path / "r0.npy"); b = np.load(tmp_path / "r1.npy")
-    assert a.shape[0] == nframes and np.array_equal(a, b)               # every rank holds all records, frame order
+    mp.spawn(_worker, args=(world, port, nframes, str(tmp_path)), nprocs=world, join=True)
+    views = [np.load(tmp_path / f"r{r}.npy") for r in range(world)]
+    a = views[0]
+    assert a.shape[0] == nframes and all(np.array_equal(a, v) for v in views[1:])     # every rank holds all records, frame order
     rec, koff, doff = _rec_layout()
     orc = oracle_mod.Oracle(WT.pack_blob(WT.make_synthetic(1234, 3.0)))
     frames = synth.frames(nframes, 64, 96, seed=5)
@@ -68,6 +76,12 @@ def test_shard_arithmetic():
     assert xd.frames_per_rank(10, 4) == 3 and xd.frames_per_rank(8, 8) == 1
     g = [[f"r{r}j{j}" for j in range(3)] for r in range(4)]
     assert xd.unshard(g, 10, 4) == [f"r{i % 4}j{i // 4}" for i in range(10)]
+    p = xd.ShardPlan(10, 1, 4)
+    assert p.slots == 3 and p.local == [1, 5, 9] and xd.ShardPlan(10, 3, 4).local == [3, 7, 7]           # the last round is padded
+    assert xd.ShardPlan(2, 2, 3).local == [0] and xd.ShardPlan(2, 2, 3).slots == 1                       # a rank without a frame of its own
+    assert p.global_order() == [(i % 4, i // 4) for i in range(10)]
+    flat = np.arange(4 * 3 * 2, dtype=np.uint8)                                                          # [world][slots] records of 2 bytes
+    assert [v.tolist() for v in p.unshard_bytes(flat, 2)] == [[(i % 4 * 3 + i // 4) * 2, (i % 4 * 3 + i // 4) * 2 + 1] for i in range(10)]
 
 
 def _uid_worker(rank, world, port, out_dir):

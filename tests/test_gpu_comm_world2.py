@@ -1,0 +1,100 @@
+"""BASELINE.json configs[3] with MORE THAN ONE RANK: a global batch is sharded frame i -> rank i mod R over R
+processes, each with its own ctx, and the records reach the consumer through xfh_comm_* -- ncclAllGather, the ncclSend / ncclRecv
+group (r * nb offsets, both roots), and the compact exchange (size all-gather, exact counts) -- i.e. every line of
+csrc/comm.cpp that a world of one rank never executes.  The box has ONE GPU and real RCCL refuses two ranks on one device, so the
+worker processes load the TEST-ONLY librccl stand-in of tests/stubs (same symbols; bytes move through a shared file) through the
+dlopen search comm.cpp performs anyway.  Rank 0's gathered records, unsharded to global frame order, must equal the records a
+single serial ctx produces for the same frames bit for bit, and the oracle's keypoints / descriptors."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, joined_desc_diff, kp_set
+from xfeatslam_amd import capi, dist as xd, weights as WT
+
+pytestmark = pytest.mark.gpu
+
+sys.path.insert(0, os.path.join(ROOT, "tests", "workers"))
+
+
+def _run_world(world, n, out_dir):
+    stub_dir = os.path.join(ROOT, "tests", "stubs")
+    if not os.path.exists(os.path.join(stub_dir, "librccl.so.1")):
+        subprocess.check_call(["make", "-C", stub_dir, "-s"])
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = stub_dir + (":" + env["LD_LIBRARY_PATH"] if env.get("LD_LIBRARY_PATH") else "")
+    worker = os.path.join(ROOT, "tests", "workers", "comm_world_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), str(port), str(n), str(out_dir)], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=300)[0])
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, f"rank {r} failed:\n{outs[r] if r < len(outs) else ''}"
+    return outs
+
+
+@pytest.mark.parametrize("world,n", [(2, 7), (3, 4)])
+def test_sharded_extract_and_gathers_world_n(gpu_lib, oracle_mod, tmp_path, world, n):
+    import comm_world_worker as Wk
+    from xfeatslam_amd.extractor import Context
+    outs = _run_world(world, n, tmp_path)
+    assert any("rccl_stub: TEST-ONLY" in o for o in outs)
+    NF, H, W = Wk.NF, Wk.H, Wk.W
+    blob = WT.pack_blob(WT.make_synthetic(1234, 6.0))
+    ref = Context(nfeatures=NF, max_height=H, max_width=W, max_batch=n, flags=capi.FLAG_SERIAL_BRANCH)
+    ref.load_weights(blob)
+    rec = ref.rec_bytes
+    plan = xd.ShardPlan(n, 0, world)
+    want = {}
+    for step in range(Wk.STEPS):
+        fr = Wk.step_frames(n, step)
+        raw = np.empty(n * rec, np.uint8)
+        capi.check(gpu_lib.xfh_extract_batch(ref.h, fr.ctypes.data, n, H, W, 0, 64, raw.ctypes.data), ref.h)
+        want[step] = raw.reshape(n, rec)
+    # all-gather: every rank holds the records of all ranks, rank-major; unsharded = the serial ctx' records in frame order
+    for step in range(Wk.STEPS):
+        views = [np.load(tmp_path / f"allgather_s{step}_r{r}.npy") for r in range(world)]
+        for r in range(1, world):
+            assert np.array_equal(views[0], views[r]), (step, r)
+        got = plan.unshard_bytes(views[0], rec)
+        for i in range(n):
+            assert np.array_equal(got[i], want[step][i]), (step, i)
+    # gather to either root = the all-gather's bytes of the last step
+    last = np.load(tmp_path / f"allgather_s{Wk.STEPS - 1}_r0.npy")
+    for root in range(world):
+        assert np.array_equal(np.load(tmp_path / f"root{root}.npy"), last), root
+    # compact gather of step 1 (it holds the frame without keypoints), unpacked on the host = the padded records
+    comp = plan.unshard_bytes(np.load(tmp_path / "compact.npy"), rec)
+    nvs = []
+    for i in range(n):
+        a, b = ref.parse_records(np.ascontiguousarray(comp[i]), 1)[0], ref.parse_records(np.ascontiguousarray(want[1][i]), 1)[0]
+        assert a[2:4] == b[2:4] and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), i
+        nvs.append(b[2])
+    assert nvs[n // 2] == 0 and sum(nvs) > 0
+    sizes = np.load(tmp_path / "compact_sizes.npy")
+    for r in range(world):
+        rows = sum(ref.parse_records(np.ascontiguousarray(want[1][i]), 1)[0][2] for i in xd.ShardPlan(n, r, world).local)
+        S = plan.slots
+        assert sizes[r] == 256 + ((S * 16 + 255) & ~255) + ((rows * 28 + 255) & ~255) + rows * 256, r
+    # and the serial ctx itself against the oracle (the parity anchor of the records that travelled)
+    orc = oracle_mod.Oracle(blob)
+    fr = Wk.step_frames(n, 0)
+    for i in range(n):
+        hk, hd, hnv, hmono, _ = ref.parse_records(np.ascontiguousarray(want[0][i]), 1)[0]
+        ok, od, onv, omono = orc.extract(fr[i], NF, (0, 64))
+        assert (hnv, hmono) == (onv, omono) and kp_set(hk) == kp_set(ok), i
+        dd, _, ncommon = joined_desc_diff(ok, od, hk, hd)
+        assert ncommon == hnv and dd <= 1e-4, (i, dd)
+    ref.close()

@@ -487,3 +487,92 @@ def test_match_records_drops_padding_pairs(gpu_lib, oracle_mod):
     assert got == want and len(want) > 10
     assert all(k1["size"][i] > 0 and k2["size"][j] > 0 for i, j in got)
     ctx.close()
+
+
+def test_host_visible_batch_pipeline(gpu_lib, oracle_mod, weights_dense):
+    """xfh_extract_batch / _submit / _wait (host frames in, host records out): a call of B frames with B far above
+    cfg.max_batch is cut into sub-batches that rotate over the lanes (own activations and streams, shared weights), with H2D,
+    kernels and D2H on separate streams.  Pinned and pageable caller buffers, blocking and asynchronous form, ragged last
+    sub-batch, several submits outstanding: every record equals the one a lone serial ctx produces for the frame, bit for bit;
+    frame 0 is checked against the oracle."""
+    from xfeatslam_amd.extractor import Context
+    L = gpu_lib
+    _, blob = weights_dense
+    H, W, nf, S = 96, 128, 256, 6
+    n = 5 * S + 2                                            # 6 sub-batches on 4 lanes (two lanes run twice: both buffer generations), ragged tail
+    fr = synth.frames(n, H, W, seed=123)
+    fr[7] = 0                                                # a frame without keypoints
+    ref_ctx = Context(nfeatures=nf, max_height=H, max_width=W, max_batch=n, flags=capi.FLAG_SERIAL_BRANCH); ref_ctx.load_weights(blob)
+    rb = ref_ctx.rec_bytes
+    d_in = capi.DeviceBuffer(fr.nbytes).upload(fr); d_rec = capi.DeviceBuffer(n * rb)
+    capi.check(L.xfh_extract_batch_device(ref_ctx.h, d_in.ptr, n, H, W, 0, 64, d_rec.ptr), ref_ctx.h)
+    ref_ctx.synchronize()
+    want = d_rec.download(np.uint8, n * rb)
+    ref_ctx.close()
+    ctx = _ctx(nf, H, W, B=S); ctx.load_weights(blob)
+    # pageable caller memory, blocking call
+    out = np.zeros(n * rb, np.uint8)
+    capi.check(L.xfh_extract_batch(ctx.h, fr.ctypes.data, n, H, W, 0, 64, out.ctypes.data), ctx.h)
+    assert np.array_equal(out, want)
+    # pinned caller memory (xfh_host_alloc), three submits outstanding, one wait; different lane counts
+    hin = capi.HostBuffer(fr.nbytes); hin.array[:] = fr.reshape(-1)
+    houts = [capi.HostBuffer(n * rb) for _ in range(3)]
+    for lanes in (4, 2, 1, 8):
+        assert L.xfh_pipeline_lanes(ctx.h, lanes) == 0
+        for h in houts:
+            h.array[:] = 0
+            capi.check(L.xfh_extract_batch_submit(ctx.h, hin.ptr, n, H, W, 0, 64, h.ptr), ctx.h)
+        capi.check(L.xfh_extract_batch_wait(ctx.h), ctx.h)       # the oldest submit
+        assert np.array_equal(houts[0].array, want), lanes
+        capi.check(L.xfh_extract_batch_drain(ctx.h), ctx.h)
+        assert L.xfh_extract_batch_wait(ctx.h) == 1                # nothing outstanding any more
+        for h in houts:
+            assert np.array_equal(h.array, want), lanes
+    assert L.xfh_pipeline_lanes(ctx.h, 0) == 1 and L.xfh_pipeline_lanes(ctx.h, 9) == 1
+    # a registered caller buffer
+    reg = np.zeros(n * rb + 4096, np.uint8)
+    assert L.xfh_host_register(reg.ctypes.data, reg.nbytes) == 0
+    capi.check(L.xfh_extract_batch(ctx.h, hin.ptr, n, H, W, 0, 64, reg.ctypes.data), ctx.h)
+    assert L.xfh_host_unregister(reg.ctypes.data) == 0
+    assert np.array_equal(reg[:n * rb], want)
+    # the single-frame ring and the batch path share the ctx' first frame buffer: refused while a submission is outstanding
+    img = np.ascontiguousarray(fr[0])
+    capi.check(L.xfh_extract_submit(ctx.h, img.ctypes.data, H, W, W, 0, 64), ctx.h)
+    k = np.zeros(nf, capi.KP_DTYPE); d = np.zeros((nf, 64), np.float32); nv, mono = C.c_int(), C.c_int()
+    assert L.xfh_extract_batch(ctx.h, hin.ptr, n, H, W, 0, 64, houts[0].ptr) == 1
+    assert L.xfh_extract(ctx.h, img.ctypes.data, H, W, W, 0, 64, k.ctypes.data, d.ctypes.data, C.byref(nv), C.byref(mono)) == 1
+    capi.check(L.xfh_extract_collect(ctx.h, k.ctypes.data, d.ctypes.data, C.byref(nv), C.byref(mono)), ctx.h)
+    r0 = ctx.parse_records(want, 1)[0]
+    assert (nv.value, mono.value) == (r0[2], r0[3]) and np.array_equal(k, r0[0]) and np.array_equal(d, r0[1])
+    # reloading the weights reaches the lanes as well
+    ctx.load_weights(WT.pack_blob(WT.make_synthetic(77, 6.0)))
+    capi.check(L.xfh_extract_batch(ctx.h, hin.ptr, n, H, W, 0, 64, houts[0].ptr), ctx.h)
+    a = houts[0].array.copy()
+    assert not np.array_equal(a, want)
+    one = _ctx(nf, H, W, B=n); one.load_weights(WT.pack_blob(WT.make_synthetic(77, 6.0)))
+    capi.check(L.xfh_extract_batch(one.h, hin.ptr, n, H, W, 0, 64, houts[1].ptr), one.h)
+    assert np.array_equal(a, houts[1].array)
+    one.close()
+    ok, od, onv, omono = oracle_mod.Oracle(blob).extract(fr[0], nf, (0, 64))
+    assert (r0[2], r0[3]) == (onv, omono) and kp_set(r0[0]) == kp_set(ok)
+    assert L.xfh_extract_batch_wait(None) == 1 and L.xfh_host_alloc(None, 16) == 1
+    for h in houts + [hin]:
+        h.free()
+    ctx.close()
+
+
+def test_eval_bn_modes_through_the_pipeline_lanes(gpu_lib, weights_dense):
+    """the lanes of a ctx in an eval()-BatchNorm mode carry the parent's statistics slots (ctx_share_weights)"""
+    L = gpu_lib
+    from xfeatslam_amd.extractor import Context
+    blob = WT.pack_blob(WT.make_synthetic(1234, 6.0, with_bn=True))
+    H, W, nf, S, n = 64, 96, 128, 3, 11
+    fr = synth.frames(n, H, W, seed=5)
+    for mode in (1, 2):
+        one = Context(nfeatures=nf, max_height=H, max_width=W, max_batch=n, bn_mode=mode); one.load_weights(blob)
+        want = one.extract_batch(fr, (0, 0)); one.close()
+        ctx = Context(nfeatures=nf, max_height=H, max_width=W, max_batch=S, bn_mode=mode); ctx.load_weights(blob)
+        got = ctx.extract_batch(fr, (0, 0)); ctx.close()
+        for i, (a, b) in enumerate(zip(got, want)):
+            for x, y in zip(a, b):
+                assert np.array_equal(x, y), (mode, i)

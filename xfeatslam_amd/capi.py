@@ -56,6 +56,14 @@ SYMBOLS = [
     ("xfh_record_kps_offset", _sz, []),
     ("xfh_record_desc_offset", _sz, [_i]),
     ("xfh_extract_batch", _i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    ("xfh_extract_batch_submit", _i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    ("xfh_extract_batch_wait", _i, [_vp]),
+    ("xfh_extract_batch_drain", _i, [_vp]),
+    ("xfh_pipeline_lanes", _i, [_vp, _i]),
+    ("xfh_host_alloc", _i, [C.POINTER(_vp), _sz]),
+    ("xfh_host_free", _i, [_vp]),
+    ("xfh_host_register", _i, [_vp, _sz]),
+    ("xfh_host_unregister", _i, [_vp]),
     ("xfh_extract_batch_device", _i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     ("xfh_extract_batch_device_images", _i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     ("xfh_match_mnn", _i, [_vp, _vp, _i, _vp, _i, _f, _vp, _vp, _vp, _pi]),
@@ -101,6 +109,7 @@ SYMBOLS = [
     ("xfh_bench_mnn_gemm", _i, [_vp, _vp, _i, _vp, _i, _i, C.POINTER(C.c_double)]),
     ("xfh_bench_match_prepared", _i, [_vp, _vp, _i, _vp, _i, C.c_float, _vp, _vp, _vp, _vp, _i, C.POINTER(C.c_double)]),
     ("xfh_bench_match_raw", _i, [_vp, _vp, _i, _vp, _i, C.c_float, _vp, _vp, _vp, _vp, _i, C.POINTER(C.c_double)]),
+    ("xfh_bench_calib", _i, [_vp, _i, _sz, _i]),
     ("xfh_kernel_name", C.c_char_p, [_i]),
     ("xfh_debug_tensor", _i, [_vp, _i, _i, _vp, _sz, C.POINTER(_sz)]),
 ]
@@ -137,6 +146,29 @@ def check(status: int, ctx=None):
         if ctx is not None and status in (6, 11):
             detail = lib().xfh_last_hip_error(ctx).decode()
         raise XfhError(status, detail)
+
+
+class HostBuffer:
+    """pinned host allocation through the C ABI (xfh_host_alloc), viewed as a numpy array"""
+
+    def __init__(self, nbytes: int):
+        p = C.c_void_p()
+        check(lib().xfh_host_alloc(C.byref(p), nbytes))
+        self.ptr = p.value
+        self.nbytes = nbytes
+        self.array = np.ctypeslib.as_array((C.c_uint8 * nbytes).from_address(self.ptr))
+
+    def free(self):
+        if self.ptr:
+            self.array = None
+            lib().xfh_host_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 class DeviceBuffer:

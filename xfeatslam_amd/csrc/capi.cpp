@@ -130,8 +130,10 @@ int xfh_create(const xfh_config* cfg, xfh_ctx** out) {
     A(c->sel_n, sizeof(int) * B);
     const size_t rec = xfh_record_bytes(cfg->nfeatures);
     A(c->d_records, rec * B);
-    if (hipHostMalloc((void**)&c->h_records, rec * B, hipHostMallocDefault) != hipSuccess) return fail(XFH_ERR_OUT_OF_MEMORY);
-    if (hipHostMalloc((void**)&c->h_gray, (size_t)B * cfg->max_height * cfg->max_width, hipHostMallocDefault) != hipSuccess) return fail(XFH_ERR_OUT_OF_MEMORY);
+    // pinned slot 0 of the submit / collect ring: ONE frame and ONE record (the batch pipeline copies between the caller's
+    // buffers and HBM directly, pipeline.cpp)
+    if (hipHostMalloc((void**)&c->h_records, rec, hipHostMallocDefault) != hipSuccess) return fail(XFH_ERR_OUT_OF_MEMORY);
+    if (hipHostMalloc((void**)&c->h_gray, (size_t)cfg->max_height * cfg->max_width, hipHostMallocDefault) != hipSuccess) return fail(XFH_ERR_OUT_OF_MEMORY);
     c->s_hgray[0] = c->h_gray; c->s_dgray[0] = c->d_gray; c->s_hrec[0] = c->h_records;
     for (int k = 1; k < xfh_ctx::SLOTS; ++k) {
         A(c->s_dgray[k], (size_t)cfg->max_height * cfg->max_width);
@@ -162,6 +164,7 @@ int xfh_destroy(xfh_ctx* c) {
     if (!c) return XFH_OK;
     hipSetDevice(c->cfg.device);
     if (c->twin) { xfh_destroy(c->twin); c->twin = nullptr; }
+    pipe_destroy(c);
     xfh_comm_destroy(c);
     if (c->stream && c->stream != c->own_stream) hipStreamSynchronize(c->stream);     // work queued on a caller's stream
     if (c->own_stream) hipStreamSynchronize(c->own_stream);
@@ -169,7 +172,7 @@ int xfh_destroy(xfh_ctx* c) {
     auto F = [](void* p) { if (p) hipFree(p); };
     F(c->d_gray); F(c->X); F(c->pre_part); F(c->xstat);
     for (int i = 0; i < XFH_NUM_LAYERS; ++i) { F(c->raw[i]); F(c->part[i]); F(c->stat[i]); }
-    if (!c->is_twin) {                                   // a twin borrows the weights of its parent
+    if (!c->is_twin && !c->is_lane) {                    // a twin / pipeline lane borrows the weights of its parent
         for (int i = 0; i < XFH_NUM_LAYERS; ++i) { F(c->w.mfma[i]); F(c->w.alt[i]); F(c->w.alt2[i]); F(c->w.m16[i]); F(c->w.bn_bias[i]); }
         for (int i = 0; i < 3; ++i) F(c->w.direct[i]);
         F(c->w.fus2); F(c->w.fus2_bias); F(c->w.skip_w); F(c->w.skip_b); F(c->w.heat2_w); F(c->w.heat2_b); F(c->w.kp3_w); F(c->w.kp3_b);
@@ -244,7 +247,6 @@ static std::vector<float> pack_mfma(const float* w, int cout, int cin, int ks, i
     return o;
 }
 
-static void twin_share_weights(xfh_ctx* c);
 
 int xfh_load_weights(xfh_ctx* c, const void* blob, size_t nbytes) {
     if (!c || !blob) return XFH_ERR_INVALID_ARG;
@@ -330,8 +332,8 @@ int xfh_load_weights(xfh_ctx* c, const void* blob, size_t nbytes) {
     if (!blob_find(blob, nbytes, "keypoint_head.3.bias", &e) || e.dims[0] != 65) return XFH_ERR_BAD_WEIGHTS;
     if ((rc = upload(c, &c->w.kp3_b, std::vector<float>(e.p, e.p + 65))) != XFH_OK) return rc;
     c->w.loaded = true;
-    if (c->twin) { HIPCK(c, hipStreamSynchronize(c->twin->stream)); twin_share_weights(c); }
-    return XFH_OK;
+    if (c->twin) { HIPCK(c, hipStreamSynchronize(c->twin->stream)); if ((rc = ctx_share_weights(c, c->twin)) != XFH_OK) return rc; }
+    return pipe_reshare_weights(c);
 }
 
 int xfh_load_weights_file(xfh_ctx* c, const char* path) {
@@ -375,29 +377,19 @@ int xfh_extract_batch_device_images(xfh_ctx* c, const uint8_t* d_gray, int B, in
     return XFH_OK;
 }
 
-int xfh_extract_batch(xfh_ctx* c, const uint8_t* gray, int B, int H, int W, int lap0, int lap1, void* records_out) {
-    int rc = check_extract(c, gray, B, H, W);
-    if (rc != XFH_OK) return rc;
-    if (!records_out) return XFH_ERR_INVALID_ARG;
-    HIPCK(c, hipSetDevice(c->cfg.device));
-    const size_t nb = (size_t)B * H * W, rec = xfh_record_bytes(c->cfg.nfeatures);
-    memcpy(c->h_gray, gray, nb);
-    HIPCK(c, hipMemcpyAsync(c->d_gray, c->h_gray, nb, hipMemcpyHostToDevice, c->stream));
-    HIPCK(c, run_extract(c, c->d_gray, B, H, W, lap0, lap1, c->d_records));
-    HIPCK(c, hipMemcpyAsync(c->h_records, c->d_records, rec * B, hipMemcpyDeviceToHost, c->stream));
-    HIPCK(c, hipStreamSynchronize(c->stream));
-    memcpy(records_out, c->h_records, rec * B);
+// second single-frame ctx of the submission ring (ctx.h): same configuration with max_batch 1, the parent's weights
+}  // extern "C"
+int ctx_share_weights(xfh_ctx* c, xfh_ctx* t) {
+    t->w = c->w;
+    if (c->cfg.bn_mode != XFH_BN_BATCH_STATS && c->w.loaded) {
+        // eval() modes: the statistics slots of every frame of the child (the file's values, or the identity when folded)
+        const int nb = t->cfg.max_batch < c->cfg.max_batch ? t->cfg.max_batch : c->cfg.max_batch;
+        for (int i = 0; i < XFH_NUM_LAYERS; ++i)
+            HIPCK(c, hipMemcpy(t->stat[i], c->stat[i], sizeof(float) * 2 * XFH_LAYERS[i].cout * nb, hipMemcpyDeviceToDevice));
+    }
     return XFH_OK;
 }
-
-// second single-frame ctx of the submission ring (ctx.h): same configuration with max_batch 1, the parent's weights
-static void twin_share_weights(xfh_ctx* c) {
-    xfh_ctx* t = c->twin;
-    t->w = c->w;
-    if (c->cfg.bn_mode != XFH_BN_BATCH_STATS && c->w.loaded)
-        for (int i = 0; i < XFH_NUM_LAYERS; ++i)
-            hipMemcpy(t->stat[i], c->stat[i], sizeof(float) * 2 * XFH_LAYERS[i].cout, hipMemcpyDeviceToDevice);
-}
+extern "C" {
 static int twin_ready(xfh_ctx* c) {
     if (c->twin) return XFH_OK;
     xfh_config cfg = c->cfg;
@@ -407,8 +399,7 @@ static int twin_ready(xfh_ctx* c) {
     if (rc != XFH_OK) return rc;
     t->is_twin = true;
     c->twin = t;
-    twin_share_weights(c);
-    return XFH_OK;
+    return ctx_share_weights(c, t);
 }
 
 // xfh_extract = submit + collect.  The split form lets the caller overlap its own work (the other camera of a stereo
@@ -452,7 +443,10 @@ int xfh_extract_collect(xfh_ctx* c, xfh_keypoint* kps, float* desc, int* n_valid
     const xfh_keypoint* rk = (const xfh_keypoint*)(r + xfh_record_kps_offset());
     const float* rd = (const float*)(r + xfh_record_desc_offset(nf));
     int front = h->mono_index, back = h->n_valid - h->mono_index;
-    if (front < 0 || back < 0 || front + back > nf) { front = nf; back = 0; }          // never trust a torn header: copy everything
+    if (front < 0 || back < 0 || front + back > nf) {                                   // a torn header: the padding rows were never written, so there is nothing safe to copy
+        c->hip_err = "xfh_extract_collect: inconsistent record header (n_valid / mono_index)";
+        return XFH_ERR_HIP;
+    }
     memcpy(kps, rk, (size_t)front * sizeof(xfh_keypoint));
     memcpy(desc, rd, (size_t)front * 256);
     const int pad = nf - front - back;
@@ -473,6 +467,7 @@ int xfh_extract_collect(xfh_ctx* c, xfh_keypoint* kps, float* desc, int* n_valid
 int xfh_extract(xfh_ctx* c, const uint8_t* gray, int H, int W, int stride, int lap0, int lap1,
                 xfh_keypoint* kps, float* desc, int* n_valid, int* mono_index) {
     if (!kps || !desc) return XFH_ERR_INVALID_ARG;
+    if (c && c->s_count != 0) return XFH_ERR_INVALID_ARG;      // a submission is outstanding: collect would hand back THAT frame, not this one
     const int rc = xfh_extract_submit(c, gray, H, W, stride, lap0, lap1);
     if (rc != XFH_OK) return rc;
     return xfh_extract_collect(c, kps, desc, n_valid, mono_index);
@@ -701,6 +696,7 @@ int xfh_synchronize(xfh_ctx* c) {
     if (!c) return XFH_ERR_INVALID_ARG;
     HIPCK(c, hipStreamSynchronize(c->stream));
     if (c->twin) HIPCK(c, hipStreamSynchronize(c->twin->stream));
+    for (int l = 1; l < c->pipe.nlanes; ++l) HIPCK(c, hipStreamSynchronize(c->pipe.lane[l].ctx->stream));
     return XFH_OK;
 }
 int xfh_set_stream(xfh_ctx* c, void* s) {

@@ -57,6 +57,7 @@ struct XfhComm {
     unsigned long long* h_sizes = nullptr;         // pinned: compact sizes of all ranks
     unsigned long long* d_sizes = nullptr;         // [world] + [1] own
     uint8_t* d_pack = nullptr; size_t cap_pack = 0;
+    int* d_prefix = nullptr; int cap_prefix = 0;   // [frames + 1] rows before each frame of a compact shard; grown on demand (several ctx may feed one gather)
 };
 
 #define HIPCK(c, x) do { hipError_t _e = (x); if (_e != hipSuccess) { (c)->hip_err = std::string(#x) + ": " + hipGetErrorString(_e); return XFH_ERR_HIP; } } while (0)
@@ -120,6 +121,7 @@ int xfh_comm_destroy(xfh_ctx* c) {
     if (m->h_sizes) hipHostFree(m->h_sizes);
     if (m->d_sizes) hipFree(m->d_sizes);
     if (m->d_pack) hipFree(m->d_pack);
+    if (m->d_prefix) hipFree(m->d_prefix);
     if (m->stream) hipStreamDestroy(m->stream);
     delete m;
     c->comm = nullptr;
@@ -139,7 +141,7 @@ int xfh_comm_create(xfh_ctx* c, const void* unique_id, int rank, int world) {
     if (hipEventCreateWithFlags(&m->ev_ready, hipEventDisableTiming) != hipSuccess) return bail(XFH_ERR_HIP);
     for (int g = 0; g < 2; ++g) if (hipEventCreateWithFlags(&m->ev_done[g], hipEventDisableTiming) != hipSuccess) return bail(XFH_ERR_HIP);
     if (hipHostMalloc((void**)&m->h_sizes, sizeof(unsigned long long) * (world + 1), hipHostMallocDefault) != hipSuccess) return bail(XFH_ERR_OUT_OF_MEMORY);
-    if (hipMalloc((void**)&m->d_sizes, sizeof(unsigned long long) * (world + 1) + sizeof(int) * (c->cfg.max_batch + 1)) != hipSuccess) return bail(XFH_ERR_OUT_OF_MEMORY);
+    if (hipMalloc((void**)&m->d_sizes, sizeof(unsigned long long) * (world + 1)) != hipSuccess) return bail(XFH_ERR_OUT_OF_MEMORY);
     ncclUniqueId id; memcpy(&id, unique_id, sizeof id);
     ncclResult_t r = R->CommInitRank(&m->comm, world, id, rank);
     if (r != 0) { c->hip_err = std::string("ncclCommInitRank: ") + R->GetErrorString(r); return bail(XFH_ERR_COMM); }
@@ -203,9 +205,10 @@ size_t xfh_compact_bytes_max(int nfeatures, int B) {
 }
 
 int xfh_gather_compact_root(xfh_ctx* c, const void* d_records, int B, void* d_all, size_t* shard_bytes, int root, int gen) {
-    if (!c || !c->comm || !d_records || B < 1 || B > c->cfg.max_batch || gen < 0 || gen > 1) return XFH_ERR_INVALID_ARG;
+    if (!c || !c->comm || !d_records || B < 1 || gen < 0 || gen > 1) return XFH_ERR_INVALID_ARG;
     XfhComm* m = c->comm;
     if (root < 0 || root >= m->world || (m->rank == root && (!d_all || !shard_bytes))) return XFH_ERR_INVALID_ARG;
+    HIPCK(c, hipSetDevice(c->cfg.device));
     const int nf = c->cfg.nfeatures;
     const size_t cap = xfh_compact_bytes_max(nf, B), rec = xfh_record_bytes(nf);
     if (m->cap_pack < cap) {
@@ -213,11 +216,16 @@ int xfh_gather_compact_root(xfh_ctx* c, const void* d_records, int B, void* d_al
         HIPCK(c, hipMalloc((void**)&m->d_pack, cap));
         m->cap_pack = cap;
     }
+    if (m->cap_prefix < B + 1) {                      // B is the caller's frame count (bench.py: the sub-batches of several ctx), not this ctx' max_batch
+        if (m->d_prefix) { HIPCK(c, hipStreamSynchronize(m->stream)); hipFree(m->d_prefix); m->d_prefix = nullptr; m->cap_prefix = 0; }
+        HIPCK(c, hipMalloc((void**)&m->d_prefix, sizeof(int) * (size_t)(B + 1)));
+        m->cap_prefix = B + 1;
+    }
     int rc = comm_begin(c, gen);
     if (rc != XFH_OK) return rc;
     Rccl* R = rccl();
     unsigned long long* d_own = m->d_sizes + m->world;
-    int* d_prefix = (int*)(m->d_sizes + m->world + 1);
+    int* d_prefix = m->d_prefix;
     hipLaunchKernelGGL(k_pack_offsets, dim3(1), dim3(64), 0, m->stream, (const uint8_t*)d_records, rec, B, nf, d_own, d_prefix);
     hipLaunchKernelGGL(k_pack_rows, dim3(64, B), dim3(256), 0, m->stream, (const uint8_t*)d_records, rec, B, nf, xfh_record_kps_offset(), xfh_record_desc_offset(nf),
                        (const int*)d_prefix, m->d_pack);

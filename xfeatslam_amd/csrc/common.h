@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stddef.h>
 #include "../../include/xfeat_hip.h"
+#include "../../include/xfeat_hip_bench.h"
 
 #define XFH_NUM_LAYERS 23
 #define XFH_DESC_DIM 64

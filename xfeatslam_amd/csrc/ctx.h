@@ -22,6 +22,37 @@ struct DevWeights {
 };
 
 struct XfhComm;
+struct xfh_ctx;
+
+// xfh_extract_batch / _submit / _wait (host-visible frames in, host-visible records out).  A call of B frames is
+// cut into sub-batches of cfg.max_batch frames that rotate over up to XFH_PIPE_MAX_LANES lanes.  A lane = one ctx (lane 0: the
+// ctx itself, the others: children with their own activations and streams that borrow its weights) + two generations of
+// device-side frame and record buffers + an H2D and a D2H stream, so that the upload of sub-batch j + L, the kernels of
+// sub-batch j and the download of sub-batch j - L overlap on one lane, and the kernels of L sub-batches share the CUs.
+#define XFH_PIPE_MAX_LANES 8
+struct PipeLane {
+    xfh_ctx* ctx = nullptr;
+    uint8_t* d_gray[2] = {nullptr, nullptr};    // [0] of lane ctx: its own d_gray / d_records; [1] allocated when the lane is built
+    uint8_t* d_rec[2] = {nullptr, nullptr};
+    hipStream_t h2d = nullptr, d2h = nullptr;
+    hipEvent_t ev_h2d[2] = {nullptr, nullptr};   // upload into d_gray[g] finished
+    hipEvent_t ev_k[2] = {nullptr, nullptr};     // kernels that read d_gray[g] / wrote d_rec[g] finished
+    hipEvent_t ev_d2h[2] = {nullptr, nullptr};   // download of d_rec[g] finished
+    unsigned long long uses = 0;                 // sub-batches this lane has run: generation = uses & 1
+    bool busy = false;                           // something was queued on d2h since the last wait
+};
+#define XFH_PIPE_MAX_BATCHES 8                   // xfh_extract_batch_submit calls outstanding (include/xfeat_hip.h: XFH_MAX_BATCHES_INFLIGHT)
+struct Pipe {
+    int nlanes = 0, max_lanes = 4;
+    PipeLane lane[XFH_PIPE_MAX_LANES];
+    unsigned long long next = 0;                 // sub-batches submitted so far
+    // completion of whole submits, oldest first: batch_ev[k] is recorded on `join` after join has waited for the last download of
+    // every lane the submit touched
+    hipStream_t join = nullptr;
+    hipEvent_t batch_ev[XFH_PIPE_MAX_BATCHES] = {};
+    int b_head = 0, b_count = 0;
+};
+
 struct xfh_ctx {
     xfh_config cfg;
     XfhComm* comm = nullptr;        // RCCL communicator + communication stream (comm.cpp), created by xfh_comm_create
@@ -58,9 +89,9 @@ struct xfh_ctx {
     int* slot_src = nullptr;                    // [B][nfeatures]
     u64* sel_key = nullptr;                     // [B][nfeatures]
     int* sel_n = nullptr;                       // [B]
-    uint8_t* d_records = nullptr;               // [B][record_bytes] for the host API (xfh_extract_batch)
-    uint8_t* h_records = nullptr;               // pinned mirror, [B][record_bytes]
-    uint8_t* h_gray = nullptr;                  // pinned, [B] frames
+    uint8_t* d_records = nullptr;               // [B][record_bytes]: record buffer 0 of the batch pipeline (xfh_extract_batch, pipeline.cpp)
+    uint8_t* h_records = nullptr;               // pinned, ONE record: slot 0 of the submit / collect ring
+    uint8_t* h_gray = nullptr;                  // pinned, ONE frame: slot 0 of the submit / collect ring
 
     // xfh_extract_submit / _collect: a ring of SLOTS single-frame submissions, collected in order.  Slot buffers: pinned
     // image, device image, and a pinned record that the kernels write DIRECTLY (host memory is device visible: no D2H
@@ -74,9 +105,17 @@ struct xfh_ctx {
     bool is_twin = false;                       // a twin does not own its weights
     int s_head = 0, s_count = 0;                // oldest outstanding slot, number outstanding
 
+    Pipe pipe;                                  // xfh_extract_batch: lanes of the host-visible batch pipeline (pipeline.cpp)
+    bool is_lane = false;                       // a lane ctx borrows the weights of its parent, like a twin
+
     MatchWs mws;
     KTimer timer;
 };
+
+// helpers shared by capi.cpp / pipeline.cpp
+int ctx_share_weights(xfh_ctx* parent, xfh_ctx* child);      // child borrows the parent's packed weights (and its eval()-mode statistics)
+void pipe_destroy(xfh_ctx* c);
+int pipe_reshare_weights(xfh_ctx* c);
 
 // helpers implemented in capi.cpp
 // kernel timing: when the timer is armed for (kernel_id, layer) the launch goes through

@@ -11,8 +11,8 @@ One process per GPU (`python -m torch.distributed.run --nproc-per-node N ...` on
 and sets RANK / WORLD_SIZE / MASTER_*).  On the GPU the collective is the C ABI's (`xfh_comm_create`,
 `xfh_allgather_records`, `xfh_gather_records_root`, `xfh_gather_compact_root`: librccl called directly by
 libxfeat_hip.so, class `Comm` below); the 128-byte RCCL unique id travels from rank 0 to the others over a
-plain TCP socket (`exchange_unique_id`), so no torch is needed in the data path.  The torch/gloo functions
-further down serve the CPU tests of the shard / gather / unshard logic.
+plain TCP socket (`exchange_unique_id`), so no torch is needed in the data path.  `ShardPlan` is the index arithmetic of the
+partitioning (frame i -> rank i mod R and back), shared by the RCCL path and the CPU tests (which move the bytes over gloo).
 """
 from __future__ import annotations
 
@@ -138,46 +138,28 @@ class Comm:
         self.capi.lib().xfh_comm_destroy(self.ctx.h)
 
 
-def init_process_group(device_is_gpu: bool):
-    import torch.distributed as dist
-    if dist.is_initialized():
-        return dist
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29517")
-    rank, _, world = env_world()
-    dist.init_process_group("nccl" if device_is_gpu else "gloo", rank=rank, world_size=world)
-    return dist
+class ShardPlan:
+    """Who extracts which frame of a global batch, and where its record lands after the gather (BASELINE.json
+    configs[3]: "Batch-8 1280x720 frames sharded 1/GPU across 8 MI355X, RCCL all-gather of kpts+desc").
 
+    frame i -> rank i mod world, slot i // world of that rank; every rank runs `slots` = ceil(n / world) slots so that the
+    exchange is fixed size, and a rank whose last slot has no frame repeats its last one (dropped again by `global_order`).
+    Pure index arithmetic: the same object drives the RCCL path (`Comm`, bench.py, tests/test_gpu_comm_world2.py) and the CPU
+    world-2 test over gloo (tests/test_dist_gloo.py)."""
 
-def all_gather_records(local):
-    """local: uint8 tensor [slots * record_bytes] (device tensor -> RCCL, CPU tensor -> gloo).
-    Returns a [world, slots * record_bytes] tensor on every rank."""
-    import torch
-    import torch.distributed as dist
-    world = dist.get_world_size()
-    out = torch.empty((world, local.numel()), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out.view(-1), local.contiguous().view(-1))
-    return out
+    def __init__(self, n_frames: int, rank: int, world: int):
+        assert n_frames >= 1 and 0 <= rank < world
+        self.n, self.rank, self.world = n_frames, rank, world
+        self.slots = frames_per_rank(n_frames, world)
+        mine = shard_indices(n_frames, rank, world)
+        # a rank without any frame of its own (n < world) still runs its slot: on frame 0, dropped afterwards
+        self.local = mine + [mine[-1] if mine else 0] * (self.slots - len(mine))
 
+    def global_order(self):
+        """[(rank, slot)] of frame 0, 1, ... n-1 inside a gathered [world][slots] array of records"""
+        return [(i % self.world, i // self.world) for i in range(self.n)]
 
-class ShardedFrontEnd:
-    """extract_fn(frames_u8[B,H,W]) -> uint8 tensor [B * record_bytes] on this rank's device."""
-
-    def __init__(self, extract_fn, record_bytes: int):
-        self.extract_fn = extract_fn
-        self.record_bytes = record_bytes
-
-    def run(self, frames):
-        """frames: the full batch [N,H,W] (every rank sees it, as every rank could read the
-        sequence from disk).  Returns N record byte-blobs in frame order (valid on every rank)."""
-        import torch
-        import torch.distributed as dist
-        rank, world = dist.get_rank(), dist.get_world_size()
-        n = len(frames)
-        slots = frames_per_rank(n, world)
-        mine = shard_indices(n, rank, world)
-        idx = mine + [mine[-1] if mine else 0] * (slots - len(mine))      # pad the last round
-        local = self.extract_fn(frames[idx])
-        gathered = all_gather_records(local)
-        per_rank = [[gathered[r, j * self.record_bytes:(j + 1) * self.record_bytes] for j in range(slots)] for r in range(world)]
-        return unshard(per_rank, n, world)
+    def unshard_bytes(self, gathered, record_bytes: int):
+        """gathered: u8 array of world * slots * record_bytes (rank-major, the layout of xfh_allgather_records /
+        xfh_gather_records_root) -> list of n record views in global frame order"""
+        return [gathered[(r * self.slots + j) * record_bytes:(r * self.slots + j + 1) * record_bytes] for r, j in self.global_order()]
