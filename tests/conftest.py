@@ -61,3 +61,13 @@ def gpu_lib():
     L = capi.lib()
     assert L.xfh_device_count() > 0, "no HIP device visible: gpu tests need an MI355X"
     return L
+
+
+def records_equal(ctx, raw_a, raw_b, n):
+    """two byte blobs of n records hold the same records: header fields, keypoints and descriptors (the alignment gaps between
+    the sections of a record are never written by the kernels, so whole-blob comparison would compare uninitialised bytes)"""
+    a = ctx.parse_records(np.ascontiguousarray(raw_a).reshape(-1), n); b = ctx.parse_records(np.ascontiguousarray(raw_b).reshape(-1), n)
+    for i, (x, y) in enumerate(zip(a, b)):
+        if x[2:] != y[2:] or not np.array_equal(x[0], y[0]) or not np.array_equal(x[1], y[1]):
+            return False
+    return True

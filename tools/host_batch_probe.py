@@ -16,8 +16,10 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 blob = WT.pack_blob(WT.make_synthetic(1234, 6.0))
 frames = synth.frames(N, H, W, seed=42)
 hin = capi.HostBuffer(frames.nbytes); hin.array[:] = frames.reshape(-1)
-for S, lanes in ((64, 4), (32, 4), (32, 8), (64, 2), (128, 2), (16, 8)):
-    ctx = Context(nfeatures=NF, max_height=H, max_width=W, max_batch=S)
+SHAPES = [tuple(int(v) for v in t.split("x")) for t in (sys.argv[2] if len(sys.argv) > 2 else "64x4,32x4,32x8,64x2,128x2,16x8").split(",")]
+print("frames per step", N, "serial-branch", os.environ.get("XFH_PROBE_SERIAL", "0"), "GPU_MAX_HW_QUEUES", os.environ.get("GPU_MAX_HW_QUEUES", "default"), flush=True)
+for S, lanes in SHAPES:
+    ctx = Context(nfeatures=NF, max_height=H, max_width=W, max_batch=S, flags=capi.FLAG_SERIAL_BRANCH if os.environ.get("XFH_PROBE_SERIAL") else 0)
     ctx.load_weights(blob)
     assert L.xfh_pipeline_lanes(ctx.h, lanes) == 0
     rb = ctx.rec_bytes

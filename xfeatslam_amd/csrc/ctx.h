@@ -24,33 +24,25 @@ struct DevWeights {
 struct XfhComm;
 struct xfh_ctx;
 
-// xfh_extract_batch / _submit / _wait (host-visible frames in, host-visible records out).  A call of B frames is
-// cut into sub-batches of cfg.max_batch frames that rotate over up to XFH_PIPE_MAX_LANES lanes.  A lane = one ctx (lane 0: the
-// ctx itself, the others: children with their own activations and streams that borrow its weights) + two generations of
-// device-side frame and record buffers + an H2D and a D2H stream, so that the upload of sub-batch j + L, the kernels of
-// sub-batch j and the download of sub-batch j - L overlap on one lane, and the kernels of L sub-batches share the CUs.
+// xfh_extract_batch / _submit / _wait (host-visible frames in, host-visible records out; pipeline.cpp).  A call of
+// B frames is cut into sub-batches of cfg.max_batch frames that rotate over up to XFH_PIPE_MAX_LANES lanes.  A lane = one ctx
+// (lane 0: the ctx itself, the others: children with their own activations and streams that borrow its weights) whose ONE
+// stream carries, in order, the H2D copy of a sub-batch, its kernels and the D2H copy of its records; the lanes overlap
+// each other (one lane's copies run on the SDMA engines while other lanes' kernels own the CUs).  No cross-stream event
+// anywhere: pipeline.cpp explains why.
 #define XFH_PIPE_MAX_LANES 8
+#define XFH_PIPE_MAX_BATCHES 8                   // xfh_extract_batch_submit calls outstanding (include/xfeat_hip.h: XFH_MAX_BATCHES_INFLIGHT)
 struct PipeLane {
     xfh_ctx* ctx = nullptr;
-    uint8_t* d_gray[2] = {nullptr, nullptr};    // [0] of lane ctx: its own d_gray / d_records; [1] allocated when the lane is built
-    uint8_t* d_rec[2] = {nullptr, nullptr};
-    hipStream_t h2d = nullptr, d2h = nullptr;
-    hipEvent_t ev_h2d[2] = {nullptr, nullptr};   // upload into d_gray[g] finished
-    hipEvent_t ev_k[2] = {nullptr, nullptr};     // kernels that read d_gray[g] / wrote d_rec[g] finished
-    hipEvent_t ev_d2h[2] = {nullptr, nullptr};   // download of d_rec[g] finished
-    unsigned long long uses = 0;                 // sub-batches this lane has run: generation = uses & 1
-    bool busy = false;                           // something was queued on d2h since the last wait
+    hipEvent_t done[XFH_PIPE_MAX_BATCHES] = {};  // done[k]: this lane's last download of outstanding batch slot k has finished
+    bool busy = false;                           // something was queued since the last drain
 };
-#define XFH_PIPE_MAX_BATCHES 8                   // xfh_extract_batch_submit calls outstanding (include/xfeat_hip.h: XFH_MAX_BATCHES_INFLIGHT)
 struct Pipe {
     int nlanes = 0, max_lanes = 4;
     PipeLane lane[XFH_PIPE_MAX_LANES];
     unsigned long long next = 0;                 // sub-batches submitted so far
-    // completion of whole submits, oldest first: batch_ev[k] is recorded on `join` after join has waited for the last download of
-    // every lane the submit touched
-    hipStream_t join = nullptr;
-    hipEvent_t batch_ev[XFH_PIPE_MAX_BATCHES] = {};
-    int b_head = 0, b_count = 0;
+    unsigned lanes_of[XFH_PIPE_MAX_BATCHES] = {};   // bit l: lane l carries a part of outstanding batch slot k
+    int b_head = 0, b_count = 0;                 // ring of outstanding submits, oldest first
 };
 
 struct xfh_ctx {

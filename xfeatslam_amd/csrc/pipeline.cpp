@@ -8,12 +8,23 @@
 //   xfh_extract_batch          submit + drain
 //
 // A call is cut into sub-batches of cfg.max_batch frames which rotate over the lanes of the ctx (ctx.h: PipeLane).  Per
-// sub-batch: one H2D copy on the lane's upload stream (SDMA), the kernels on the lane ctx' streams, one D2H copy of the
-// padded records on the lane's download stream (SDMA); two generations of device buffers per lane, events only, no host
-// synchronisation before xfh_extract_batch_wait.  PCIe carries 0.31 MB in + 1.16 MB out per VGA frame at nfeatures 4096.
+// sub-batch, IN ORDER ON THE LANE'S ONE STREAM: the H2D copy of its frames (SDMA), the kernels, the D2H copy of the padded
+// records (SDMA).  Overlap comes from the lanes: while one lane's stream sits in a copy, the kernels of the others own the
+// CUs; PCIe carries 0.31 MB in + 1.16 MB out per VGA frame at nfeatures 4096.  The host never waits before
+// xfh_extract_batch_wait, and there is NO cross-stream event:
+//
+// the classic three-stream form (upload stream | kernel stream | download stream, two buffer generations, events between them)
+// was built first and traced (rocprofv3 --kernel-trace --memory-copy-trace, profiles/r03_host_pipeline.md): the kernels of
+// sub-batch t+1 did not start before the DOWNLOAD of sub-batch t had finished although nothing orders them.  The runtime
+// multiplexes all HIP streams of a process onto four hardware queues; an event wait is a barrier packet in the waiting stream's
+// queue, and a barrier packet that waits for a millisecond-long SDMA copy stalls every other stream that happens to share
+// that queue -- 15-16 k frames/s whatever the shape, the same as doing the three stages one after the other.  (Kernels that
+// read / write the caller's pinned memory themselves, no copy commands at all, were measured too: 15-16 k, k_desc then stalls on
+// PCIe writes while it occupies the CUs.)  With in-order lanes a copy can only ever delay its own lane.
 // The caller's buffers should be pinned (xfh_host_alloc / xfh_host_register): with pageable memory the HIP runtime stages
-// every copy through its own bounce buffers and the copies serialise against the kernels -- still correct, much slower.
+// every copy through its own bounce buffers and blocks the calling thread -- still correct, much slower.
 #include "ctx.h"
+#include <stdlib.h>
 #include <string.h>
 
 #define HIPCK(c, x) do { hipError_t _e = (x); if (_e != hipSuccess) { (c)->hip_err = std::string(#x) + ": " + hipGetErrorString(_e); return XFH_ERR_HIP; } } while (0)
@@ -22,24 +33,12 @@ void pipe_destroy(xfh_ctx* c) {
     Pipe& P = c->pipe;
     for (int l = 0; l < P.nlanes; ++l) {
         PipeLane& L = P.lane[l];
-        if (L.h2d) hipStreamSynchronize(L.h2d);
-        if (L.d2h) hipStreamSynchronize(L.d2h);
         if (L.ctx && L.ctx != c) xfh_destroy(L.ctx);          // synchronises the lane's own streams first
         else if (c->stream) hipStreamSynchronize(c->stream);
-        if (L.d_gray[1]) hipFree(L.d_gray[1]);
-        if (L.d_rec[1]) hipFree(L.d_rec[1]);
-        for (int g = 0; g < 2; ++g) {
-            if (L.ev_h2d[g]) hipEventDestroy(L.ev_h2d[g]);
-            if (L.ev_k[g]) hipEventDestroy(L.ev_k[g]);
-            if (L.ev_d2h[g]) hipEventDestroy(L.ev_d2h[g]);
-        }
-        if (L.h2d) hipStreamDestroy(L.h2d);
-        if (L.d2h) hipStreamDestroy(L.d2h);
+        for (int k = 0; k < XFH_PIPE_MAX_BATCHES; ++k) if (L.done[k]) hipEventDestroy(L.done[k]);
         L = PipeLane();
     }
     P.nlanes = 0;
-    if (P.join) { hipStreamSynchronize(P.join); hipStreamDestroy(P.join); P.join = nullptr; }
-    for (int k = 0; k < XFH_PIPE_MAX_BATCHES; ++k) if (P.batch_ev[k]) { hipEventDestroy(P.batch_ev[k]); P.batch_ev[k] = nullptr; }
     P.b_head = P.b_count = 0;
 }
 
@@ -56,18 +55,16 @@ int pipe_reshare_weights(xfh_ctx* c) {
 // lanes [0, want) exist afterwards
 static int pipe_ready(xfh_ctx* c, int want) {
     Pipe& P = c->pipe;
-    const size_t rec = xfh_record_bytes(c->cfg.nfeatures), gb = (size_t)c->cfg.max_batch * c->cfg.max_height * c->cfg.max_width;
-    if (!P.join) {
-        HIPCK(c, hipStreamCreateWithFlags(&P.join, hipStreamNonBlocking));
-        for (int k = 0; k < XFH_PIPE_MAX_BATCHES; ++k) HIPCK(c, hipEventCreateWithFlags(&P.batch_ev[k], hipEventDisableTiming));
-    }
     while (P.nlanes < want) {
         PipeLane& L = P.lane[P.nlanes];
         L = PipeLane();
         if (P.nlanes == 0) L.ctx = c;
         else {
             xfh_ctx* t = nullptr;
-            const int rc = xfh_create(&c->cfg, &t);
+            xfh_config cfg = c->cfg;
+            cfg.flags |= XFH_FLAG_SERIAL_BRANCH;       // one stream per lane (the keypoint branch inline): the lanes are the concurrency here; measured
+                                                        // 25.2-25.7 k frames/s against 18-23 k with a second stream per lane (profiles/r03_host_pipeline.md)
+            const int rc = xfh_create(&cfg, &t);
             if (rc != XFH_OK) return rc;
             t->is_lane = true;
             L.ctx = t;
@@ -75,15 +72,7 @@ static int pipe_ready(xfh_ctx* c, int want) {
             if (rs != XFH_OK) { xfh_destroy(t); L = PipeLane(); return rs; }
         }
         ++P.nlanes;                                   // from here on pipe_destroy cleans the lane up
-        L.d_gray[0] = L.ctx->d_gray; L.d_rec[0] = L.ctx->d_records;
-        if (hipMalloc((void**)&L.d_gray[1], gb) != hipSuccess || hipMalloc((void**)&L.d_rec[1], rec * c->cfg.max_batch) != hipSuccess) return XFH_ERR_OUT_OF_MEMORY;
-        HIPCK(c, hipStreamCreateWithFlags(&L.h2d, hipStreamNonBlocking));
-        HIPCK(c, hipStreamCreateWithFlags(&L.d2h, hipStreamNonBlocking));
-        for (int g = 0; g < 2; ++g) {
-            HIPCK(c, hipEventCreateWithFlags(&L.ev_h2d[g], hipEventDisableTiming));
-            HIPCK(c, hipEventCreateWithFlags(&L.ev_k[g], hipEventDisableTiming));
-            HIPCK(c, hipEventCreateWithFlags(&L.ev_d2h[g], hipEventDisableTiming));
-        }
+        for (int k = 0; k < XFH_PIPE_MAX_BATCHES; ++k) HIPCK(c, hipEventCreateWithFlags(&L.done[k], hipEventDisableTiming));
     }
     return XFH_OK;
 }
@@ -121,38 +110,29 @@ int xfh_extract_batch_submit(xfh_ctx* c, const uint8_t* gray, int B, int H, int 
     int rc = pipe_ready(c, nl);
     if (rc != XFH_OK) return rc;
     const size_t rec = xfh_record_bytes(c->cfg.nfeatures), fb = (size_t)H * W;
-    int last_gen[XFH_PIPE_MAX_LANES];
-    for (int l = 0; l < XFH_PIPE_MAX_LANES; ++l) last_gen[l] = -1;
+    const int slot = (P.b_head + P.b_count) % XFH_PIPE_MAX_BATCHES;
+    unsigned used = 0;
     for (int j = 0; j < nsub; ++j) {
         const int n = B - j * S < S ? B - j * S : S;
         const int li = nl == 1 ? 0 : (int)(P.next % (unsigned)nl);             // a call of one sub-batch always runs on the ctx itself
-        PipeLane& L = P.lane[li];
         ++P.next;
-        const int g = (int)(L.uses & 1);
-        ++L.uses;
+        PipeLane& L = P.lane[li];
         xfh_ctx* lc = L.ctx;
-        // upload: d_gray[g] is free once the kernels of its previous use have finished
-        HIPCK(c, hipStreamWaitEvent(L.h2d, L.ev_k[g], 0));
-        HIPCK(c, hipMemcpyAsync(L.d_gray[g], gray + (size_t)j * S * fb, (size_t)n * fb, hipMemcpyHostToDevice, L.h2d));
-        HIPCK(c, hipEventRecord(L.ev_h2d[g], L.h2d));
-        // kernels: after the upload, and after the download that last read d_rec[g]
-        HIPCK(c, hipStreamWaitEvent(lc->stream, L.ev_h2d[g], 0));
-        HIPCK(c, hipStreamWaitEvent(lc->stream, L.ev_d2h[g], 0));
+        L.busy = true;
+        HIPCK(c, hipMemcpyAsync(lc->d_gray, gray + (size_t)j * S * fb, (size_t)n * fb, hipMemcpyHostToDevice, lc->stream));
         {
-            const hipError_t e = run_extract(lc, L.d_gray[g], n, H, W, lap0, lap1, L.d_rec[g]);
+            const int flags = lc->cfg.flags;
+            if (nl > 1) lc->cfg.flags |= XFH_FLAG_SERIAL_BRANCH;            // lane 0 is the caller's ctx: same rule while it works as a lane
+            const hipError_t e = run_extract(lc, lc->d_gray, n, H, W, lap0, lap1, lc->d_records);
+            lc->cfg.flags = flags;
             if (e != hipSuccess) { c->hip_err = std::string("run_extract: ") + hipGetErrorString(e); return XFH_ERR_HIP; }
         }
-        HIPCK(c, hipEventRecord(L.ev_k[g], lc->stream));
-        // download of the padded records
-        HIPCK(c, hipStreamWaitEvent(L.d2h, L.ev_k[g], 0));
-        HIPCK(c, hipMemcpyAsync((uint8_t*)records_out + (size_t)j * S * rec, L.d_rec[g], (size_t)n * rec, hipMemcpyDeviceToHost, L.d2h));
-        HIPCK(c, hipEventRecord(L.ev_d2h[g], L.d2h));
-        L.busy = true;
-        last_gen[li] = g;
+        HIPCK(c, hipMemcpyAsync((uint8_t*)records_out + (size_t)j * S * rec, lc->d_records, (size_t)n * rec, hipMemcpyDeviceToHost, lc->stream));
+        used |= 1u << li;
     }
-    // the batch is complete when the last download of every lane it touched is (downloads of one lane finish in order)
-    for (int l = 0; l < nl; ++l) if (last_gen[l] >= 0) HIPCK(c, hipStreamWaitEvent(P.join, P.lane[l].ev_d2h[last_gen[l]], 0));
-    HIPCK(c, hipEventRecord(P.batch_ev[(P.b_head + P.b_count) % XFH_PIPE_MAX_BATCHES], P.join));
+    // the batch is complete when the last download of every lane it touched is: one event per lane, waited for by the HOST
+    for (int l = 0; l < nl; ++l) if (used >> l & 1) HIPCK(c, hipEventRecord(P.lane[l].done[slot], P.lane[l].ctx->stream));
+    P.lanes_of[slot] = used;
     ++P.b_count;
     return XFH_OK;
 }
@@ -162,7 +142,7 @@ int xfh_extract_batch_wait(xfh_ctx* c) {
     Pipe& P = c->pipe;
     if (P.b_count <= 0) return XFH_ERR_INVALID_ARG;             // nothing outstanding
     HIPCK(c, hipSetDevice(c->cfg.device));
-    HIPCK(c, hipEventSynchronize(P.batch_ev[P.b_head]));
+    for (int l = 0; l < P.nlanes; ++l) if (P.lanes_of[P.b_head] >> l & 1) HIPCK(c, hipEventSynchronize(P.lane[l].done[P.b_head]));
     P.b_head = (P.b_head + 1) % XFH_PIPE_MAX_BATCHES; --P.b_count;
     return XFH_OK;
 }
@@ -173,10 +153,9 @@ int xfh_extract_batch_drain(xfh_ctx* c) {
     for (int l = 0; l < c->pipe.nlanes; ++l) {
         PipeLane& L = c->pipe.lane[l];
         if (!L.busy) continue;
-        HIPCK(c, hipStreamSynchronize(L.d2h));                  // the download is the last command of every sub-batch
+        HIPCK(c, hipStreamSynchronize(L.ctx->stream));          // the download is the last command of every sub-batch
         L.busy = false;
     }
-    if (c->pipe.join) HIPCK(c, hipStreamSynchronize(c->pipe.join));
     c->pipe.b_head = c->pipe.b_count = 0;
     return XFH_OK;
 }
