@@ -10,19 +10,27 @@ script imports no torch: device memory, streams and the RCCL exchange all go thr
 
 A "step" is one pass of the extraction hot path (XFextractor::operator(), reference src/XFextractor.cc:250-356) over
 one batch of B distinct synthetic VGA frames per GPU, with the frames already resident in HBM and the 4096-row
-(keypoints, descriptors) records left in HBM; with N > 1 the step also moves the records with RCCL (frame i -> GPU
-i mod N; xfh_allgather_records by default, --gather root|compact for the cheaper forms) on the ctx's
-communication stream, overlapped with the next step.  `value` = frames/s over all GPUs.  Rank 0 then reports, in the
-same JSON line:
-  roofline      dominant extraction kernel (3x3 64->64 at 1/8 resolution): algorithmic flops / average launch duration,
-                HIP events attached to every dispatch of the kernel inside the timed region
+(keypoints, descriptors) records left in HBM (the task's rule for `value`); with N > 1 the step also moves the records
+with RCCL (frame i -> GPU i mod N; xfh_allgather_records by default, --gather root|compact for the cheaper
+forms) on the ctx's communication stream, overlapped with the next step.  `value` = frames/s over all GPUs.  In the same
+JSON line:
+  host_visible  SURVEY.md 8d read literally: the same frames from (pinned) HOST memory to records in HOST memory through
+                xfh_extract_batch_submit / _wait (csrc/pipeline.cpp), PCIe inside the clock, with the fraction of the PCIe rate
+  roofline      dominant extraction kernel (3x3 64->64 at 1/8 resolution): algorithmic flops / average launch duration of the
+                kernel alone on the GPU (HIP events attached to every dispatch); `in_timed_region` = the same events inside the
+                timed region, where the launches share the CUs with the other sub-batches
+  configs3      BASELINE.json configs[3]: one 1280x720 frame per rank per step + the gather, all three gather forms (N > 1);
+                with one GPU the batch of 8 on that GPU
+  gather_forms  (N > 1) the headline workload under the two gather forms that are not the default
   single_frame  one frame per call, device resident (latency path)
   host_api      what the drop-in operator() really does: xfh_extract from host memory (H2D + kernels + record to host
                 inside the clock), synchronous latency and pipelined (2 frames in flight) throughput, nfeatures 4096 / 1000
   match         4096 x 4096 MNN: whole call on raw descriptor rows (3 launches), on prepared images (2 launches), through
                 the host API, and the MFMA roofline of k_mnn_gemm_img
   aux_kernels   k_dist_i32, k_best2_csr, k_distinctive_csr timings
-  cpu_baseline  the oracle (oracle/, a C restatement of the reference; "port") on the host cores: all cores and 1 thread
+  cpu_baseline  the oracle (oracle/, a C restatement of the reference; "port") on the host cores: all cores and 1 thread; and
+                `libtorch_ops`: oracle/torch_restatement.py (the reference's own libtorch CPU operators, statement by statement)
+                timed in a child process on the same cores
   parity        GPU output of frame 0 / the match against the oracle, and a near-tie audit of the discrete decisions
 """
 from __future__ import annotations
@@ -107,7 +115,9 @@ def main():
                          "root = send/recv group into rank 0 only (rank 0 is the only consumer; an all-gather lands N x 298 MB per step in EVERY GPU), "
                          "compact = header + valid rows to rank 0")
     ap.add_argument("--force-comm", action="store_true", help="run the RCCL exchange also with one rank")
-    ap.add_argument("--no-legs", action="store_true", help="timed region only (no host_api / match / aux / cpu legs)")
+    ap.add_argument("--no-legs", action="store_true", help="timed region only (no host_visible / configs3 / host_api / match / aux / cpu legs)")
+    ap.add_argument("--host-steps", type=int, default=12, help="steps of the host-visible leg (each: the same frames per GPU as a timed step)")
+    ap.add_argument("--libtorch-leg", type=str, default="", help=argparse.SUPPRESS)        # child process of the cpu_baseline leg: "threads,threads,..."
     ap.add_argument("--only-match-leg", action="store_true", help="of the extra legs run the matcher ones only (short traces for the PMC passes)")
     ap.add_argument("--no-bn-leg", action="store_true", help="skip the eval()-BatchNorm legs (their kernels share names with the headline's in a kernel trace)")
     ap.add_argument("--serial-branch", action="store_true", help="XFH_FLAG_SERIAL_BRANCH: no overlapping kernels (for per-kernel profiles)")
@@ -115,6 +125,8 @@ def main():
                     help="BatchNorm mode of the timed region: batch = the reference's per-frame statistics (the headline), running = upstream eval(), "
                          "folded = eval() folded into the weights at load (SURVEY.md N4)")
     args = ap.parse_args()
+    if args.libtorch_leg:
+        return libtorch_leg(args)
 
     rank = int(os.environ.get("RANK", 0)); local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -135,7 +147,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X: libxfeat_hip.so has no CPU fallback")
 
     B, H, W, K = args.batch, args.height, args.width, args.steps
-    dev = local_rank if N > 1 else 0
+    dev = (local_rank % max(1, lib.xfh_device_count())) if N > 1 else 0      # (fewer GPUs than ranks only happens under the test stand-in for librccl)
     bn_mode = BN_MODES[args.bn]
     blob = WT.pack_blob(WT.make_synthetic(1234, KP_GAIN, with_bn=True))       # the running statistics are ignored in batch mode
     S = max(1, args.streams)
@@ -154,18 +166,35 @@ def main():
         comm = xd.Comm(ctx, rank, N, os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29500")) + 17)
     d_in = capi.DeviceBuffer(frames.nbytes).upload(frames)
     d_rec = [capi.DeviceBuffer(S * B * rec_bytes) for _ in range(2 if use_comm else 1)]     # two generations under the exchange
-    d_all = None
-    if use_comm:
-        if args.gather == "allgather":
-            d_all = [capi.DeviceBuffer(N * S * B * rec_bytes) for _ in range(2)]
-        elif args.gather == "root":
-            d_all = [capi.DeviceBuffer(N * S * B * rec_bytes if rank == 0 else 16) for _ in range(2)]
+    d_all_of = {}
+
+    def gather_target(form, frames_per_rank):
+        """two generations of the buffer the gather form `form` fills with `frames_per_rank` records per rank"""
+        key = (form, frames_per_rank)
+        if key not in d_all_of:
+            if form == "allgather":
+                nb = N * frames_per_rank * rec_bytes
+            elif form == "root":
+                nb = N * frames_per_rank * rec_bytes if rank == 0 else 16
+            else:
+                nb = N * int(lib.xfh_compact_bytes_max(nf, frames_per_rank)) if rank == 0 else 16
+            d_all_of[key] = [capi.DeviceBuffer(nb) for _ in range(2)]
+        return d_all_of[key]
+
+    def gather(form, d_records, frames_per_rank, g):
+        tgt = gather_target(form, frames_per_rank)[g].ptr
+        if form == "allgather":
+            comm.allgather_records(d_records, frames_per_rank, tgt, g)
+        elif form == "root":
+            comm.gather_records_root(d_records, frames_per_rank, tgt, 0, g)
         else:
-            d_all = [capi.DeviceBuffer(N * int(lib.xfh_compact_bytes_max(nf, S * B)) if rank == 0 else 16) for _ in range(2)]
+            comm.gather_compact_root(d_records, frames_per_rank, tgt, 0, g)
+
     in_ptr, rec_ptr = d_in.ptr, d_rec[0].ptr
     step_no = [0]
 
-    def step():
+    def step(form=None):
+        form = form or args.gather
         # S sub-batches of B frames, each on its own ctx / stream; the exchange of generation g runs on the ctx's
         # communication stream while the next step extracts into the other generation
         g = step_no[0] & 1 if use_comm else 0
@@ -178,12 +207,7 @@ def main():
         if use_comm:
             for c_ in ctxs[1:]:
                 comm.wait_ctx(c_)                          # the collective waits for every sub-batch, not only ctx 0's
-            if args.gather == "allgather":
-                comm.allgather_records(d_rec[g].ptr, S * B, d_all[g].ptr, g)
-            elif args.gather == "root":
-                comm.gather_records_root(d_rec[g].ptr, S * B, d_all[g].ptr, 0, g)
-            else:
-                comm.gather_compact_root(d_rec[g].ptr, S * B, d_all[g].ptr, 0, g)
+            gather(form, d_rec[g].ptr, S * B, g)
         step_no[0] += 1
 
     def sync(value=0.0):
@@ -195,6 +219,8 @@ def main():
             return comm.barrier_max(value)
         return value
 
+    if use_comm:
+        gather_target(args.gather, S * B)                  # allocated before the clock
     for _ in range(args.warmup):
         step()
     sync()
@@ -230,6 +256,24 @@ def main():
     ctx.timing_enable(0)
     frames_per_s = N * B * S * K / elapsed
 
+    def timed(fn, k, warm=2):
+        """k calls of fn between two barriers; MAX over ranks of the elapsed time per call [s]"""
+        for _ in range(warm):
+            fn()
+        sync()
+        t_ = time.perf_counter()
+        for _ in range(k):
+            fn()
+        for c_ in ctxs:
+            c_.synchronize()
+        if use_comm:
+            comm.synchronize()
+        return sync(time.perf_counter() - t_) / k
+
+    multi = None
+    if use_comm and not args.no_legs:
+        multi = multi_rank_legs(args, lib, capi, synth, Context, xd, comm, ctx, blob, rank, N, dev, nf, rec_bytes, step, timed, gather, gather_target, B * S)
+
     if rank != 0:
         sync()                                             # rank 0 runs its extra legs, then everybody leaves together
         comm.close()
@@ -261,6 +305,7 @@ def main():
     if traffic and traffic.get("conv_bytes_per_launch"):
         conv_traffic = traffic["conv_bytes_per_launch"] * (B / traffic["conv_batch"] if traffic.get("conv_batch") else 1.0)
     out["config"]["bn_mode"] = args.bn
+    pmc_src = "profiles/pmc_traffic.json: the builder's separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes (tools/gpu_round.sh), corrected with the factors calibrated on known-byte-count kernels (xfh_bench_calib); a constant in this run, not an observation of it"
     step_tf = net_flops(H, W) * frames_per_s / N / 1e12
     out["step_roofline"] = {"what": "all convolutions of the network (algorithmic flops per frame) x frames/s per GPU of the timed region, against the f32 MFMA peak: "
                                     "the whole step, every non-convolution kernel and every gap included",
@@ -270,16 +315,22 @@ def main():
     comp = H * W + 4096 * (28 + 256)
     meas = traffic.get("extract_hbm_bytes_per_frame") if traffic else None
     out["step_roofline"]["hbm"] = {"peak_GBps": 8000.0, "compulsory_bytes_per_frame": comp, "compulsory_frac": comp * frames_per_s / N / 8e12,
-                                   "measured_bytes_per_frame": meas, "measured_GBps": (meas * frames_per_s / N / 1e9) if meas else None,
+                                   "measured_bytes_per_frame": meas, "measured_source": pmc_src if meas else None,
+                                   "measured_GBps": (meas * frames_per_s / N / 1e9) if meas else None,
                                    "measured_frac": (meas * frames_per_s / N / 8e12) if meas else None,
                                    "note": "the step is bound by the vector / matrix pipe (frac above), not by HBM"}
     kname = ("k_conv_mfma<64,64,3,...>" if B > 32 else "k_conv_mfma16<64,64,1,16,2,...> (16x16x4 tiles, the form for batches <= 32)") + " (block3.1, block_fusion.1: 3x3 64->64 at 1/8 res)" + ("" if args.bn != "folded" else ", bias+ReLU epilogue")
     out["roofline"] = {"kernel": kname,
-                       "measured": "HIP events attached to every dispatch of the kernel inside the timed region (all ctx)" + ("; the launches share the CUs with the other sub-batches' kernels" if S > 1 else ""),
-                       "bound": "mfma", "achieved": conv_tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": conv_tf / PEAK_F32_MFMA_TFLOPS,
-                       "traffic": conv_traffic, "avg_launch_us": conv_us, "launches": n_conv, "flops_per_launch": conv_flops(H, W) * B,
-                       "isolated": {"note": f"the same launches ({B} frames) with one ctx alone on the GPU, after the timed region",
-                                    "achieved": iso_tf, "frac": iso_tf / PEAK_F32_MFMA_TFLOPS, "avg_launch_us": iso_us, "launches": n_iso}}
+                       "measured": f"HIP events attached to every dispatch of the kernel (hipExtLaunchKernelGGL): the same launches ({B} frames each) with ONE ctx alone on the GPU "
+                                   "right after the timed region -- the kernel's own duration, the view rocprofv3 --kernel-trace gives of a serial run (profiles/r03_roofline_table.md)",
+                       "bound": "mfma", "achieved": iso_tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": iso_tf / PEAK_F32_MFMA_TFLOPS,
+                       "traffic": conv_traffic, "traffic_source": pmc_src if conv_traffic else None,
+                       "avg_launch_us": iso_us, "launches": n_iso, "flops_per_launch": conv_flops(H, W) * B,
+                       "in_timed_region": {"note": "the same events inside the timed region, all ctx" + (f": {S} sub-batches are in flight, a launch shares the CUs with the other ctx' kernels, so this "
+                                                   "span is longer than the kernel's own speed (it measures neither the kernel nor the step)" if S > 1 else ""),
+                                           "achieved": conv_tf, "frac": conv_tf / PEAK_F32_MFMA_TFLOPS, "avg_launch_us": conv_us, "launches": n_conv}}
+    if multi is not None:
+        out.update(multi)
 
     if not args.no_legs:
         legs(out, args, lib, capi, synth, Context, ctx, blob, frames, d_in, d_rec[0], B, H, W, nf, rec_bytes, traffic, N)
@@ -292,6 +343,94 @@ def main():
         C.CDLL(None).fflush(None)                          # RCCL's banner sits in the C stdio buffer of fd 1: out to stderr with it
         os.dup2(saved_stdout, 1)
     print(json.dumps(out), flush=True)
+
+
+PCIE_GBPS = 63.0      # PCIe 5.0 x16, one direction, after 128b/130b (tools/pcie_probe.py on the bench box: 56.5 GB/s for one copy stream)
+C3_H, C3_W = 720, 1280
+
+
+def multi_rank_legs(args, lib, capi, synth, Context, xd, comm, ctx, blob, rank, N, dev, nf, rec_bytes, step, timed, gather, gather_target, frames_per_rank):
+    """collective legs, run by EVERY rank after the timed region: the headline workload under the other two gather forms, and
+    BASELINE.json configs[3] itself -- one 1280x720 frame per rank per step (frame i of the batch of N -> rank i), extracted on the
+    rank's GPU and gathered to rank 0, all three gather forms; reference consumer: the sequential loop of src/System.cc:197-233"""
+    res = {}
+    forms = ["allgather", "root", "compact"]
+    k2 = max(3, min(10, args.steps))
+    gf = {}
+    for form in forms:
+        if form == args.gather:
+            continue
+        gather_target(form, frames_per_rank)
+        dt = timed(lambda: step(form), k2)
+        gf[form] = {"frames_per_s": N * frames_per_rank / dt, "ms_per_step": dt * 1e3, "steps": k2}
+    gf["note"] = f"the timed region's workload ({frames_per_rank} VGA frames per GPU per step) with the other gather forms; `value` uses --gather {args.gather}"
+    res["gather_forms"] = gf
+    # ---- configs[3] ---------------------------------------------------------------------------------------------------
+    ctx3 = Context(nfeatures=nf, max_height=C3_H, max_width=C3_W, max_batch=1, device=dev)
+    ctx3.load_weights(blob)
+    fr3 = synth.frames(1, C3_H, C3_W, seed=4242 + rank)
+    d_in3 = capi.DeviceBuffer(fr3.nbytes).upload(fr3)
+    d_rec3 = [capi.DeviceBuffer(rec_bytes) for _ in range(2)]
+    no = [0]
+
+    def step3(form):
+        g = no[0] & 1
+        no[0] += 1
+        comm.fence_ctx(ctx3, g)                            # the gather that last read generation g has finished
+        capi.check(lib.xfh_extract_batch_device(ctx3.h, d_in3.ptr, 1, C3_H, C3_W, 0, 0, d_rec3[g].ptr), ctx3.h)
+        comm.wait_ctx(ctx3)
+        gather(form, d_rec3[g].ptr, 1, g)
+    c3 = {}
+    k3 = max(5, min(30, args.steps))
+    for form in forms:
+        gather_target(form, 1)
+        dt = timed(lambda: step3(form), k3)
+        # latency of ONE step: frame in HBM -> all records at rank 0, nothing else in flight
+        lat = 0.0
+        for _ in range(3):
+            ctx3.synchronize(); comm.synchronize()
+            comm.barrier_max(0.0)
+            t_ = time.perf_counter()
+            step3(form)
+            ctx3.synchronize(); comm.synchronize()
+            lat = max(lat, time.perf_counter() - t_) if _ == 0 else min(lat, time.perf_counter() - t_)
+        lat = comm.barrier_max(lat)
+        c3[form] = {"frames_per_s": N / dt, "ms_per_step": dt * 1e3, "steps": k3, "one_step_latency_ms": lat * 1e3}
+    res["configs3"] = {"workload": f"configs[3]: a batch of {N} 1280x720 frames sharded one per GPU (frame i -> rank i), extracted at 704x1280 into 4096-row records on each GPU, "
+                                   f"records gathered to rank 0 with RCCL through the C ABI (xfh_comm_*); steps back to back, the gather of step t overlaps the extraction of step t + 1",
+                       "n_ranks": N, "per_gather_form": c3,
+                       "note": "frames_per_s = N / step time (MAX over ranks); one_step_latency_ms = one isolated step, frame resident in HBM -> gather complete"}
+    ctx3.synchronize(); comm.synchronize()
+    ctx3.close()
+    return res
+
+
+def libtorch_leg(args):
+    """child process of the cpu_baseline leg: oracle/torch_restatement.py -- the reference's own libtorch CPU operators, statement by
+    statement (conv2d, batch_norm(training), instance_norm, interpolate, softmax, max_pool2d, nonzero, grid_sample, argsort, normalize;
+    the reference itself cannot be built here: OpenCV) -- on the same synthetic frames / weights, for each thread count in the argument"""
+    import torch
+    from oracle import torch_restatement as TR
+    from xfeatslam_amd import synth, weights as WT
+    wt = WT.make_synthetic(1234, KP_GAIN)
+    frames = synth.frames(4, args.height, args.width, seed=42)
+    d1, d2 = synth.descriptor_sets(NFEATURES, NFEATURES, noise=0.1)
+    res = {}
+    for nthr in [int(v) for v in args.libtorch_leg.split(",")]:
+        torch.set_num_threads(nthr)
+        t0 = time.perf_counter()
+        TR.extract(frames[0], wt, NFEATURES, (0, 0))
+        warm = time.perf_counter() - t0
+        nfr = max(1, min(8, int(5.0 / max(warm, 1e-3))))
+        t0 = time.perf_counter()
+        for i in range(nfr):
+            TR.extract(frames[i % len(frames)], wt, NFEATURES, (0, 0))
+        fdt = (time.perf_counter() - t0) / nfr
+        t0 = time.perf_counter()
+        TR.match_mnn(d1, d2)
+        mdt = time.perf_counter() - t0
+        res[str(nthr)] = {"frames_per_s": 1.0 / fdt, "frames": nfr, "match_pairs_per_s": NFEATURES * NFEATURES / mdt}
+    print(json.dumps({"torch": torch.__version__, "legs": res}), flush=True)
 
 
 def legs(out, args, lib, capi, synth, Context, ctx, blob, frames, d_in, d_recb, B, H, W, nf, rec_bytes, traffic, N):
@@ -314,6 +453,71 @@ def legs(out, args, lib, capi, synth, Context, ctx, blob, frames, d_in, d_recb, 
                            "note": "one 480x640 frame per xfh_extract_batch_device call, back to back on one stream (latency path of configs[1], device resident)"}
     capi.check(lib.xfh_extract_batch_device(ctx.h, in_ptr, B, H, W, 0, 0, rec_ptr), ctx.h)   # restore the batch records
     ctx.synchronize()
+
+    # ---- SURVEY.md 8d read literally: host-visible.  The step's frames from pinned host memory to records in pinned host memory
+    # through the batch pipeline (csrc/pipeline.cpp: sub-batches of B frames over 4 in-order lanes), PCIe inside the clock
+    if not args.only_match_leg:
+        S = max(1, args.streams)
+        nfr = S * B
+        hin = capi.HostBuffer(nfr * H * W); hin.array[:] = frames.reshape(-1)[:nfr * H * W]
+        houts = [capi.HostBuffer(nfr * rec_bytes) for _ in range(2)]
+        hk = max(3, args.host_steps)
+        for _ in range(3):
+            capi.check(lib.xfh_extract_batch(ctx.h, hin.ptr, nfr, H, W, 0, 0, houts[0].ptr), ctx.h)
+        t1 = time.perf_counter()
+        for _ in range(hk):
+            capi.check(lib.xfh_extract_batch(ctx.h, hin.ptr, nfr, H, W, 0, 0, houts[0].ptr), ctx.h)
+        blocking_dt = (time.perf_counter() - t1) / hk
+        t1 = time.perf_counter()
+        capi.check(lib.xfh_extract_batch_submit(ctx.h, hin.ptr, nfr, H, W, 0, 0, houts[0].ptr), ctx.h)
+        for t in range(1, hk):
+            capi.check(lib.xfh_extract_batch_submit(ctx.h, hin.ptr, nfr, H, W, 0, 0, houts[t & 1].ptr), ctx.h)
+            capi.check(lib.xfh_extract_batch_wait(ctx.h), ctx.h)           # step t - 1 is complete in houts[(t - 1) & 1]: the consumer's turn
+        capi.check(lib.xfh_extract_batch_wait(ctx.h), ctx.h)
+        piped_dt = (time.perf_counter() - t1) / hk
+        got = ctx.parse_records(np.array(houts[(hk - 1) & 1].array[:2 * rec_bytes]), 2)
+        dev_recs = ctx.parse_records(d_recb.download(np.uint8, rec_bytes * 2), 2) if B > 1 else None
+        same = None if dev_recs is None else bool(all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2:4] == b[2:4] for a, b in zip(got, dev_recs)))
+        out_b, in_b = nfr * rec_bytes, nfr * H * W
+        out["host_visible"] = {
+            "value": nfr / piped_dt, "unit": "frames/s",
+            "workload": f"SURVEY.md 8d metric read literally (host-visible): {nfr} distinct {H}x{W} u8 frames per step from pinned HOST memory -> {nfr} padded {nf}-row records "
+                        f"(keypoints + descriptors, {rec_bytes} B each) in pinned HOST memory through xfh_extract_batch_submit / _wait: sub-batches of {B} frames over 4 in-order "
+                        "lanes (H2D, kernels, D2H per lane), the consumer double-buffers the records (submit(t + 1); wait() -> step t); PCIe both ways inside the clock",
+            "ms_per_step": piped_dt * 1e3, "steps": hk, "frames_per_step": nfr,
+            "blocking": {"value": nfr / blocking_dt, "ms_per_step": blocking_dt * 1e3, "note": "xfh_extract_batch per step (submit + drain): the last sub-batches' downloads are exposed"},
+            "pcie": {"bytes_out_per_frame": rec_bytes, "bytes_in_per_frame": H * W, "out_GBps": out_b / piped_dt / 1e9, "in_GBps": in_b / piped_dt / 1e9,
+                     "peak_GBps_per_direction": PCIE_GBPS, "out_frac_of_peak": out_b / piped_dt / 1e9 / PCIE_GBPS, "in_frac_of_peak": in_b / piped_dt / 1e9 / PCIE_GBPS},
+            "vs_hbm_resident": (nfr / piped_dt) / (out["value"] / N),
+            "records_equal_device_resident_path": same,
+            "n_gpus": 1, "note": "one GPU (rank 0's); `value` of the line is the HBM-resident regime the bench contract prescribes"}
+        for h in houts + [hin]:
+            h.free()
+        # ---- BASELINE.json configs[3] on ONE GPU: the batch of 8 1280x720 frames (the multi-rank form is `configs3` of a --gpus N run)
+        c3 = Context(nfeatures=nf, max_height=C3_H, max_width=C3_W, max_batch=8, device=ctx.device)
+        c3.load_weights(blob)
+        fr3 = synth.frames(8, C3_H, C3_W, seed=4242)
+        d_in3 = capi.DeviceBuffer(fr3.nbytes).upload(fr3); d_rec3 = capi.DeviceBuffer(8 * rec_bytes)
+        for _ in range(3):
+            capi.check(lib.xfh_extract_batch_device(c3.h, d_in3.ptr, 8, C3_H, C3_W, 0, 0, d_rec3.ptr), c3.h)
+        c3.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(20):
+            capi.check(lib.xfh_extract_batch_device(c3.h, d_in3.ptr, 8, C3_H, C3_W, 0, 0, d_rec3.ptr), c3.h)
+        c3.synchronize()
+        dt3 = (time.perf_counter() - t1) / 20
+        h3 = capi.HostBuffer(fr3.nbytes); h3.array[:] = fr3.reshape(-1); o3 = capi.HostBuffer(8 * rec_bytes)
+        for _ in range(2):
+            capi.check(lib.xfh_extract_batch(c3.h, h3.ptr, 8, C3_H, C3_W, 0, 0, o3.ptr), c3.h)
+        t1 = time.perf_counter()
+        for _ in range(20):
+            capi.check(lib.xfh_extract_batch(c3.h, h3.ptr, 8, C3_H, C3_W, 0, 0, o3.ptr), c3.h)
+        dt3h = (time.perf_counter() - t1) / 20
+        out["configs3_one_gpu"] = {"workload": "configs[3] on one GPU: the batch of 8 1280x720 frames in one call (extracted at 704x1280, 4096-row records)",
+                                   "device_resident": {"frames_per_s": 8 / dt3, "ms_per_batch": dt3 * 1e3},
+                                   "host_visible_blocking": {"frames_per_s": 8 / dt3h, "ms_per_batch": dt3h * 1e3},
+                                   "note": "the sharded form (one frame per GPU + RCCL gather) is the `configs3` key of a --gpus N run"}
+        h3.free(); o3.free(); d_in3.free(); d_rec3.free(); c3.close()
 
     # ---- the same workload with upstream-XFeat eval() BatchNorm, exact (running) and folded into the weights
     if args.bn == "batch" and not args.no_bn_leg and not args.only_match_leg:
@@ -390,9 +594,9 @@ def legs(out, args, lib, capi, synth, Context, ctx, blob, frames, d_in, d_recb, 
     host["note"] = ("xfh_extract / xfh_extract_submit+collect on one ctx: pageable host image -> pinned -> H2D -> kernels -> record written "
                     "to pinned host memory -> caller's buffers; everything inside the clock (SURVEY.md 8d 'host-visible')")
     out["host_api"] = host
-    if host.get("nfeatures_4096"):
-        out["host_visible"] = {"value": host["nfeatures_4096"]["pipelined_frames_per_s"], "unit": "frames/s",
-                               "note": "single ctx, one frame per call, 2 frames in flight, host memory in and out (nfeatures 4096)"}
+    if host.get("nfeatures_4096") and "host_visible" in out:
+        out["host_visible"]["one_frame_per_call"] = {"value": host["nfeatures_4096"]["pipelined_frames_per_s"], "unit": "frames/s",
+                                                     "note": "what a single SLAM thread sees: xfh_extract_submit / _collect, one frame per call, 2 frames in flight, pageable host memory in and out"}
 
     # ---- matching leg: 4096 x 4096 MNN on the descriptors of frame 0 vs frame 1 (device resident) ----------------------
     d1p = rec_ptr + ctx.desc_off
@@ -570,6 +774,24 @@ def legs(out, args, lib, capi, synth, Context, ctx, blob, frames, d_in, d_recb, 
                          "n_candidates": int(hnc), "near_tie_audit": audit}
         fdt, mdt, nfr = cpu_legs[best]
         f1, m1, n1r = cpu_legs[1]
+        # north_star: "the libtorch CPU path timed on the same box's host cores".  The reference itself cannot be built here (OpenCV);
+        # its libtorch operator sequence can: oracle/torch_restatement.py in a child process (torch is imported nowhere else)
+        import subprocess
+        lt = None
+        try:
+            thr = sorted({1, min(ncores, 16), ncores})
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--libtorch-leg", ",".join(str(t) for t in thr), "--height", str(H), "--width", str(W)],
+                               capture_output=True, text=True, timeout=420)
+            if r.returncode == 0:
+                lt = json.loads(r.stdout.strip().splitlines()[-1])
+            else:
+                lt = {"skipped": "child failed: " + r.stderr.strip()[-300:]}
+        except Exception as e:       # noqa: BLE001
+            lt = {"skipped": f"{type(e).__name__}: {e}"}
+        if lt and "legs" in lt:
+            bt = max(lt["legs"], key=lambda k: lt["legs"][k]["frames_per_s"])
+            lt.update({"kind": "restatement of the reference's libtorch operator sequence (oracle/torch_restatement.py), NOT the reference binary",
+                       "best": {"cores": int(bt), **lt["legs"][bt]}, "one_thread": lt["legs"].get("1")})
         out["cpu_baseline"] = {"value": 1.0 / fdt, "unit": "frames/s", "cores": best, "kind": "port", "cpu_model": cpu_model(),
                                "host_hardware_threads": os.cpu_count(), "usable_hardware_threads": ncores,
                                "sample": f"{nfr} of the same {H}x{W} frames through oracle/xfeat_oracle.c (OpenMP, {best} threads = the fastest of the thread counts tried); "
@@ -577,7 +799,8 @@ def legs(out, args, lib, capi, synth, Context, ctx, blob, frames, d_in, d_recb, 
                                "match_pairs_per_s": nf * nf / mdt,
                                "one_thread": {"value": 1.0 / f1, "unit": "frames/s", "cores": 1, "match_pairs_per_s": nf * nf / m1,
                                               "sample": f"{n1r} frames, 4096x4096 MNN once, 1 thread"},
-                               "legs": {str(k): {"frames_per_s": 1.0 / v[0], "match_pairs_per_s": nf * nf / v[1], "frames": v[2]} for k, v in sorted(cpu_legs.items())}}
+                               "legs": {str(k): {"frames_per_s": 1.0 / v[0], "match_pairs_per_s": nf * nf / v[1], "frames": v[2]} for k, v in sorted(cpu_legs.items())},
+                               "libtorch_ops": lt}
 
 
 if __name__ == "__main__":

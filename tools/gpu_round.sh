@@ -16,7 +16,7 @@ for cfg in "1 1" "1 8" "1 64" "1 256" "2 128" "3 85" "4 64" "4 128" "8 32"; do s
 import json, sys
 d = json.load(open(sys.argv[1])); c = d["config"]
 print(c["sub_batches_in_flight"], c["frames_per_gpu_per_step"] // c["sub_batches_in_flight"], round(d["value"]), round(d["ms_per_step"], 3),
-      round(d["step_roofline"]["frac"], 4), round(d["roofline"]["frac"], 4), round(d["roofline"]["isolated"]["frac"], 4))
+      round(d["step_roofline"]["frac"], 4), round(d["roofline"]["frac"], 4), round(d["roofline"]["in_timed_region"]["frac"], 4))
 PY
 done
 ( timeout 300 python bench.py --force-comm --steps 20 --no-legs ) 2> $O/bench_dist1.err | tail -1 > $O/bench_dist1.json
