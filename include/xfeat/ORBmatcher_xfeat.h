@@ -83,6 +83,7 @@ public:
         if (rc != XFH_OK) throw std::runtime_error(std::string("XFmatcher::matchPrepared: ") + xfh_strerror(rc));
         int n = 0;
         xfh_memcpy_d2h(&n, o + 12 * (size_t)nm, 4);
+        if (n < 0 || n > nm) throw std::runtime_error("XFmatcher::matchPrepared: the device reported a collector time-out (n_matches < 0)");
         i1.resize(nm); i2.resize(nm); d.resize(nm);
         if (n > 0) { xfh_memcpy_d2h(i1.data(), o, 4 * (size_t)n); xfh_memcpy_d2h(i2.data(), o + 4 * (size_t)nm, 4 * (size_t)n); xfh_memcpy_d2h(d.data(), o + 8 * (size_t)nm, 4 * (size_t)n); }
         _matches.reserve(n);

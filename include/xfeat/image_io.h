@@ -22,19 +22,22 @@ namespace xfeat {
 
 struct Image8 { int rows = 0, cols = 0, channels = 0; std::vector<unsigned char> data; };   // channels in FILE order (R,G,B[,A])
 
+static const int kMaxSide = 16384;      // largest image side a file header may claim (TUM / EuRoC / KITTI frames are < 2k)
+
 inline bool load_pgm(const std::string& path, Image8& im) {
     std::ifstream f(path, std::ios::binary);
     std::string magic; int w = 0, h = 0, maxv = 0;
     if (!(f >> magic) || magic != "P5") return false;
     auto skip = [&]() { while (f.peek() == '#' || isspace(f.peek())) { if (f.peek() == '#') { std::string l; std::getline(f, l); } else f.get(); } };
     skip(); f >> w; skip(); f >> h; skip(); f >> maxv; f.get();
-    if (w <= 0 || h <= 0 || maxv != 255) return false;
+    if (w <= 0 || h <= 0 || w > kMaxSide || h > kMaxSide || maxv != 255) return false;       // bounded before anything is allocated
     im.rows = h; im.cols = w; im.channels = 1; im.data.resize((size_t)w * h);
     f.read((char*)im.data.data(), (std::streamsize)w * h);
     return (bool)f;
 }
 
 inline bool load_png(const std::string& path, Image8& im) {
+    // width / height come from the file: they are bounded by kMaxSide before any size is computed from them
     std::ifstream f(path, std::ios::binary);
     std::vector<unsigned char> buf((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
     static const unsigned char sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
@@ -46,13 +49,14 @@ inline bool load_png(const std::string& path, Image8& im) {
         const uint32_t len = be32(o);
         if (o + 12 + (size_t)len > buf.size()) return false;
         const char* ty = (const char*)&buf[o + 4];
-        if (!memcmp(ty, "IHDR", 4) && len >= 13) { w = be32(o + 8); h = be32(o + 12); depth = buf[o + 16]; ctype = buf[o + 17]; interlace = buf[o + 20]; }
+        if (!memcmp(ty, "IHDR", 4) && len >= 13 && ctype < 0) { w = be32(o + 8);       /* only the first IHDR counts */ h = be32(o + 12); depth = buf[o + 16]; ctype = buf[o + 17]; interlace = buf[o + 20]; }
         else if (!memcmp(ty, "IDAT", 4)) idat.insert(idat.end(), buf.begin() + o + 8, buf.begin() + o + 8 + len);
         else if (!memcmp(ty, "IEND", 4)) break;
         o += 12 + (size_t)len;
     }
     const int ch = ctype == 0 ? 1 : ctype == 4 ? 2 : ctype == 2 ? 3 : ctype == 6 ? 4 : 0;
     if (!w || !h || depth != 8 || !ch || interlace) return false;          // palette / 16-bit / Adam7 are not needed for TUM or EuRoC frames
+    if (w > (uint32_t)kMaxSide || h > (uint32_t)kMaxSide) return false;    // a crafted header must not size the allocations below
     const size_t stride = (size_t)w * ch;
     std::vector<unsigned char> raw((stride + 1) * h);
     uLongf rawlen = (uLongf)raw.size();

@@ -172,7 +172,11 @@ int xfh_extract_batch_device_images(xfh_ctx* ctx, const uint8_t* d_gray, int B, 
  * ORBmatcher.cc:340-405; these are the semantics of that code with float descriptors):
  * rows L2-normalised, cosine similarity, mutual nearest neighbours, first maximum wins
  * ties, matches in ascending idx1 order, dist = sqrt(2 (1 - cos)).  min_cossim <= 0
- * disables the gate as the reference does (:361).  idx1/idx2/dist need min(n1,n2) slots. */
+ * disables the gate as the reference does (:361).  idx1/idx2/dist need min(n1,n2) slots.
+ * Descriptors must be finite.  Rows holding NaN or Inf are outside the contract: the calls still return (a bounded wait, never a
+ * hang) and the pairs among finite rows that do not compete with a poisoned row are unaffected, but which partner a poisoned row
+ * gets -- the reference's torch::max would propagate the NaN -- is unspecified (the match GEMM is built with -fno-honor-nans).
+ * The extraction never produces such rows. */
 int xfh_match_mnn(xfh_ctx* ctx, const float* d1, int n1, const float* d2, int n2, float min_cossim,
                   int* idx1, int* idx2, float* dist, int* n_matches);
 /* device-resident variant: d1/d2 device pointers (e.g. the desc block of two records),

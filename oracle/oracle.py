@@ -12,7 +12,7 @@ import subprocess
 import numpy as np
 
 _DIR = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_DIR, "libxfeat_oracle.so")
+_LIB = os.environ.get("XFO_LIB") or os.path.join(_DIR, "libxfeat_oracle.so")     # XFO_LIB: the sanitizer build (make -C oracle asan)
 
 KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
                      ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])

@@ -105,6 +105,18 @@ def test_cpp_dropin_compiles_and_links():
     assert r.returncode == 0, r.stderr
 
 
+def test_host_code_under_sanitizers(tmp_path):
+    """libxfeat_hip's HOST code built with AddressSanitizer + UBSan (make -C xfeatslam_amd/csrc asan; device code is not
+    instrumented): tests/cpp/asan_host_test.cpp drives every entry point that needs no GPU, hostile compact shards included"""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "xfeatslam_amd", "csrc"), "asan", "-s", "-j8"])
+    exe = str(tmp_path / "asan_host_test")
+    subprocess.check_call(["/opt/rocm/lib/llvm/bin/clang++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "asan_host_test.cpp"), "-L" + os.path.join(ROOT, "xfeatslam_amd"), "-lxfeat_hip_asan",
+                           "-Wl,-rpath," + os.path.join(ROOT, "xfeatslam_amd"), "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
+    assert r.returncode == 0 and "asan_host_test ok" in r.stdout, r.stderr[-3000:]
+
+
 def test_convert_weights_tool(tmp_path):
     import torch
     w = WT.make_synthetic(99)
@@ -112,6 +124,59 @@ def test_convert_weights_tool(tmp_path):
     sd["fine_matcher.0.weight"] = torch.zeros(512, 128)            # extra tensors are ignored
     sd["block1.0.layer.1.running_mean"] = torch.zeros(4)
     torch.save(sd, tmp_path / "xfeat.pt")
+    r = subprocess.run(["python", os.path.join(ROOT, "tools", "convert_weights.py"), str(tmp_path / "xfeat.pt"), str(tmp_path / "o.xfhw")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert (tmp_path / "o.xfhw").read_bytes() == WT.pack_blob(w)
+
+
+def test_convert_weights_tool_reads_a_libtorch_archive(tmp_path):
+    """the form the reference actually loads (XFextractor.cc:133-137: torch::serialize::InputArchive + model->load): a TorchScript
+    zip whose parameters carry libtorch's module-tree names -- Sequential children "0", "1", ..., BasicLayerImpl's Sequential
+    registered as `layer` (XFeat.cc:22).  A scripted module with that tree, saved with torch.jit.save, converts key for key
+    (SURVEY.md Appendix B), BatchNorm buffers and the unused fine_matcher included."""
+    import torch
+    from torch import nn
+    w = WT.make_synthetic(321, with_bn=True)
+
+    class BasicLayer(nn.Module):
+        def __init__(self, cin, cout, k, stride):
+            super().__init__()
+            self.layer = nn.Sequential(nn.Conv2d(cin, cout, k, stride=stride, padding=k // 2, bias=False), nn.BatchNorm2d(cout, affine=False), nn.ReLU())
+
+        def forward(self, x):
+            return self.layer(x)
+
+    class XFeatModel(nn.Module):
+        def __init__(self):
+            super().__init__()
+            B = BasicLayer
+            self.norm = nn.InstanceNorm2d(1)
+            self.skip1 = nn.Sequential(nn.AvgPool2d(4, 4), nn.Conv2d(1, 24, 1))
+            self.block1 = nn.Sequential(B(1, 4, 3, 1), B(4, 8, 3, 2), B(8, 8, 3, 1), B(8, 24, 3, 2))
+            self.block2 = nn.Sequential(B(24, 24, 3, 1), B(24, 24, 3, 1))
+            self.block3 = nn.Sequential(B(24, 64, 3, 2), B(64, 64, 3, 1), B(64, 64, 1, 1))
+            self.block4 = nn.Sequential(B(64, 64, 3, 2), B(64, 64, 3, 1), B(64, 64, 3, 1))
+            self.block5 = nn.Sequential(B(64, 128, 3, 2), B(128, 128, 3, 1), B(128, 128, 3, 1), B(128, 64, 1, 1))
+            self.block_fusion = nn.Sequential(B(64, 64, 3, 1), B(64, 64, 3, 1), nn.Conv2d(64, 64, 1))
+            self.heatmap_head = nn.Sequential(B(64, 64, 1, 1), B(64, 64, 1, 1), nn.Conv2d(64, 1, 1), nn.Sigmoid())
+            self.keypoint_head = nn.Sequential(B(64, 64, 1, 1), B(64, 64, 1, 1), B(64, 64, 1, 1), nn.Conv2d(64, 65, 1))
+            self.fine_matcher = nn.Sequential(nn.Linear(128, 512), nn.BatchNorm1d(512, affine=False), nn.ReLU(), nn.Linear(512, 64))
+
+        def forward(self, x):
+            return self.block1(self.norm(x))
+
+    m = XFeatModel()
+    sd = m.state_dict()
+    # key for key: every tensor the path consumes exists under the Appendix-B name with the Appendix-B shape
+    for name, shape in WT.TENSORS + WT.BN_TENSORS:
+        assert name in sd and tuple(sd[name].shape) == tuple(shape), name
+    with torch.no_grad():
+        for name, _ in WT.TENSORS + WT.BN_TENSORS:
+            sd[name].copy_(torch.from_numpy(w[name]))
+    torch.jit.save(torch.jit.script(m), str(tmp_path / "xfeat.pt"))
+    with pytest.raises(Exception):
+        torch.load(str(tmp_path / "xfeat.pt"), map_location="cpu", weights_only=True)          # not a torch.save pickle: only the jit branch can read it
     r = subprocess.run(["python", os.path.join(ROOT, "tools", "convert_weights.py"), str(tmp_path / "xfeat.pt"), str(tmp_path / "o.xfhw")],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
@@ -154,6 +219,23 @@ def test_png_reader_and_gray_conversion(tmp_path):
     bad = open(tmp_path / "rgb_1_0.png", "rb").read()[:200]
     open(tmp_path / "bad.png", "wb").write(bad)
     assert subprocess.call([exe, str(tmp_path / "bad.png"), "1", str(tmp_path / "o.bin")]) == 1
+    # crafted headers: a PNG whose IHDR claims 2^31 x 2^31 pixels and a PGM claiming 10^6 x 10^6 are refused before anything is
+    # allocated; a second IHDR does not override the first
+    import struct
+    import zlib
+    good = open(tmp_path / "g_1_0.png", "rb").read()
+
+    def chunk(ty, data):
+        return struct.pack(">I", len(data)) + ty + data + struct.pack(">I", zlib.crc32(ty + data) & 0xFFFFFFFF)
+    huge = good[:8] + chunk(b"IHDR", struct.pack(">IIBBBBB", 0x7FFFFFFF, 0x7FFFFFFF, 8, 0, 0, 0, 0)) + good[33:]
+    open(tmp_path / "huge.png", "wb").write(huge)
+    assert subprocess.call([exe, str(tmp_path / "huge.png"), "1", str(tmp_path / "o.bin")]) == 1
+    twice = good[:33] + chunk(b"IHDR", struct.pack(">IIBBBBB", 5, 5, 8, 0, 0, 0, 0)) + good[33:]
+    open(tmp_path / "twice.png", "wb").write(twice)
+    subprocess.check_call([exe, str(tmp_path / "twice.png"), "1", str(tmp_path / "o.bin")])
+    assert open(tmp_path / "o.bin", "rb").read().split(b"\n", 1)[0] == b"37 53 1"
+    open(tmp_path / "huge.pgm", "wb").write(b"P5\n1000000 1000000\n255\n")
+    assert subprocess.call([exe, str(tmp_path / "huge.pgm"), "1", str(tmp_path / "o.bin")]) == 1
 
 
 def test_panel_layout_is_conflict_free():

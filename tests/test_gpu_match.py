@@ -215,3 +215,56 @@ def test_mnn_random_shapes(mctx, oracle_mod):
         a = oracle_mod.match_mnn(d1, d2, thr); b = mctx.match_mnn(d1, d2, thr)
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (trial, n1, n2, thr)
         assert np.array_equal(a[2], b[2], equal_nan=True)
+
+
+def test_match_under_four_busy_extraction_ctx(gpu_lib, oracle_mod):
+    """k_mnn_post's collector blocks poll (column, value) pairs that writer blocks of the same grid publish; forward progress must
+    not depend on the GPU being otherwise idle.  Four extraction ctx keep 4 x 24 frames in flight on their own streams while a
+    fifth ctx runs 4096 x 4096 matches back to back (raw rows and prepared images): every call returns the oracle's pairs."""
+    from xfeatslam_amd import weights as WT
+    from xfeatslam_amd.extractor import Context
+    L = gpu_lib
+    H, W, nf, B = 256, 320, 1024, 24
+    blob = WT.pack_blob(WT.make_synthetic(1234, 6.0))
+    busy = [Context(nfeatures=nf, max_height=H, max_width=W, max_batch=B) for _ in range(4)]
+    for c in busy:
+        c.load_weights(blob)
+    fr = synth.frames(B, H, W, seed=3)
+    d_in = capi.DeviceBuffer(fr.nbytes).upload(fr)
+    d_rec = [capi.DeviceBuffer(B * busy[0].rec_bytes) for _ in busy]
+    m = Context(nfeatures=4096, max_height=32, max_width=32)
+    d1, d2 = synth.descriptor_sets(4096, 4096, noise=0.3, zero_rows=50)
+    want = oracle_mod.match_mnn(d1, d2)
+    p1, p2 = m.match_prepare(d1), m.match_prepare(d2)
+    for rnd in range(6):
+        for k, c in enumerate(busy):                       # ~40 ms of queued extraction work per round, never waited for here
+            for _ in range(3):
+                capi.check(L.xfh_extract_batch_device(c.h, d_in.ptr, B, H, W, 0, 0, d_rec[k].ptr), c.h)
+        for _ in range(4):
+            a = m.match_mnn(d1, d2)
+            b = m.match_mnn_prepared(p1, p2)
+            for got in (a, b):
+                assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), rnd
+    for c in busy:
+        c.synchronize(); c.close()
+    m.close()
+
+
+def test_nan_and_inf_descriptors_return(mctx):
+    """NaN / Inf descriptor rows are outside the contract (include/xfeat_hip.h: results for such rows are unspecified), but the
+    calls must come back: no hang in the collectors, a status, and sane pairs for the finite rows that do not touch them"""
+    d1, d2 = synth.descriptor_sets(300, 260, noise=0.2)
+    want = mctx.match_mnn(d1, d2)
+    bad1, bad2 = d1.copy(), d2.copy()
+    bad1[7] = np.nan; bad1[100, 3] = np.inf; bad2[11] = -np.inf; bad2[200, 63] = np.nan
+    try:
+        got = mctx.match_mnn(bad1, bad2)
+    except capi.XfhError as e:                             # a refused call is fine too, a hang is not
+        assert e.status in (1, 6)
+        return
+    n = len(got[0])
+    assert 0 <= n <= 260 and np.all((got[0] >= 0) & (got[0] < 300)) and np.all((got[1] >= 0) & (got[1] < 260))
+    clean = {(int(a), int(b)) for a, b in zip(want[0], want[1]) if a not in (7, 100) and b not in (11, 200)}
+    have = {(int(a), int(b)) for a, b in zip(got[0], got[1])}
+    assert len(clean - have) <= 8                           # pairs of finite rows survive unless a poisoned row displaced their partner
+    assert mctx.match_mnn(d1, d2)[0].tolist() == want[0].tolist()       # and the ctx is still usable

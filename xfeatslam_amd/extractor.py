@@ -112,6 +112,9 @@ class Context:
                                                   out.ptr + 64, out.ptr + 64 + 4 * nm, out.ptr + 64 + 8 * nm, out.ptr), self.h)
         self.synchronize()
         k = int(out.download(np.int32, 1)[0])
+        if k < 0 or k > nm:
+            out.free()
+            raise capi.XfhError(6, "k_mnn_post: collector timed out (n_matches < 0)")
         i1 = out.download(np.int32, nm, 64)[:k]; i2 = out.download(np.int32, nm, 64 + 4 * nm)[:k]; dist = out.download(np.float32, nm, 64 + 8 * nm)[:k]
         out.free()
         return i1, i2, dist
