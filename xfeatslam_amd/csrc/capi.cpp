@@ -3,6 +3,7 @@
 // compute entry point fails with XFH_ERR_NO_DEVICE / XFH_ERR_HIP.
 #include "ctx.h"
 
+#include <dlfcn.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -10,6 +11,33 @@
 #include <vector>
 
 int conv_layer_npart(int li, int Hout, int Wout);
+
+// ---- tracing / verbosity switches (ctx.h) ---------------------------------------------------------------------------------
+namespace {
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+};
+Roctx* roctx() {
+    static Roctx* R = []() -> Roctx* {
+        const char* e = getenv("XFH_ROCTX");
+        if (!e || !*e || *e == '0') return nullptr;
+        static Roctx r;
+        for (const char* n : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
+            void* h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (!h) continue;
+            *(void**)(&r.push) = dlsym(h, "roctxRangePushA");
+            *(void**)(&r.pop) = dlsym(h, "roctxRangePop");
+            if (r.push && r.pop) return &r;
+        }
+        return nullptr;
+    }();
+    return R;
+}
+}  // namespace
+void xfh_trace_push(const char* name) { if (Roctx* r = roctx()) r->push(name); }
+void xfh_trace_pop() { if (Roctx* r = roctx()) r->pop(); }
+bool xfh_verbose() { static const bool v = []() { const char* e = getenv("XFH_VERBOSE"); return e && *e && *e != '0'; }(); return v; }
 
 #define HIPCK(c, x) do { hipError_t _e = (x); if (_e != hipSuccess) { (c)->hip_err = std::string(#x) + ": " + hipGetErrorString(_e); return XFH_ERR_HIP; } } while (0)
 
@@ -156,6 +184,8 @@ int xfh_create(const xfh_config* cfg, xfh_ctx** out) {
         if (hipMalloc((void**)&w.h_d1, w.cap_in) != hipSuccess) return fail(XFH_ERR_OUT_OF_MEMORY);
     }
     if (hipStreamSynchronize(c->stream) != hipSuccess) return fail(XFH_ERR_HIP);
+    if (xfh_verbose()) fprintf(stderr, "[xfh] ctx %p: device %d, %dx%d (x32: %dx%d), nfeatures %d, max_batch %d, bn_mode %d, flags %d\n", (void*)c, cfg->device,
+                               cfg->max_height, cfg->max_width, c->Hmax, c->Wmax, cfg->nfeatures, cfg->max_batch, cfg->bn_mode, cfg->flags);
     *out = c;
     return XFH_OK;
 }
@@ -173,7 +203,7 @@ int xfh_destroy(xfh_ctx* c) {
     F(c->d_gray); F(c->X); F(c->pre_part); F(c->xstat);
     for (int i = 0; i < XFH_NUM_LAYERS; ++i) { F(c->raw[i]); F(c->part[i]); F(c->stat[i]); }
     if (!c->is_twin && !c->is_lane) {                    // a twin / pipeline lane borrows the weights of its parent
-        for (int i = 0; i < XFH_NUM_LAYERS; ++i) { F(c->w.mfma[i]); F(c->w.alt[i]); F(c->w.alt2[i]); F(c->w.m16[i]); F(c->w.bn_bias[i]); }
+        for (int i = 0; i < XFH_NUM_LAYERS; ++i) { F(c->w.mfma[i]); F(c->w.alt[i]); F(c->w.alt2[i]); F(c->w.m16[i]); F(c->w.m4[i]); F(c->w.bn_bias[i]); }
         for (int i = 0; i < 3; ++i) F(c->w.direct[i]);
         F(c->w.fus2); F(c->w.fus2_bias); F(c->w.skip_w); F(c->w.skip_b); F(c->w.heat2_w); F(c->w.heat2_b); F(c->w.kp3_w); F(c->w.kp3_b);
     }
@@ -289,6 +319,12 @@ int xfh_load_weights(xfh_ctx* c, const void* blob, size_t nbytes) {
                 rc = upload(c, &c->w.alt2[i], pack_mfma(wp, L.cout, L.cin, L.ks, coutp, 64, 3));
             if (rc == XFH_OK && L.ks == 3 && L.cin >= 64)                                                // 7, 9-14, 16, 17: single-frame form
                 rc = upload(c, &c->w.m16[i], pack_mfma(wp, L.cout, L.cin, L.ks, L.cout, 64, 1, true));
+            if (rc == XFH_OK && L.ks == 3 && L.cout <= 24) {                                           // 3, 4, 5: k_conv4_p: [co][(ky, kx, ci)] in natural k order
+                std::vector<float> o((size_t)L.cout * 9 * L.cin);
+                for (int co = 0; co < L.cout; ++co) for (int ci = 0; ci < L.cin; ++ci) for (int tap = 0; tap < 9; ++tap)
+                    o[((size_t)co * 9 + tap) * L.cin + ci] = wp[((size_t)co * L.cin + ci) * 9 + tap];
+                rc = upload(c, &c->w.m4[i], o);
+            }
             if (rc == XFH_OK && L.ks == 3 && L.cin <= 24 && L.cout == 24)                              // 3, 4, 5: all nine taps in one chunk (persistent kernels, block1.3)
                 rc = upload(c, &c->w.alt[i], pack_mfma(wp, L.cout, L.cin, L.ks, coutp, 64, 9));
         }
@@ -332,6 +368,7 @@ int xfh_load_weights(xfh_ctx* c, const void* blob, size_t nbytes) {
     if (!blob_find(blob, nbytes, "keypoint_head.3.bias", &e) || e.dims[0] != 65) return XFH_ERR_BAD_WEIGHTS;
     if ((rc = upload(c, &c->w.kp3_b, std::vector<float>(e.p, e.p + 65))) != XFH_OK) return rc;
     c->w.loaded = true;
+    if (xfh_verbose()) fprintf(stderr, "[xfh] ctx %p: weights loaded (%zu bytes, bn_mode %d)\n", (void*)c, nbytes, c->cfg.bn_mode);
     if (c->twin) { HIPCK(c, hipStreamSynchronize(c->twin->stream)); if ((rc = ctx_share_weights(c, c->twin)) != XFH_OK) return rc; }
     return pipe_reshare_weights(c);
 }
@@ -364,6 +401,7 @@ int xfh_extract_batch_device(xfh_ctx* c, const uint8_t* d_gray, int B, int H, in
     if (rc != XFH_OK) return rc;
     if (!d_records) return XFH_ERR_INVALID_ARG;
     HIPCK(c, hipSetDevice(c->cfg.device));
+    XfhRange range("xfh:extract_batch_device");
     HIPCK(c, run_extract(c, d_gray, B, H, W, lap0, lap1, (uint8_t*)d_records));
     return XFH_OK;
 }
@@ -373,6 +411,7 @@ int xfh_extract_batch_device_images(xfh_ctx* c, const uint8_t* d_gray, int B, in
     if (rc != XFH_OK) return rc;
     if (!d_records || !d_images || (((uintptr_t)d_images) & 15)) return XFH_ERR_INVALID_ARG;
     HIPCK(c, hipSetDevice(c->cfg.device));
+    XfhRange range("xfh:extract_batch_device_images");
     HIPCK(c, run_extract(c, d_gray, B, H, W, lap0, lap1, (uint8_t*)d_records, true, (float*)d_images));
     return XFH_OK;
 }
@@ -423,6 +462,7 @@ int xfh_extract_submit(xfh_ctx* c, const uint8_t* gray, int H, int W, int stride
         if (rc != XFH_OK) return rc;
         run = c->twin;
     }
+    XfhRange range("xfh:extract_submit");
     HIPCK(c, hipMemcpyAsync(c->s_dgray[k], hg, (size_t)H * W, hipMemcpyHostToDevice, run->stream));
     HIPCK(c, run_extract(run, c->s_dgray[k], 1, H, W, lap0, lap1, c->s_hrec[k], false));
     HIPCK(c, hipEventRecord(c->s_done[k], run->stream));
@@ -500,6 +540,7 @@ int xfh_match_mnn_device(xfh_ctx* c, const float* d1, int n1, const float* d2, i
     if (n1 > 0 && n2 > 0 && (!idx1 || !idx2 || !dist)) return XFH_ERR_INVALID_ARG;
     if ((((uintptr_t)d1) | ((uintptr_t)d2)) & 15) return XFH_ERR_INVALID_ARG;
     HIPCK(c, hipSetDevice(c->cfg.device));
+    XfhRange range("xfh:match_mnn_device");
     HIPCK(c, launch_mnn(c, d1, n1, d2, n2, min_cossim, idx1, idx2, dist, n_matches));
     return XFH_OK;
 }
@@ -522,6 +563,7 @@ int xfh_match_mnn_prepared_device(xfh_ctx* c, const void* image1, int n1, const 
     if (n1 > 0 && n2 > 0 && (!idx1 || !idx2 || !dist)) return XFH_ERR_INVALID_ARG;
     if ((((uintptr_t)image1) | ((uintptr_t)image2)) & 15) return XFH_ERR_INVALID_ARG;
     HIPCK(c, hipSetDevice(c->cfg.device));
+    XfhRange range("xfh:match_mnn_prepared_device");
     HIPCK(c, launch_mnn_prepared(c, (const float*)image1, n1, (const float*)image2, n2, min_cossim, idx1, idx2, dist, n_matches));
     return XFH_OK;
 }
@@ -546,6 +588,7 @@ int xfh_match_mnn(xfh_ctx* c, const float* d1, int n1, const float* d2, int n2, 
     if (n1 == 0 || n2 == 0) { *n_matches = 0; return XFH_OK; }
     if (!d1 || !d2 || !idx1 || !idx2 || !dist) return XFH_ERR_INVALID_ARG;
     HIPCK(c, hipSetDevice(c->cfg.device));
+    XfhRange range("xfh:match_mnn");
     MatchWs& w = c->mws;
     const size_t b1 = (size_t)n1 * 64 * 4, b2 = (size_t)n2 * 64 * 4;
     const size_t b1p = (b1 + 255) & ~(size_t)255;

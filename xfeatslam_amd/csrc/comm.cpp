@@ -10,6 +10,7 @@
 // extraction after the collective that read a record buffer.
 #include "ctx.h"
 #include <dlfcn.h>
+#include <stdio.h>
 #include <string.h>
 #include <vector>
 
@@ -145,6 +146,7 @@ int xfh_comm_create(xfh_ctx* c, const void* unique_id, int rank, int world) {
     ncclUniqueId id; memcpy(&id, unique_id, sizeof id);
     ncclResult_t r = R->CommInitRank(&m->comm, world, id, rank);
     if (r != 0) { c->hip_err = std::string("ncclCommInitRank: ") + R->GetErrorString(r); return bail(XFH_ERR_COMM); }
+    if (xfh_verbose()) fprintf(stderr, "[xfh] ctx %p: communicator rank %d of %d on device %d\n", (void*)c, rank, world, c->cfg.device);
     return XFH_OK;
 }
 
@@ -154,6 +156,7 @@ int xfh_comm_world(xfh_ctx* c) { return c && c->comm ? c->comm->world : 0; }
 // the collective starts when the ctx stream reaches this point (the records are complete)
 static int comm_begin(xfh_ctx* c, int gen) {
     XfhComm* m = c->comm;
+    XfhRange range("xfh:gather_begin");
     HIPCK(c, hipSetDevice(c->cfg.device));
     HIPCK(c, hipEventRecord(m->ev_ready, c->stream));
     HIPCK(c, hipStreamWaitEvent(m->stream, m->ev_ready, 0));

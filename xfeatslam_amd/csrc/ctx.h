@@ -11,6 +11,7 @@ struct DevWeights {
     float* mfma[XFH_NUM_LAYERS] = {};                          // layers 3..22: [chunk][n][CB], k-permuted
     float* alt2[XFH_NUM_LAYERS] = {};                          // third packing: three taps per chunk (small-batch configurations)
     float* m16[XFH_NUM_LAYERS] = {};                           // k_conv_mfma16 packing (single-frame form of the 3x3 stride-1 layers with >= 64 channels): channels permuted in groups of 16
+    float* m4[XFH_NUM_LAYERS] = {};                            // k_conv4_p packing (4x4x1 MFMA, layers with few output channels): [co][(ky, kx, ci)], natural order
     float* alt[XFH_NUM_LAYERS] = {};                           // second packing of some layers (32-channel chunks / all taps in one chunk), see launch_basic_layer
     float* bn_bias[XFH_NUM_LAYERS] = {};                       // XFH_BN_RUNNING_FOLDED: -running_mean * rstd per output channel (rstd is folded into the weights)
     float* fus2 = nullptr;                                     // block_fusion.2 packed like an MFMA layer
@@ -103,6 +104,15 @@ struct xfh_ctx {
     MatchWs mws;
     KTimer timer;
 };
+
+// ---- tracing (the reference has none; these are this build's equivalents) ---------------------------------------
+// XFH_ROCTX=1 in the environment: named roctx ranges around every public phase (librocprofiler-sdk-roctx / libroctx64 opened with
+// dlopen, so there is no link-time dependency): `rocprofv3 --marker-trace` then shows xfh:extract / xfh:match / xfh:batch_submit /
+// xfh:gather with the kernels under them.  XFH_VERBOSE=1: one stderr line per ctx / lane / communicator created and per weight load.
+void xfh_trace_push(const char* name);
+void xfh_trace_pop();
+bool xfh_verbose();
+struct XfhRange { explicit XfhRange(const char* n) { xfh_trace_push(n); } ~XfhRange() { xfh_trace_pop(); } };
 
 // helpers shared by capi.cpp / pipeline.cpp
 int ctx_share_weights(xfh_ctx* parent, xfh_ctx* child);      // child borrows the parent's packed weights (and its eval()-mode statistics)

@@ -24,6 +24,7 @@
 // The caller's buffers should be pinned (xfh_host_alloc / xfh_host_register): with pageable memory the HIP runtime stages
 // every copy through its own bounce buffers and blocks the calling thread -- still correct, much slower.
 #include "ctx.h"
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -72,6 +73,7 @@ static int pipe_ready(xfh_ctx* c, int want) {
             if (rs != XFH_OK) { xfh_destroy(t); L = PipeLane(); return rs; }
         }
         ++P.nlanes;                                   // from here on pipe_destroy cleans the lane up
+        if (xfh_verbose()) fprintf(stderr, "[xfh] ctx %p: pipeline lane %d = ctx %p\n", (void*)c, P.nlanes - 1, (void*)L.ctx);
         for (int k = 0; k < XFH_PIPE_MAX_BATCHES; ++k) HIPCK(c, hipEventCreateWithFlags(&L.done[k], hipEventDisableTiming));
     }
     return XFH_OK;
@@ -109,6 +111,7 @@ int xfh_extract_batch_submit(xfh_ctx* c, const uint8_t* gray, int B, int H, int 
     const int S = c->cfg.max_batch, nsub = (B + S - 1) / S, nl = nsub < P.max_lanes ? nsub : P.max_lanes;
     int rc = pipe_ready(c, nl);
     if (rc != XFH_OK) return rc;
+    XfhRange range("xfh:batch_submit");
     const size_t rec = xfh_record_bytes(c->cfg.nfeatures), fb = (size_t)H * W;
     const int slot = (P.b_head + P.b_count) % XFH_PIPE_MAX_BATCHES;
     unsigned used = 0;
