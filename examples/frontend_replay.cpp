@@ -11,6 +11,12 @@
 //   frontend_replay weights.xfhw --synthetic N H W [--dump file]     N synthetic frames (texture drifting 2 px per frame)
 //   --dump: per frame n_valid, keypoint (x, y) pairs, then per pair the (idx1, idx2, dist) match list, as little-endian
 //        records -- tests/test_gpu_dropin_cpp.py recomputes them with the oracle.
+//   --fast: the library's device-resident path through the C ABI instead of the drop-in classes: the frame goes up once,
+//        xfh_extract_batch_device_images leaves the record AND the matcher's prepared image of its descriptors in HBM, the match against the
+//        previous frame is xfh_match_mnn_prepared_device on the two images (two launches, no descriptor ever crosses PCIe, no normalisation
+//        pass), and only the keypoints (header + 28 B per row) and the match list come back.  Same keypoints and the same match lists as the
+//        default mode, bit for bit.  --valid-only (with --fast): xfh_match_records_device, i.e. pairs that touch a padding slot are dropped
+//        (NOT what the reference's match() returns).
 //
 // Build: g++ -std=c++17 -O2 -Iinclude examples/frontend_replay.cpp -Lxfeatslam_amd -lxfeat_hip -lz -o frontend_replay
 #define XFEAT_NO_OPENCV 1
@@ -55,9 +61,12 @@ static void synth_frame(Mat& im, int H, int W, int t) {        // smooth texture
 int main(int argc, char** argv) {
     if (argc < 4) { fprintf(stderr, "usage: see the header of examples/frontend_replay.cpp\n"); return 2; }
     FILE* dump = nullptr;
-    for (int i = 4; i + 1 < argc; ++i) {
-        if (std::string(argv[i]) == "--dump") dump = fopen(argv[i + 1], "wb");
-        if (std::string(argv[i]) == "--rgb") g_rgb = atoi(argv[i + 1]);
+    bool fast = false, valid_only = false;
+    for (int i = 4; i < argc; ++i) {
+        if (std::string(argv[i]) == "--dump" && i + 1 < argc) dump = fopen(argv[i + 1], "wb");
+        if (std::string(argv[i]) == "--rgb" && i + 1 < argc) g_rgb = atoi(argv[i + 1]);
+        if (std::string(argv[i]) == "--fast") fast = true;
+        if (std::string(argv[i]) == "--valid-only") valid_only = true;
     }
     const int nfeatures = getenv("XFH_NFEATURES") ? atoi(getenv("XFH_NFEATURES")) : 1000;     // TUM1.yaml: ORBextractor.nFeatures 1000
     std::vector<std::string> files;
@@ -80,13 +89,55 @@ int main(int argc, char** argv) {
     std::vector<double> vTimesTrack(n);
     long total_matches = 0, total_valid = 0, total_inliers = 0;
     auto put = [&](const void* p, size_t n) { if (dump) fwrite(p, 1, n, dump); };
+    // --fast: device buffers of the C ABI path (two generations: frame t and frame t - 1)
+    xfh_ctx* ctx = extractor.context();
+    const size_t rec_bytes = xfh_record_bytes(nfeatures), img_bytes = xfh_match_image_bytes(nfeatures);
+    void* d_gray = nullptr; void* d_rec[2] = {nullptr, nullptr}; void* d_img[2] = {nullptr, nullptr}; void* d_out = nullptr;
+    std::vector<unsigned char> h_head(xfh_record_desc_offset(nfeatures));
+    std::vector<int> h_i1(nfeatures), h_i2(nfeatures); std::vector<float> h_d(nfeatures);
+    if (fast) {
+        bool ok = xfh_dev_alloc(&d_gray, (size_t)im.rows * im.cols) == XFH_OK && xfh_dev_alloc(&d_out, (size_t)nfeatures * 12 + 64) == XFH_OK;
+        for (int g = 0; g < 2; ++g) ok = ok && xfh_dev_alloc(&d_rec[g], rec_bytes) == XFH_OK && xfh_dev_alloc(&d_img[g], img_bytes) == XFH_OK;
+        if (!ok) { fprintf(stderr, "out of device memory\n"); return 1; }
+    }
+    int prev_valid = 0;
     for (int ni = 0; ni < n; ++ni) {
         if (nsyn) synth_frame(im, H, W, ni); else if (!load_frame(files[ni], im)) { fprintf(stderr, "cannot read %s\n", files[ni].c_str()); return 2; }
         const auto t1 = std::chrono::steady_clock::now();
-        const int ret = extractor(im, Mat(), keys, desc, lap);
-        if (ret < 0) { fprintf(stderr, "empty image at %d\n", ni); return 1; }
         matches.clear();
-        if (!prev.empty() && !desc.empty()) { matcher.match(prev, desc, matches); total_matches += (long)matches.size(); }
+        if (!fast) {
+            const int ret = extractor(im, Mat(), keys, desc, lap);
+            if (ret < 0) { fprintf(stderr, "empty image at %d\n", ni); return 1; }
+            if (!prev.empty() && !desc.empty()) matcher.match(prev, desc, matches);
+        } else {
+            const int g = ni & 1;
+            char* o = (char*)d_out;
+            int rc = xfh_memcpy_h2d(d_gray, im.data, (size_t)im.rows * im.cols);
+            if (rc == XFH_OK) rc = xfh_extract_batch_device_images(ctx, (const uint8_t*)d_gray, 1, im.rows, im.cols, lap[0], lap[1], d_rec[g], d_img[g]);
+            const bool have_pair = ni > 0 && prev_valid > 0;          // (the reference releases the descriptors of a frame without keypoints: nothing to match)
+            if (rc == XFH_OK && have_pair) {
+                if (valid_only) rc = xfh_match_records_device(ctx, d_rec[g ^ 1], d_img[g ^ 1], d_rec[g], d_img[g], -1.f, (int*)(o + 64), (int*)(o + 64 + 4 * (size_t)nfeatures),
+                                                              (float*)(o + 64 + 8 * (size_t)nfeatures), (int*)o);
+                else rc = xfh_match_mnn_prepared_device(ctx, d_img[g ^ 1], nfeatures, d_img[g], nfeatures, -1.f, (int*)(o + 64), (int*)(o + 64 + 4 * (size_t)nfeatures),
+                                                        (float*)(o + 64 + 8 * (size_t)nfeatures), (int*)o);
+            }
+            if (rc == XFH_OK) rc = xfh_synchronize(ctx);
+            if (rc == XFH_OK) rc = xfh_memcpy_d2h(h_head.data(), d_rec[g], h_head.size());       // header + keypoints: 28 B per row, no descriptors
+            if (rc != XFH_OK) { fprintf(stderr, "fast path: %s (%s)\n", xfh_strerror(rc), xfh_last_hip_error(ctx)); return 1; }
+            const int* hdr = (const int*)h_head.data();
+            const xfh_keypoint* kp = (const xfh_keypoint*)(h_head.data() + xfh_record_kps_offset());
+            keys.resize(nfeatures);
+            for (int q = 0; q < nfeatures; ++q) { keys[q].pt.x = kp[q].x; keys[q].pt.y = kp[q].y; keys[q].size = kp[q].size; keys[q].angle = kp[q].angle; keys[q].response = kp[q].response; keys[q].octave = kp[q].octave; keys[q].class_id = kp[q].class_id; }
+            int nm = 0;
+            if (have_pair && hdr[0] > 0) {
+                xfh_memcpy_d2h(&nm, o, 4);
+                if (nm < 0 || nm > nfeatures) { fprintf(stderr, "fast path: the matcher reported a time-out\n"); return 1; }
+                if (nm > 0) { xfh_memcpy_d2h(h_i1.data(), o + 64, 4 * (size_t)nm); xfh_memcpy_d2h(h_i2.data(), o + 64 + 4 * (size_t)nfeatures, 4 * (size_t)nm); xfh_memcpy_d2h(h_d.data(), o + 64 + 8 * (size_t)nfeatures, 4 * (size_t)nm); }
+                for (int q = 0; q < nm; ++q) matches.emplace_back(XFmatcher::DMatch(h_i1[q], h_i2[q], h_d[q]));
+            }
+            prev_valid = hdr[0];
+        }
+        total_matches += (long)matches.size();
         const auto t2 = std::chrono::steady_clock::now();
         vTimesTrack[ni] = std::chrono::duration_cast<std::chrono::duration<double>>(t2 - t1).count();
         int nv = 0;
@@ -119,6 +170,7 @@ int main(int argc, char** argv) {
     std::sort(vTimesTrack.begin(), vTimesTrack.end());                                         // rgbd_tum.cc:128-139
     double tot = 0; for (double t : vTimesTrack) tot += t;
     if (dump) fclose(dump);
+    if (fast) { xfh_dev_free(d_gray); xfh_dev_free(d_out); for (int g = 0; g < 2; ++g) { xfh_dev_free(d_rec[g]); xfh_dev_free(d_img[g]); } }
     printf("-------\n\nframes: %d  keypoints/frame: %.1f  mutual matches/frame pair: %.1f  inliers/frame pair: %.1f\n", n, (double)total_valid / n,
            n > 1 ? (double)total_matches / (n - 1) : 0.0, n > 1 ? (double)total_inliers / (n - 1) : 0.0);
     printf("median front-end time: %f\nmean front-end time: %f\n", vTimesTrack[n / 2], tot / n);

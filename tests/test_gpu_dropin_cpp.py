@@ -102,6 +102,25 @@ def test_frontend_replay_matches_oracle(gpu_lib, oracle_mod, tmp_path):
             assert len(m) == 0
         prev = (ok, od)
     assert "median displacement (-8.0, 0.0)" in r.stdout
+    # --fast: the device-resident path of the library (record + prepared match image stay in HBM, two-launch match, only keypoints and
+    # match lists come back) must dump the very same bytes; --valid-only drops the pairs that touch a padding slot
+    dump_fast = str(tmp_path / "dump_fast.bin")
+    rf = subprocess.run([exe, str(tmp_path / "w.xfhw"), str(tmp_path / "assoc.txt"), str(tmp_path), "--dump", dump_fast, "--fast"], capture_output=True, text=True,
+                        env=dict(os.environ, XFH_NFEATURES=str(nf)))
+    assert rf.returncode == 0, rf.stderr
+    assert open(dump_fast, "rb").read() == open(dump, "rb").read()
+    dump_valid = str(tmp_path / "dump_valid.bin")
+    rv = subprocess.run([exe, str(tmp_path / "w.xfhw"), str(tmp_path / "assoc.txt"), str(tmp_path), "--dump", dump_valid, "--fast", "--valid-only"], capture_output=True,
+                        text=True, env=dict(os.environ, XFH_NFEATURES=str(nf)))
+    assert rv.returncode == 0, rv.stderr
+    fv = _read_dump(dump_valid, n)
+    dropped = 0
+    for i in range(1, n):
+        (_, kp0, _), (_, kp1, m_all), (_, _, m_val) = frames[i - 1], frames[i], fv[i]
+        keep = (kp0[m_all["q"], 2] > 0) & (kp1[m_all["t"], 2] > 0)                 # both ends are real keypoints (size 1; padding rows have size 0)
+        assert np.array_equal(m_val["q"], m_all["q"][keep]) and np.array_equal(m_val["t"], m_all["t"][keep]) and np.array_equal(m_val["d"], m_all["d"][keep], equal_nan=True), i
+        dropped += int((~keep).sum())
+    assert all(np.array_equal(fv[i][1], frames[i][1]) for i in range(n))
 
 
 def test_frontend_replay_example(gpu_lib, tmp_path):

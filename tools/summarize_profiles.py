@@ -35,13 +35,36 @@ def pmc(d, name):
                 out[r["Kernel_Name"]].append(float(r["Counter_Value"]))
     return out
 
+# ---- calibration (tools/pmc_calib.sh): counter value of kernels that move exactly 1 GiB per launch, per access width
+CAL_BYTES = float(1 << 30)
+CAL_MODES = {"k_calib<0>": ("read", 4), "k_calib<1>": ("read", 16), "k_calib<4>": ("read", 32), "k_calib<2>": ("write", 4), "k_calib<3>": ("write", 16), "k_calib<5>": ("write", 32)}
+calib = {}
+for (d, name) in (("calib_fetch", "FETCH_SIZE"), ("calib_write", "WRITE_SIZE")):
+    for k, v in pmc(d, name).items():
+        for tag_, (kind, width) in CAL_MODES.items():
+            if tag_ in k:
+                raw = sum(v) / len(v)
+                e = calib.setdefault(f"{kind}_{width}B_per_lane", {})
+                e[name + "_kib_raw"] = raw
+                e[name + "_bytes_per_true_byte"] = raw * 1024.0 / CAL_BYTES
+FF, WF = 2.0, 1.0          # factors that turn the raw KiB counters into bytes (defaults: the guide's gfx950 note; WRITE uncalibrated)
+cal_note = "no calibration run found: FETCH x2 (MI355X_MICROARCH.md, HBM), WRITE x1 uncalibrated"
+if calib.get("read_16B_per_lane", {}).get("FETCH_SIZE_bytes_per_true_byte") and calib.get("write_16B_per_lane", {}).get("WRITE_SIZE_bytes_per_true_byte"):
+    FF = 1.0 / calib["read_16B_per_lane"]["FETCH_SIZE_bytes_per_true_byte"]
+    WF = 1.0 / calib["write_16B_per_lane"]["WRITE_SIZE_bytes_per_true_byte"]
+    cal_note = ("factors from tools/pmc_calib.sh on this box: kernels that read / write exactly 1 GiB per launch with 16 bytes per lane (the access width of "
+                "nearly every load / store of the extraction); the other widths are listed in `calibration`")
+if calib:
+    print("calibration:", json.dumps(calib), "-> FETCH x%.3f WRITE x%.3f" % (FF, WF))
+
 fetch, write = pmc("pmc_fetch", "FETCH_SIZE"), pmc("pmc_write", "WRITE_SIZE")
 if fetch or write:
     per = {}
     for k in set(fetch) | set(write):
         fe = sum(fetch[k]) / len(fetch[k]) if fetch.get(k) else 0.0
         wr = sum(write[k]) / len(write[k]) if write.get(k) else 0.0
-        per[k] = {"fetch_kib_raw": fe, "write_kib_raw": wr, "hbm_bytes_per_launch": (2.0 * fe + wr) * 1024.0, "launches": len(fetch.get(k, write.get(k, [])))}
+        per[k] = {"fetch_kib_raw": fe, "write_kib_raw": wr, "fetch_bytes": FF * fe * 1024.0, "write_bytes": WF * wr * 1024.0,
+                  "hbm_bytes_per_launch": (FF * fe + WF * wr) * 1024.0, "launches": len(fetch.get(k, write.get(k, [])))}
     def pick(sub):
         for k, v in per.items():
             if sub in k:
@@ -68,10 +91,10 @@ if fetch or write:
     ff, fw = grid_frames("pmc_fetch"), grid_frames("pmc_write")
     tot_f = sum(sum(v) for k, v in fetch.items() if not any(m in k for m in MATCH))
     tot_w = sum(sum(v) for k, v in write.items() if not any(m in k for m in MATCH))
-    per_frame = (2.0 * tot_f / ff + tot_w / fw) * 1024.0 if ff and fw else None
+    per_frame = (FF * tot_f / ff + WF * tot_w / fw) * 1024.0 if ff and fw else None
     js = {"extract_hbm_bytes_per_frame": per_frame, "extract_frames_counted": [ff, fw],
-          "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch "
-                    "(gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md §HBM; WRITE_SIZE uncalibrated)",
+          "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; bytes = (fetch_factor * FETCH_SIZE + write_factor * WRITE_SIZE) * 1024 per launch; " + cal_note,
+          "fetch_factor": FF, "write_factor": WF, "calibration": calib,
           "conv_batch": B, "conv_bytes_per_launch": pick("k_conv_mfma<64, 64, 3, 1, 4, 2, 1, 16, 1, 0, 32"),
           "gemm_bytes_per_launch": pick("k_mnn_gemm"), "per_kernel": per}
     json.dump(js, open(os.path.join(P, "pmc_traffic.json"), "w"), indent=1)

@@ -122,9 +122,35 @@ int xfh_create(const xfh_config* cfg, xfh_ctx** out) {
     auto fail = [&](int code) { xfh_destroy(c); return code; };
 #define A(ptr, bytes) do { if (hipMalloc((void**)&(ptr), (bytes)) != hipSuccess) return fail(XFH_ERR_OUT_OF_MEMORY); } while (0)
     if (hipSetDevice(cfg->device) != hipSuccess) return fail(XFH_ERR_HIP);
-    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) return fail(XFH_ERR_HIP);
+    {
+        // XFH_CU_MASKS="lo-hi,lo-hi,..." (measurement knob, tools/cu_mask_ab.sh): the k-th ctx created in this process runs its streams on
+        // the CUs [lo, hi] of entry k mod n only (hipExtStreamCreateWithCUMask).  Unset (the default): all CUs.
+        static std::atomic<int> created{0};
+        uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        bool masked = false;
+        if (const char* e = getenv("XFH_CU_MASKS")) {
+            std::vector<std::pair<int, int>> rg;
+            for (const char* p = e; *p;) {
+                int lo = 0, hi = 0, n = 0;
+                if (sscanf(p, "%d-%d%n", &lo, &hi, &n) == 2 && lo >= 0 && hi >= lo && hi < 256) rg.push_back({lo, hi});
+                p += n > 0 ? n : 1;
+                while (*p == ',') ++p;
+            }
+            if (!rg.empty()) {
+                const auto r = rg[(size_t)created.fetch_add(1) % rg.size()];
+                for (int cu = r.first; cu <= r.second; ++cu) mask[cu >> 5] |= 1u << (cu & 31);
+                masked = true;
+            }
+        }
+        if (masked) {
+            if (hipExtStreamCreateWithCUMask(&c->own_stream, 8, mask) != hipSuccess) return fail(XFH_ERR_HIP);
+            if (hipExtStreamCreateWithCUMask(&c->aux_stream, 8, mask) != hipSuccess) return fail(XFH_ERR_HIP);
+        } else {
+            if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) return fail(XFH_ERR_HIP);
+            if (hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) != hipSuccess) return fail(XFH_ERR_HIP);
+        }
+    }
     c->stream = c->own_stream;
-    if (hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) != hipSuccess) return fail(XFH_ERR_HIP);
     if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) return fail(XFH_ERR_HIP);
     if (hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) return fail(XFH_ERR_HIP);
     if (hipEventCreateWithFlags(&c->ev_out, hipEventDisableTiming) != hipSuccess) return fail(XFH_ERR_HIP);

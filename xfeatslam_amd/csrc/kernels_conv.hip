@@ -199,6 +199,12 @@ void k_block1_stats(const float* __restrict__ X, size_t x_stride, StatSrc xs, in
 // FOLD (small batches, PRO_BN): the workgroup folds the producer's statistic partials itself (LDS); otherwise the
 // finalised statistics come through the scalar cache -- staging them through LDS first would put a second dependent
 // memory round trip into every workgroup's latency chain, which is what bounds these kernels (measured 3.5x slower).
+// workgroup x of n -> tile: the workgroups x = k (mod 8) -- one XCD -- take the k-th contiguous eighth of the tile sequence (a bijection)
+__device__ __forceinline__ int xcd_tile(int x, int n) {
+    const int k = x & 7, q = n >> 3, r = n & 7;
+    return k * q + (k < r ? k : r) + (x >> 3);
+}
+
 template <int CIN, int COUT, int ST, int PRO, bool FOLD, int EPI>
 __global__ __launch_bounds__(256)
 void k_conv_direct(ConvArgs a) {
@@ -214,7 +220,11 @@ void k_conv_direct(ConvArgs a) {
     __shared__ __attribute__((aligned(16))) float s_xwin[PRO == PRO_L0 ? XW * XS : 1];
     __shared__ double s_red[FOLD ? 512 : 8 * COUT];
     const int t = threadIdx.x, b = blockIdx.z;
-    const int tile = blockIdx.x, tx0 = (tile % a.tiles_x) * 16, ty0 = (tile / a.tiles_x) * 16;
+    // XCD-aware tile order.  Workgroups go round robin over the eight XCDs (each with its own L2), so with the plain order two
+    // neighbouring tiles never share an L2 and every halo line is fetched twice from the fabric: calibrated counters
+    // (profiles/pmc_traffic.json) read 2.55x the algorithmic fetch bytes for block1.2, and at that traffic the kernel sits at 84 % of the
+    // memory rate.  Workgroup x therefore takes tile  (x & 7) * n / 8 + (x >> 3): XCD k walks a contiguous eighth of the tile sequence.
+    const int tile = xcd_tile(blockIdx.x, gridDim.x), tx0 = (tile % a.tiles_x) * 16, ty0 = (tile / a.tiles_x) * 16;
     const float* in = a.in + (size_t)b * a.in_stride;
     __shared__ float s_stat[FOLD ? 2 * CIN : 1];
     if constexpr (FOLD) stage_stat(a.st, b, CIN, tile == 0, s_stat, s_red, t, 256);                // s_red is free until the epilogue
