@@ -25,6 +25,9 @@ rm -rf $O/prof $O/pmc_fetch $O/pmc_write $O/prof_serial
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o bench -- python $R/bench.py --steps 3 --warmup 1 --match-iters 10 --cpu-frames 0 --only-match-leg ) > $O/pmc_fetch.json 2> $O/pmc_fetch.err
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o bench -- python $R/bench.py --steps 3 --warmup 1 --match-iters 10 --cpu-frames 0 --only-match-leg ) > $O/pmc_write.json 2> $O/pmc_write.err
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/prof_serial -o bench -- python $R/bench.py --streams 1 --batch 256 --serial-branch --no-bn-leg --steps 10 --warmup 3 --match-iters 10 --cpu-frames 0 ) > $O/bench_prof_serial.json 2> $O/bench_prof_serial.err
+bash tools/pmc_calib.sh > $O/pmc_calib.out 2>&1
+( timeout 200 python tools/host_batch_probe.py 512 "64x4,64x3,32x4,128x2" ) > $O/host_batch_probe.log 2>&1
+( timeout 100 python tools/pcie_probe.py ) > $O/pcie_probe.log 2>&1
 python tools/queue_view.py $(ls $O/prof/*kernel_trace.csv | head -1) > $O/queue_view.txt 2>&1
 ls $O/prof $O/pmc_fetch $O/pmc_write $O/prof_serial
 echo round done

@@ -27,7 +27,7 @@ agg = collections.defaultdict(list)
 for r in csv.DictReader(open(f)):
     gz, gx = int(r["Grid_Size_Z"]), int(r["Grid_Size_X"]) // max(int(r["Workgroup_Size_X"]), 1)
     n = r["Kernel_Name"]
-    batched = gz == B or (gx == B and any(k in n for k in ("k_bn_finalize", "k_select"))) or "k_conv_mfma_p" in n   # persistent kernels only run for B > 8
+    batched = gz == B or (gx == B and any(k in n for k in ("k_bn_finalize", "k_select"))) or "k_conv_mfma_p" in n or "k_chain1x1" in n   # persistent kernels only run for B > 8
     if batched or any(k in n for k in ("k_mnn", "k_rownorm", "k_dist_mfma", "k_best2_csr", "k_distinctive_csr")):
         agg[n].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 steps = len(agg[[k for k in agg if "k_preproc" in k][0]])
@@ -37,8 +37,20 @@ for n, d in agg.items():
     MATCH = ("k_mnn", "k_rownorm", "k_dist_mfma", "k_best2_csr", "k_distinctive_csr")
     per_step = len(d) / steps if not any(k in n for k in MATCH) else 1
     flops = bytes_ = None; bound = "latency"
+    m4 = re.match(r"void k_conv4_p<(\d+), (\d+), (\d+)", n)
     m = re.match(r"void k_conv_(mfma_p|mfma|direct)<(\d+), (\d+), (\d+), (\d+)(?:, (\d+), (\d+), (\d+), (\d+))?", n)
-    if m:
+    if m4:                                            # 4x4x1 MFMA form of the 3x3 layers with few output channels
+        cin, cout, st = int(m4.group(1)), int(m4.group(2)), int(m4.group(3))
+        ho, wo = L[(cin, cout, 3, st)]
+        flops = 2.0 * ho * wo * cout * cin * 9 * B
+        bytes_ = 4.0 * B * (ho * st * wo * st * cin + ho * wo * cout)
+        bound = "mfma" if flops / bytes_ > PEAK_TF / PEAK_TB else "hbm"
+    elif "k_chain1x1" in n:                           # block_fusion.2 -> heatmap_head.0 in one pass: two 1x1 64->64 layers, feats written, raw map written
+        ho, wo = L[(64, 64, 1, 1)]
+        flops = 2 * 2.0 * ho * wo * 64 * 64 * B
+        bytes_ = 4.0 * B * ho * wo * 64 * 3
+        bound = "hbm"
+    elif m:
         if m.group(1) != "direct":
             cin, cout, k, st, ww = int(m.group(2)), int(m.group(3)), int(m.group(4)), int(m.group(5)), int(m.group(9))
         else:

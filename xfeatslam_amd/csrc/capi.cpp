@@ -229,7 +229,7 @@ int xfh_destroy(xfh_ctx* c) {
     F(c->d_gray); F(c->X); F(c->pre_part); F(c->xstat);
     for (int i = 0; i < XFH_NUM_LAYERS; ++i) { F(c->raw[i]); F(c->part[i]); F(c->stat[i]); }
     if (!c->is_twin && !c->is_lane) {                    // a twin / pipeline lane borrows the weights of its parent
-        for (int i = 0; i < XFH_NUM_LAYERS; ++i) { F(c->w.mfma[i]); F(c->w.alt[i]); F(c->w.alt2[i]); F(c->w.m16[i]); F(c->w.m4[i]); F(c->w.bn_bias[i]); }
+        for (int i = 0; i < XFH_NUM_LAYERS; ++i) { F(c->w.mfma[i]); F(c->w.alt[i]); F(c->w.alt2[i]); F(c->w.m16[i]); F(c->w.bn_bias[i]); }
         for (int i = 0; i < 3; ++i) F(c->w.direct[i]);
         F(c->w.fus2); F(c->w.fus2_bias); F(c->w.skip_w); F(c->w.skip_b); F(c->w.heat2_w); F(c->w.heat2_b); F(c->w.kp3_w); F(c->w.kp3_b);
     }
@@ -345,12 +345,6 @@ int xfh_load_weights(xfh_ctx* c, const void* blob, size_t nbytes) {
                 rc = upload(c, &c->w.alt2[i], pack_mfma(wp, L.cout, L.cin, L.ks, coutp, 64, 3));
             if (rc == XFH_OK && L.ks == 3 && L.cin >= 64)                                                // 7, 9-14, 16, 17: single-frame form
                 rc = upload(c, &c->w.m16[i], pack_mfma(wp, L.cout, L.cin, L.ks, L.cout, 64, 1, true));
-            if (rc == XFH_OK && L.ks == 3 && L.cout <= 24) {                                           // 3, 4, 5: k_conv4_p: [co][(ky, kx, ci)] in natural k order
-                std::vector<float> o((size_t)L.cout * 9 * L.cin);
-                for (int co = 0; co < L.cout; ++co) for (int ci = 0; ci < L.cin; ++ci) for (int tap = 0; tap < 9; ++tap)
-                    o[((size_t)co * 9 + tap) * L.cin + ci] = wp[((size_t)co * L.cin + ci) * 9 + tap];
-                rc = upload(c, &c->w.m4[i], o);
-            }
             if (rc == XFH_OK && L.ks == 3 && L.cin <= 24 && L.cout == 24)                              // 3, 4, 5: all nine taps in one chunk (persistent kernels, block1.3)
                 rc = upload(c, &c->w.alt[i], pack_mfma(wp, L.cout, L.cin, L.ks, coutp, 64, 9));
         }

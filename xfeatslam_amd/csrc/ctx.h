@@ -11,7 +11,6 @@ struct DevWeights {
     float* mfma[XFH_NUM_LAYERS] = {};                          // layers 3..22: [chunk][n][CB], k-permuted
     float* alt2[XFH_NUM_LAYERS] = {};                          // third packing: three taps per chunk (small-batch configurations)
     float* m16[XFH_NUM_LAYERS] = {};                           // k_conv_mfma16 packing (single-frame form of the 3x3 stride-1 layers with >= 64 channels): channels permuted in groups of 16
-    float* m4[XFH_NUM_LAYERS] = {};                            // k_conv4_p packing (4x4x1 MFMA, layers with few output channels): [co][(ky, kx, ci)], natural order
     float* alt[XFH_NUM_LAYERS] = {};                           // second packing of some layers (32-channel chunks / all taps in one chunk), see launch_basic_layer
     float* bn_bias[XFH_NUM_LAYERS] = {};                       // XFH_BN_RUNNING_FOLDED: -running_mean * rstd per output channel (rstd is folded into the weights)
     float* fus2 = nullptr;                                     // block_fusion.2 packed like an MFMA layer

@@ -856,262 +856,6 @@ void k_conv_mfma_p(ConvArgs a, int ntile, int total) {
 }
 
 // ------------------------------------------------------------------------------------
-// k_conv4_p: the 3x3 layers with FEW OUTPUT CHANNELS (24: block2.0 / block2.1; 24 <- 8: block1.3; 8: block1.2) on
-// v_mfma_f32_4x4x1_16b_f32, persistent, batches > 8.  A 32x32x2 (or 16x16x4) tile pads 24 output channels to 32: a quarter of every
-// MFMA of those layers multiplied zeros (k_conv_mfma_p<24,24,...>: 46 % of the matrix peak, 16 % of a 256-frame step).  The 16-block
-// form computes sixteen independent 4 x 4 outer products per instruction: lane l = (block l >> 2, i = l & 3) supplies A[block][i] and
-// B[block][i], and lane (block, j), register v returns D[block][v][j].  With the SAME four weights in every block it is
-// 64 pixels x 4 output channels x 1 k per instruction, i.e. N comes in steps of 4 -- 24 channels are six groups, nothing is padded --
-// at the rate of the big tiles (tools/probes/mfma4_probe.hip: 147-155 TFLOP/s, with the LDS operand pattern below 154.9; every
-// output is one fp32 fma per k, so a chain of them IS the sequential fma chain in (ky, kx, ci) order: 0 mismatches in 25 600 outputs).
-//   wave  = NBY pixel blocks of 4 rows x 16 columns stacked vertically (lane l <-> pixel (l >> 4, l & 15) of each block), all COUT / 4
-//           channel groups: NBY * COUT / 4 accumulators of 4 registers.  Per 4 k: NBY + COUT / 4 ds_read_b128 feed 4 * NBY * COUT / 4 MFMAs
-//           of 8 cycles (NBY = 3, COUT = 24: 9 reads per 576 cycles and wave; LDS 50 % busy at one wave per SIMD).
-//   A     = the activated input tile in LDS, natural channel order, pixels UNPADDED (stride CIN floats, CIN / 4 = 2 or 6) and a row pitch
-//           RP with RP / 4 odd.  A ds_read_b128 is served in the lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} (+32): eight lanes of
-//           one pixel row (columns 0-3 and 12-15, or 4-11: their 16-byte slots c * CIN / 4 mod 16 are the eight even ones) and eight of
-//           the next row (the odd pitch moves them to the eight odd slots) -- sixteen different slots, no conflict, no padding: the
-//           24-channel tile of 18 x 34 pixels is 59 KB instead of 69, which is what lets TWO workgroups share a CU (below).
-//   B     = all weights in LDS once per workgroup, [co][K + 4] (K = 9 * CIN in (ky, kx, ci) order, row stride / 4 odd): lane l reads the
-//           row of channel 4 g + (l & 3): four addresses per instruction, broadcast over the sixteen blocks.
-//   D     = lane (l >> 2, l & 3), register v: pixel 4 * (l >> 2) + v of the block = (row l >> 4, column 4 * ((l >> 2) & 3) + v),
-//           channel 4 g + (l & 3).
-// Persistent like k_conv_mfma_p: weights once, tiles  blockIdx.x, blockIdx.x + gridDim.x, ...  over frames x tiles, the global loads of
-// the next tile in flight during the MFMAs of the current one; statistics partials per tile (fp64, folded by k_bn_finalize).
-// Occupancy is the crux: a tile costs 112-96 bytes of LDS per pixel, so a CU holds 8 waves only as two workgroups of 4 (16 x 32 pixels
-// each, 81.7 KB: measured with ONE 24 x 32-pixel workgroup per CU the staging, store and statistics phases, 35 % of the kernel, had
-// nothing to overlap with and the kernel was no faster than the padded 32x32x2 form, 715 vs 702 us per 256 frames).
-template <int CIN, int COUT, int ST, int NBY, int WMY, int WMX, int PRO, int EPI>
-__global__ __launch_bounds__(64 * WMY * WMX, 2)
-void k_conv4_p(ConvArgs a, int ntile, int total) {
-    static_assert(CIN % 8 == 0 && COUT % 4 == 0 && (ST == 1 || ST == 2), "shape");
-    static_assert(PRO == PRO_BN || PRO == PRO_B2IN, "prologue");
-    constexpr int NW = WMY * WMX, NTHR = 64 * NW;
-    constexpr int NG = COUT / 4;
-    constexpr int TH = 4 * NBY * WMY, TW = 16 * WMX;
-    constexpr int TIH = (TH - 1) * ST + 3, TIW = (TW - 1) * ST + 3;
-    constexpr int CP = CIN;                                      // pixel stride: no padding (see the header: rows of different parity separate the lanes)
-    constexpr int K = 9 * CIN;
-    constexpr int WS = ((K + 4) / 4) % 2 ? K + 4 : K + 8;
-    static_assert(ST == 1, "stride 2 needs the parity-plane tile (not instantiated yet)");
-    constexpr int PLW = TIW;                                     // pixels per tile row
-    constexpr int PP = ((PLW * CP / 4) % 2 ? PLW * CP : PLW * CP + 4);      // row pitch in floats with PP / 4 odd
-    constexpr int RP = PP;                                       // pitch of one input row
-    constexpr int IN_FLOATS = TIH * RP;
-    constexpr int W_FLOATS = COUT * WS;
-    constexpr int G = CIN / 8;
-    constexpr int NITEM = TIH * TIW * G;
-    constexpr int NE = NTHR / G * G;                             // staging threads: a multiple of G, so that a thread keeps one channel group
-    constexpr int NIT = (NITEM + NE - 1) / NE;
-    static_assert(NIT <= 32, "inside mask");
-    static_assert((CP / 4) % 4 == 2 && (RP / 4) % 2 == 1 && (WS / 4) % 2 == 1, "conflict-free operand reads");
-
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* s_w = smem;                                           // weights first: every operand read of the K loop then is base + a 16-bit immediate offset
-    float* s_in = smem + W_FLOATS;
-    double* s_red = (double*)(s_in + IN_FLOATS);                 // [NW][COUT][2]
-
-    const int t = threadIdx.x;
-    for (int f = t; f < COUT * (K / 4); f += NTHR) {             // all weights, once: global [co][K] -> LDS rows of WS floats
-        const int n = f / (K / 4), c4 = f % (K / 4);
-        *(f32x4*)(s_w + n * WS + c4 * 4) = *(const f32x4*)(a.w + (size_t)f * 4);
-    }
-    const int g8 = t % G;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
-    const int wy = wave / WMX, wx = wave % WMX;
-    const int lr = lane >> 4, lc = lane & 15, lj = lane & 3;
-
-    // Staging.  Item k of thread t is pixel (item / G) of the input tile, channel group g8 -- the same tile position for every tile,
-    // so its coordinates are recomputed from t where they are needed instead of living in registers across the K loop (the kernel
-    // runs at 256 registers per wave for two waves per SIMD: with per-item pointers and masks kept alive hipcc spilled to scratch and
-    // serialised every prefetch load behind a vmcnt(0)).  Loads are branch-free (clamped addresses), so all of a tile's loads are in
-    // flight together; what lies outside the image is zeroed when the tile is written to LDS.
-    f32x4 v0[NIT], v1[NIT];
-    float pl[PRO == PRO_B2IN ? NIT : 1];
-    auto item_pos = [&](int k, int& iy, int& ix, bool& valid) {
-        int tt = t;
-        asm volatile("" : "+v"(tt));                             // keeps the index arithmetic inside the phase that uses it
-        const int item = tt + k * NE;
-        valid = tt < NE && item < NITEM;
-        const int pix = (valid ? item : NITEM - 1) / G;
-        iy = pix / TIW; ix = pix % TIW;
-    };
-    auto load_tile = [&](int tile) {                             // global -> registers (raw values)
-        const int b = tile / ntile, tl = tile - b * ntile;
-        const int tx0 = (tl % a.tiles_x) * TW, ty0 = (tl / a.tiles_x) * TH;
-        const float* in = a.in + (size_t)b * a.in_stride + g8 * 8;
-        const float* pool = PRO == PRO_B2IN ? a.pool + (size_t)b * a.pool_stride : nullptr;
-#pragma unroll
-        for (int k = 0; k < NIT; ++k) {
-            int iy, ix; bool valid;
-            item_pos(k, iy, ix, valid);
-            const int cy = min(max(ty0 * ST - 1 + iy, 0), a.Hin - 1), cx = min(max(tx0 * ST - 1 + ix, 0), a.Win - 1);
-            const float* p = in + (cy * a.Win + cx) * CIN;
-            v0[k] = *(const f32x4*)p; v1[k] = *(const f32x4*)(p + 4);
-            if constexpr (PRO == PRO_B2IN) pl[k] = pool[cy * a.Win + cx];
-        }
-    };
-    auto store_tile = [&](int tile) {                            // registers -> activated LDS tile (zero padding outside the image)
-        const int b = tile / ntile, tl = tile - b * ntile;
-        const int tx0 = (tl % a.tiles_x) * TW, ty0 = (tl / a.tiles_x) * TH;
-        const float* st = a.st.stat + (size_t)b * 2 * CIN + g8 * 8;          // batches > 8: always finalised statistics
-        const f32x4 m0 = *(const f32x4*)st, m1 = *(const f32x4*)(st + 4), r0 = *(const f32x4*)(st + CIN), r1 = *(const f32x4*)(st + CIN + 4);
-        f32x4 w0, w1, c0, c1;
-        if constexpr (PRO == PRO_B2IN) {
-            w0 = *(const f32x4*)(a.skip_w + g8 * 8); w1 = *(const f32x4*)(a.skip_w + g8 * 8 + 4);
-            c0 = *(const f32x4*)(a.skip_b + g8 * 8); c1 = *(const f32x4*)(a.skip_b + g8 * 8 + 4);
-        }
-#pragma unroll
-        for (int k = 0; k < NIT; ++k) {
-            int iy, ix; bool valid;
-            item_pos(k, iy, ix, valid);                          // (recomputed: eight more live registers across the epilogue cost 8 % of the kernel)
-            const int gy = ty0 * ST - 1 + iy, gx = tx0 * ST - 1 + ix;
-            const bool in_img = gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win;
-            f32x4 x0 = v0[k], x1 = v1[k];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                x0[q] = fmaxf((x0[q] - m0[q]) * r0[q], 0.f);
-                x1[q] = fmaxf((x1[q] - m1[q]) * r1[q], 0.f);
-                if constexpr (PRO == PRO_B2IN) { x0[q] = x0[q] + (pl[k] * w0[q] + c0[q]); x1[q] = x1[q] + (pl[k] * w1[q] + c1[q]); }
-                x0[q] = in_img ? x0[q] : 0.f; x1[q] = in_img ? x1[q] : 0.f;
-            }
-            if (valid) {
-                float* d = s_in + iy * RP + ix * CP + g8 * 8;
-                *(f32x4*)d = x0;
-                *(f32x4*)(d + 4) = x1;
-            }
-        }
-    };
-
-    int tile = blockIdx.x;
-    if (tile >= total) return;
-    float biasv[NG];
-#pragma unroll
-    for (int g = 0; g < NG; ++g) biasv[g] = EPI != EPI_STATS ? a.bias[g * 4 + lj] : 0.f;
-    // Two workgroups share a CU (one wave of each per SIMD).  Started together they would stay in lockstep -- both staging, then both
-    // in the K loop at half speed each -- and nothing would overlap; the second half of the grid (the second workgroup of every CU
-    // under breadth-first dispatch) therefore starts half a tile period late, once, and from then on one workgroup's staging /
-    // stores / statistics run under the other one's MFMAs.
-    if (blockIdx.x >= (gridDim.x + 1) / 2)
-        for (int q = 0; q < 3; ++q) __builtin_amdgcn_s_sleep(127);      // 3 x 127 x 64 cycles: about 10 us
-    load_tile(tile);
-    store_tile(tile);
-    __syncthreads();                                             // weights and the first tile are in LDS
-    // operand bases of this lane: pixel (lr, lc) of block 0 of the wave, weight row lj of channel group 0
-    const float* pa0 = s_in + (wy * 4 * NBY + lr) * ST * RP + (wx * 16 + lc) * CP;
-    const float* pb0 = s_w + lj * WS;
-    while (true) {
-        const int next = tile + gridDim.x;
-        const bool has_next = next < total;
-
-        f32x4 acc[NBY][NG];
-#pragma unroll
-        for (int nb = 0; nb < NBY; ++nb)
-#pragma unroll
-            for (int g = 0; g < NG; ++g) acc[nb][g] = f32x4{0.f, 0.f, 0.f, 0.f};
-        // K loop in (ky, kx, ci) order; a step = 4 k: NBY + NG ds_read_b128 (base + immediate offset) feed 4 * NBY * NG MFMAs.  Two waves
-        // per SIMD (one of each resident workgroup): one wave's operand latency is the other wave's issue time.
-        for (int ky = 0; ky < 3; ++ky) {
-            const float* pa = pa0 + ky * RP;
-            const float* pb = pb0 + ky * 3 * CIN;
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-#pragma unroll
-                for (int c4 = 0; c4 < CIN / 4; ++c4) {
-                    f32x4 av[NBY], bv[NG];
-#pragma unroll
-                    for (int nb = 0; nb < NBY; ++nb) av[nb] = *(const f32x4*)(pa + nb * 4 * ST * RP + kx * CP + c4 * 4);
-#pragma unroll
-                    for (int g = 0; g < NG; ++g) bv[g] = *(const f32x4*)(pb + g * 4 * WS + kx * CIN + c4 * 4);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-#pragma unroll
-                        for (int g = 0; g < NG; ++g)
-#pragma unroll
-                            for (int nb = 0; nb < NBY; ++nb)
-                                acc[nb][g] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[nb][j], bv[g][j], acc[nb][g], 0, 0, 0);
-                }
-            }
-        }
-        XFH_MFMA_SETTLE();                                        // common.h: the epilogue branches
-
-        // ---- epilogue of `tile`: lane (l >> 2, lj), register v <-> pixel (row lr, column 4 * ((l >> 2) & 3) + v) of the block, channel 4 g + lj.
-        // The loads of the next tile go out first (their latency runs under the epilogue; the registers are free again: the K loop is over).
-        if (has_next) load_tile(next);
-        __syncthreads();                                         // every wave has left the K loop: the input tile is dead
-        const int b = tile / ntile, tl = tile - b * ntile;
-        const int tx0 = (tl % a.tiles_x) * TW, ty0 = (tl / a.tiles_x) * TH;
-        double sum[NG], sq[NG];
-#pragma unroll
-        for (int g = 0; g < NG; ++g) { sum[g] = 0.0; sq[g] = 0.0; }
-        // the wave's 4 NBY x 16 pixels x COUT channels go through a private piece of the dead tile, pixel-major, so that the global
-        // stores are whole 16-byte pieces of contiguous image rows (a lane's accumulators are 4-byte pieces 4 pixels apart: stored
-        // directly they made 6 partial cache-line writes per pixel, 2.9 us per tile)
-        float* s_out = s_in + wave * (4 * NBY * 16 * COUT);
-        const int oy0 = ty0 + wy * 4 * NBY, ox0 = tx0 + wx * 16;
-#pragma unroll
-        for (int nb = 0; nb < NBY; ++nb) {
-            const int prow = nb * 4 + lr, pcol = 4 * ((lane >> 2) & 3);
-            const bool rok = oy0 + prow < a.Hout;
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const bool ok = rok && ox0 + pcol + v < a.Wout;
-                float* d = s_out + (prow * 16 + pcol + v) * COUT + lj;
-#pragma unroll
-                for (int g = 0; g < NG; ++g) {
-                    float val = acc[nb][g][v];
-                    if constexpr (EPI != EPI_STATS) val += biasv[g];
-                    if constexpr (EPI == EPI_BIAS_RELU) val = fmaxf(val, 0.f);
-                    d[g * 4] = val;
-                    if constexpr (EPI == EPI_STATS) { if (ok) { const double dv = (double)val; sum[g] += dv; sq[g] = fma(dv, dv, sq[g]); } }
-                }
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        {
-            constexpr int ROWP = 16 * COUT / 4;                  // 16-byte pieces per pixel row of the wave
-            float* orow = a.out + (size_t)b * a.out_stride + ((size_t)oy0 * a.Wout + ox0) * COUT;
-#pragma unroll
-            for (int q = 0; q < 4 * NBY * ROWP / 64; ++q) {
-                const int P = q * 64 + lane, prow = P / ROWP, pp = P % ROWP;
-                const f32x4 val = *(const f32x4*)(s_out + P * 4);
-                if (oy0 + prow < a.Hout && ox0 + pp * 4 / COUT < a.Wout) *(f32x4*)(orow + (size_t)prow * a.Wout * COUT + pp * 4) = val;
-            }
-        }
-        if constexpr (EPI == EPI_STATS) {
-#pragma unroll
-            for (int g = 0; g < NG; ++g) {                        // the sixteen lanes that hold channel 4 g + lj: masks 4, 8, 16, 32
-                sum[g] += __shfl_xor(sum[g], 4); sq[g] += __shfl_xor(sq[g], 4);
-                sum[g] += __shfl_xor(sum[g], 8); sq[g] += __shfl_xor(sq[g], 8);
-                sum[g] += __shfl_xor(sum[g], 16); sq[g] += __shfl_xor(sq[g], 16);
-                sum[g] += __shfl_xor(sum[g], 32); sq[g] += __shfl_xor(sq[g], 32);
-                if (lane < 4) {
-                    s_red[(wave * COUT + g * 4 + lj) * 2 + 0] = sum[g];
-                    s_red[(wave * COUT + g * 4 + lj) * 2 + 1] = sq[g];
-                }
-            }
-        }
-        __syncthreads();                                         // every wave is done with s_in; s_red is complete
-        if constexpr (EPI == EPI_STATS) {
-            for (int co = t; co < COUT; co += NTHR) {
-                double S = 0.0, SS = 0.0;
-#pragma unroll
-                for (int m = 0; m < NW; ++m) { S += s_red[(m * COUT + co) * 2 + 0]; SS += s_red[(m * COUT + co) * 2 + 1]; }
-                double* p = a.part + (size_t)b * a.part_stride + ((size_t)tl * COUT + co) * 2;
-                p[0] = S; p[1] = SS;
-            }
-        }
-        if (!has_next) break;
-        // (no register prefetch ACROSS the K loop: the 64-72 registers of a tile do not fit beside the accumulators at two waves per
-        // SIMD -- hipcc then waits for the loads before the K loop, or spills; the loads were issued at the top of the epilogue instead)
-        store_tile(next);
-        __syncthreads();
-        tile = next;
-    }
-}
-
-// ------------------------------------------------------------------------------------
 // k_conv_mfma16: the SINGLE-FRAME form of the 3x3 stride-1 layers with >= 64 channels, on v_mfma_f32_16x16x4_f32.
 // One frame gives a layer 40-150 workgroups; with 32x32x2 tiles a wave then walks an accumulation chain of 288-576 dependent
 // MFMAs of 64 cycles each (7.7-15 us of pure chain per layer) on a mostly idle GPU.  The 16x16x4 instruction is the same exact
@@ -1510,27 +1254,6 @@ static hipError_t conv_mfma_p_launch(xfh_ctx* c, const ConvArgs& a, int B, int* 
     return hipGetLastError();
 }
 
-template <int CIN, int COUT, int ST, int NBY, int WMY, int WMX, int PRO, int EPI>
-static hipError_t conv4_p_launch(xfh_ctx* c, const ConvArgs& a, int B, int* npart_out, int layer) {
-    constexpr int TH = 4 * NBY * WMY, TW = 16 * WMX;
-    constexpr int TIH = (TH - 1) * ST + 3, TIW = (TW - 1) * ST + 3;
-    constexpr int K = 9 * CIN, WS = ((K + 4) / 4) % 2 ? K + 4 : K + 8;
-    constexpr int PP = ((TIW * CIN / 4) % 2 ? TIW * CIN : TIW * CIN + 4);
-    constexpr size_t LDS = sizeof(float) * ((size_t)TIH * PP + (size_t)COUT * WS) + sizeof(double) * WMY * WMX * COUT * 2;
-    static_assert(LDS <= 160 * 1024, "LDS budget");
-    ConvArgs aa = a;
-    aa.tiles_x = (a.Wout + TW - 1) / TW;
-    const int ntile = aa.tiles_x * ((a.Hout + TH - 1) / TH);
-    if (npart_out) *npart_out = ntile;
-    auto kern = k_conv4_p<CIN, COUT, ST, NBY, WMY, WMX, PRO, EPI>;
-    XFH_SET_LDS_ATTR_ONCE(c, kern, LDS);
-    const int total = ntile * B;
-    const int per_cu = (int)((160 * 1024) / LDS) > 2 ? 2 : (int)((160 * 1024) / LDS);
-    const int grid = total < 256 * per_cu ? total : 256 * per_cu;
-    launch_k(c, XFH_K_CONV_MFMA, layer, kern, dim3(grid), dim3(64 * WMY * WMX), LDS, aa, ntile, total);
-    return hipGetLastError();
-}
-
 // Batch regimes (tests/test_gpu_extract.py::test_batch_is_per_frame checks that they agree bit for bit):
 //   B > 8 : persistent kernels for the short-K layers (k_conv_mfma_p), k_bn_finalize after every layer;
 //   B <= 8: a dependent launch costs ~5 us on this GPU whatever it does, so EVERY consumer folds the statistics of its
@@ -1622,11 +1345,11 @@ static hipError_t launch_basic_layer_t(xfh_ctx* c, int li, const float* in, size
             else e = conv_mfma_launch<8, 24, 3, 2, 4, 1, 1, 16, PRO_BN, EPI, 64, 9>(c, a, B, &np, li);
             break;
         case 4:                                                                                                 // input = relu(bn(block1.3)) + skip1(x), computed while staging
-            if (persistent(B)) { a.w = c->w.m4[li]; e = conv4_p_launch<24, 24, 1, 2, 2, 2, PRO_B2IN, EPI>(c, a, B, &np, li); }      // 16 x 32 pixels per workgroup, two workgroups per CU
+            if (persistent(B)) { a.w = c->w.alt[li]; e = conv_mfma_p_launch<24, 24, 3, 1, 4, 1, 1, 16, PRO_B2IN, EPI>(c, a, B, &np, li); }
             else e = conv_mfma_launch<24, 24, 3, 1, 4, 1, 1, 16, PRO_B2IN, EPI>(c, a, B, &np, li);
             break;
         case 5:
-            if (persistent(B)) { a.w = c->w.m4[li]; e = conv4_p_launch<24, 24, 1, 2, 2, 2, PRO_BN, EPI>(c, a, B, &np, li); }
+            if (persistent(B)) { a.w = c->w.alt[li]; e = conv_mfma_p_launch<24, 24, 3, 1, 4, 1, 1, 16, PRO_BN, EPI>(c, a, B, &np, li); }
             else e = conv_mfma_launch<24, 24, 3, 1, 4, 1, 1, 16, PRO_BN, EPI>(c, a, B, &np, li);
             break;
         case 6: e = conv_mfma_launch<24, 64, 3, 2, 4, 1, 2, 16, PRO_BN, EPI>(c, a, B, &np, li); break;      // 8x16 pixels; 8x8 pixels (46 KB, three workgroups per CU) measured 526 -> 757 us at B = 256
