@@ -123,21 +123,43 @@ public:
     XFextractor& operator=(const XFextractor&) = delete;
 
     // reference: int operator()(cv::InputArray image, cv::InputArray mask, std::vector<cv::KeyPoint>&,
-    //                           cv::OutputArray descriptors, std::vector<int>& vLappingArea)
+    //                           cv::OutputArray descriptors, std::vector<int>& vLappingArea)   (include/XFextractor.h:41-43)
+#if XFEAT_HAVE_OPENCV
+    // With OpenCV the signature is the reference's own, so every call site compiles unchanged whatever array type it passes
+    // (Frame.cc:611-618 passes cv::Mat, cv::Mat(), std::vector<cv::KeyPoint>, cv::Mat).  NOT compiled in this repository's image
+    // (no OpenCV headers): written against the OpenCV 4.5 API (_InputArray::getMat / empty, _OutputArray::create / getMat / release).
+    int operator()(cv::InputArray _image, cv::InputArray /*_mask: ignored, as in the reference*/, std::vector<cv::KeyPoint>& _keypoints,
+                   cv::OutputArray _descriptors, std::vector<int>& vLappingArea) {
+        if (_image.empty()) return -1;                       // :253-254
+        const cv::Mat image = _image.getMat();
+        if (image.type() != CV_8UC1) throw std::invalid_argument("Unsupported number of channels in the input image.");  // :179, :257
+        _descriptors.create(nfeatures, 64, CV_32F);          // :347
+        cv::Mat desc = _descriptors.getMat();
+        int n_valid = 0;
+        const int mono = run(image.data, image.rows, image.cols, (int)image.step, desc.ptr<float>(0), _keypoints, vLappingArea, &n_valid);
+        if (mono >= 0 && n_valid == 0) _descriptors.release();   // :350-353
+        return mono;
+    }
+#else
     int operator()(const Mat& image, const Mat& /*mask (ignored, as in the reference)*/, std::vector<KeyPoint>& _keypoints,
                    Mat& _descriptors, std::vector<int>& vLappingArea) {
         if (image.empty()) return -1;                        // :253-254
-        const int lap0 = vLappingArea.size() > 0 ? vLappingArea[0] : 0, lap1 = vLappingArea.size() > 1 ? vLappingArea[1] : 0;
-#if XFEAT_HAVE_OPENCV
-        if (image.type() != CV_8UC1) throw std::invalid_argument("Unsupported number of channels in the input image.");  // :179,:257
-        _descriptors.create(nfeatures, 64, CV_32F);
-#else
         if (image.elem != 1) throw std::invalid_argument("Unsupported number of channels in the input image.");
         _descriptors.create(nfeatures, 64, 4);
+        int n_valid = 0;
+        const int mono = run(image.data, image.rows, image.cols, (int)image.step, _descriptors.template ptr<float>(0), _keypoints, vLappingArea, &n_valid);
+        if (mono >= 0 && n_valid == 0) _descriptors.release();   // :350-353
+        return mono;
+    }
 #endif
-        int n_valid = 0, mono = 0;
-        const int rc = xfh_extract(ctx, image.data, image.rows, image.cols, (int)image.step, lap0, lap1, kbuf.data(),
-                                   _descriptors.template ptr<float>(0), &n_valid, &mono);
+
+private:
+    // the part of operator() that does not depend on the array types: C ABI call, keypoint conversion
+    int run(const unsigned char* data, int rows, int cols, int step, float* desc_out, std::vector<KeyPoint>& _keypoints,
+            std::vector<int>& vLappingArea, int* n_valid) {
+        const int lap0 = vLappingArea.size() > 0 ? vLappingArea[0] : 0, lap1 = vLappingArea.size() > 1 ? vLappingArea[1] : 0;
+        int mono = 0;
+        const int rc = xfh_extract(ctx, data, rows, cols, step, lap0, lap1, kbuf.data(), desc_out, n_valid, &mono);
         if (rc == XFH_ERR_EMPTY_IMAGE) return -1;
         if (rc != XFH_OK) throw std::runtime_error(std::string("XFextractor: ") + xfh_strerror(rc) + " " + xfh_last_hip_error(ctx));
         _keypoints.assign(nfeatures, KeyPoint());            // vector<KeyPoint>(nfeatures), :310
@@ -146,9 +168,9 @@ public:
             KeyPoint& o = _keypoints[i];
             o.pt.x = k.x; o.pt.y = k.y; o.size = k.size; o.angle = k.angle; o.response = k.response; o.octave = k.octave; o.class_id = k.class_id;
         }
-        if (n_valid == 0) _descriptors.release();            // :350-353
         return mono;
     }
+public:
 
     // Split form (not in the reference): submit() enqueues the frame and returns, collect() waits and fills the outputs
     // like operator().  Lets the Tracking thread keep both cameras of a stereo rig (two XFextractor objects) or the next

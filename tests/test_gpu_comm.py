@@ -1,7 +1,8 @@
 """GPU tests of the multi-GPU exchange behind the C ABI (xfh_comm_*, xfh_allgather_records, xfh_gather_records_root,
 xfh_gather_compact_root) with a world of ONE rank: librccl is really called (communicator, all-gather, send/recv group,
-stream ordering against the extraction), only the peers are missing.  World sizes > 1 run in the driver's scaling bench;
-the shard / unshard logic and the TCP bootstrap are covered on CPU (tests/test_dist_gloo.py)."""
+stream ordering against the extraction), only the peers are missing.  Worlds of 2 and 3 ranks run in tests/test_gpu_comm_world2.py
+(over a test-only librccl stand-in: the box has one GPU) and in the driver's scaling bench (real RCCL); the partitioning
+arithmetic and the TCP bootstrap are covered on CPU (tests/test_dist_gloo.py)."""
 import ctypes as C
 import socket
 
@@ -113,6 +114,19 @@ def test_several_ctx_feed_one_communicator(gpu_lib):
         for i, (a, b) in enumerate(zip(got, want)):
             for x, y in zip(a, b):
                 assert np.array_equal(x, y), (step, i)
+    # the compact gather of ALL sub-batches through ctx 0's communicator: S * B = 18 frames although ctx 0 was created for 6
+    # (bench.py --gather compact with several ctx: the scratch of the exchange follows the call's frame count, not cfg.max_batch)
+    last = (steps - 1) & 1
+    cap = int(L.xfh_compact_bytes_max(nf, S * B))
+    d_c = capi.DeviceBuffer(cap)
+    sizes = comm.gather_compact_root(d_rec[last].ptr, S * B, d_c.ptr, 0, last)
+    comm.synchronize()
+    shard = d_c.download(np.uint8, sizes[0])
+    want_last = ctxs[0].parse_records(d_all[steps - 1].download(np.uint8, S * B * rec), S * B)
+    for i in (0, B, S * B - 1):
+        k = np.zeros(nf, capi.KP_DTYPE); d = np.zeros((nf, 64), np.float32); nv, mono = C.c_int(), C.c_int()
+        assert L.xfh_unpack_compact(shard.ctypes.data, shard.nbytes, i, nf, k.ctypes.data, d.ctypes.data, C.byref(nv), C.byref(mono)) == 0
+        assert (nv.value, mono.value) == (want_last[i][2], want_last[i][3]) and np.array_equal(k, want_last[i][0]) and np.array_equal(d, want_last[i][1]), i
     assert L.xfh_comm_wait_ctx(ctxs[1].h, ctxs[0].h) == 1                      # ctx 1 has no communicator
     comm.close(); ref.close()
     for c in ctxs:
