@@ -19,7 +19,7 @@ print(c["sub_batches_in_flight"], c["frames_per_gpu_per_step"] // c["sub_batches
       round(d["step_roofline"]["frac"], 4), round(d["roofline"]["frac"], 4), round(d["roofline"]["in_timed_region"]["frac"], 4))
 PY
 done
-( timeout 300 python bench.py --force-comm --steps 20 --no-legs ) 2> $O/bench_dist1.err | tail -1 > $O/bench_dist1.json
+( timeout 400 python bench.py --force-comm --steps 20 --cpu-frames 0 --only-match-leg ) 2> $O/bench_dist1.err | tail -1 > $O/bench_dist1.json
 rm -rf $O/prof $O/pmc_fetch $O/pmc_write $O/prof_serial
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o bench -- python $R/bench.py --steps 20 --cpu-frames 0 ) > $O/bench_prof.json 2> $O/bench_prof.err
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o bench -- python $R/bench.py --steps 3 --warmup 1 --match-iters 10 --cpu-frames 0 --only-match-leg ) > $O/pmc_fetch.json 2> $O/pmc_fetch.err
