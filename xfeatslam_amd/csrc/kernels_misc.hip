@@ -415,21 +415,22 @@ __device__ __forceinline__ void reg_stage(u64 (&key)[KPT], int k, int t) {
     for (int q = 0; q < KPT; ++q)
         if ((q & J) == 0) cmpx(key[q], key[q + J], ((KPT * t + q) & k) == 0);
 }
-// sorts KPT*1024 keys ascending; thread t ends with ranks KPT*t .. KPT*t+KPT-1
-template <int KPT>
+// sorts KPT*NT keys ascending with NT threads (the first NT of the workgroup; the others must have left: a terminated wave does not
+// take part in s_barrier); thread t ends with ranks KPT*t .. KPT*t+KPT-1
+template <int KPT, int NT = 1024>
 __device__ __forceinline__ void hybrid_bitonic(u64 (&key)[KPT], u64* sk, int t) {
-    constexpr int NTOT = KPT * 1024;
+    constexpr int NTOT = KPT * NT;
     for (int k = 2; k <= NTOT; k <<= 1) {
         for (int j = k >> 1; j >= 1; j >>= 1) {
             if (j >= 64 * KPT) {
                 const int m = j / KPT;                        // partner thread distance (>= 64: other wave)
 #pragma unroll
-                for (int q = 0; q < KPT; ++q) sk[q * 1024 + t] = key[q];
+                for (int q = 0; q < KPT; ++q) sk[q * NT + t] = key[q];
                 __syncthreads();
                 const bool lower = (t & m) == 0;
 #pragma unroll
                 for (int q = 0; q < KPT; ++q) {
-                    const u64 o = sk[q * 1024 + (t ^ m)];
+                    const u64 o = sk[q * NT + (t ^ m)];
                     const bool keep_min = (lower == (((KPT * t + q) & k) == 0));
                     key[q] = keep_min ? (key[q] < o ? key[q] : o) : (key[q] > o ? key[q] : o);
                 }
@@ -455,12 +456,12 @@ __device__ __forceinline__ void hybrid_bitonic(u64 (&key)[KPT], u64* sk, int t) 
     }
 }
 // validity, slots and bookkeeping for the sorted keys held KPT per thread
-template <int KPT>
+template <int KPT, int NT = 1024>
 __device__ __forceinline__ void place_sorted(const u64 (&key)[KPT], int t, int b, int N, int W, int nfeatures, int lap0, int lap1, float rw,
                                              int* __restrict__ slot_src, u64* __restrict__ sel_key, int* __restrict__ sel_n,
                                              uint8_t* __restrict__ records, size_t rec_bytes, int n_cand, int* wsumF, int* wsumB) {
     const int lane = t & 63, wave = t >> 6;
-    for (int e = t; e < nfeatures; e += 1024) slot_src[(size_t)b * nfeatures + e] = -1;
+    for (int e = t; e < nfeatures; e += NT) slot_src[(size_t)b * nfeatures + e] = -1;
     __syncthreads();
     bool front[KPT], back[KPT];
     int cF = 0, cB = 0;
@@ -487,7 +488,7 @@ __device__ __forceinline__ void place_sorted(const u64 (&key)[KPT], int t, int b
     if (lane == 63) { wsumF[wave] = iF; wsumB[wave] = iB; }
     __syncthreads();
     int oF = iF - cF, oB = iB - cB, totF = 0, totB = 0;
-    for (int w = 0; w < 16; ++w) {
+    for (int w = 0; w < NT / 64; ++w) {
         if (w < wave) { oF += wsumF[w]; oB += wsumB[w]; }
         totF += wsumF[w]; totB += wsumB[w];
     }
@@ -518,16 +519,32 @@ void k_select(const u64* __restrict__ cand, size_t cand_cap, const int* __restri
     if ((size_t)C > cand_cap) C = (int)cand_cap;
     const int N = C < nfeatures ? C : nfeatures;
 
-    if (C <= 4 * 1024) {
-        u64 key[4];
+    // Sort size: 4096 keys on 1024 threads, or -- when at most 1024 keypoints are wanted (TUM1.yaml asks for 1000) or the frame has at
+    // most 1024 candidates -- 1024 keys on the first 256 threads: three LDS exchange stages between four waves instead of ten between
+    // sixteen (the sort and the placement, not the radix passes, are most of this kernel: 35 of 49 us at 4096 keys).
+    const bool small = N <= 1024;
+    const int cap = small ? 1024 : SEL_FAST_MAX;
+    auto sort_and_place = [&](bool from_lds) {
+        if (small) {
+            if (t >= 256) return;                            // (every barrier below is among the first four waves only)
+            u64 key[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) key[q] = (4 * t + q < C) ? gk[4 * t + q] : ~0ull;
-        hybrid_bitonic<4>(key, sk, t);
-        place_sorted<4>(key, t, b, N, W, nfeatures, lap0, lap1, rw, slot_src, sel_key, sel_n, records, rec_bytes, n_cand, wsumF, wsumB);
-        return;
-    }
-    // ---- more than 4096 candidates: radix select (8-bit digits from the top) until the keys at or below the current prefix
-    // fit the 4-per-thread sort (<= 4096), which then orders them exactly and the first N are taken.  Typically two
+            for (int q = 0; q < 4; ++q) key[q] = from_lds ? sk[4 * t + q] : ((4 * t + q < C) ? gk[4 * t + q] : ~0ull);
+            if (from_lds) __syncthreads();
+            hybrid_bitonic<4, 256>(key, sk, t);
+            place_sorted<4, 256>(key, t, b, N, W, nfeatures, lap0, lap1, rw, slot_src, sel_key, sel_n, records, rec_bytes, n_cand, wsumF, wsumB);
+        } else {
+            u64 key[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) key[q] = from_lds ? sk[4 * t + q] : ((4 * t + q < C) ? gk[4 * t + q] : ~0ull);
+            if (from_lds) __syncthreads();
+            hybrid_bitonic<4>(key, sk, t);
+            place_sorted<4>(key, t, b, N, W, nfeatures, lap0, lap1, rw, slot_src, sel_key, sel_n, records, rec_bytes, n_cand, wsumF, wsumB);
+        }
+    };
+    if (C <= cap) { sort_and_place(false); return; }
+    // ---- more candidates than the sort takes: radix select (8-bit digits from the top) until the keys at or below the current prefix
+    // fit the sort (<= cap), which then orders them exactly and the first N are taken.  Typically two
     // passes: the keys that share the top 16 bits of the N-th score are few.
     int shift = 64;
     u64 prefix = 0;
@@ -555,7 +572,7 @@ void k_select(const u64* __restrict__ cand, size_t cand_cap, const int* __restri
                         if (cum + h1 < need) { cum += h1; dg = lane * 4 + 2; hv = h2;
                             if (cum + h2 < need) { cum += h2; dg = lane * 4 + 3; hv = h3; } } }
                     // keys strictly better than the new prefix: (N - need) + cum; with the hv keys that share it they must fit the sort
-                    s_digit = dg; s_need = need - cum; s_done = ((N - need) + cum + hv <= SEL_FAST_MAX) ? 1 : 0;
+                    s_digit = dg; s_need = need - cum; s_done = ((N - need) + cum + hv <= cap) ? 1 : 0;
                 }
             }
             __syncthreads();
@@ -568,19 +585,14 @@ void k_select(const u64* __restrict__ cand, size_t cand_cap, const int* __restri
         }
     }
     if (t == 0) s_cnt = 0;
-    for (int e = t; e < SEL_FAST_MAX; e += 1024) sk[e] = ~0ull;
+    for (int e = t; e < cap; e += 1024) sk[e] = ~0ull;
     __syncthreads();
     for (int e = t; e < C; e += 1024) {
         const u64 k = gk[e];
         if ((k >> shift) <= prefix) sk[atomicAdd(&s_cnt, 1)] = k;
     }
     __syncthreads();
-    u64 key[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) key[q] = sk[4 * t + q];
-    __syncthreads();
-    hybrid_bitonic<4>(key, sk, t);
-    place_sorted<4>(key, t, b, N, W, nfeatures, lap0, lap1, rw, slot_src, sel_key, sel_n, records, rec_bytes, n_cand, wsumF, wsumB);
+    sort_and_place(true);
 }
 
 // ---- k_feat_norm: ||feats(p)||_2 of every feature pixel, one thread per pixel -------------------
