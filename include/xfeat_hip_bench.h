@@ -45,6 +45,14 @@ enum {
 };
 int xfh_debug_tensor(xfh_ctx* ctx, int id, int frame, float* out, size_t capacity, size_t* count_out);
 
+/* The top-k stage alone on a caller-made candidate set (tests): `keys` = n unique 64-bit keys as the NMS stage writes them
+ * ((~ordered(score)) << 32 | y * width + x: ascending key = descending score, then ascending pixel index; n <= the ctx's candidate
+ * capacity, nfeatures <= 4096).  sel_out (capacity nfeatures) receives the selected keys in rank order, *n_out their number,
+ * hdr_out[4] the record header the stage writes (n_valid, mono_index, n_candidates, 0).  form: 0 = as the ctx runs it,
+ * 1 = bucket ranking (falls back by itself when a bucket is too large), 2 = radix select + bitonic sort. */
+int xfh_debug_select(xfh_ctx* ctx, const unsigned long long* keys, int n, int width, int lap0, int lap1, int form,
+                     unsigned long long* sel_out, int* n_out, int* hdr_out);
+
 
 /* Counter calibration (MI355X_MICROARCH.md, HBM section: "calibrate on a known byte count in your own access pattern before
  * trusting an absolute"): `iters` launches of a kernel that moves exactly `nbytes` per launch (a buffer far larger than the

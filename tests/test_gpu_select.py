@@ -1,0 +1,103 @@
+"""The top-k stage (k_select) alone, on crafted candidate sets, against numpy's sort of the same keys.
+
+Reference semantics: torch::argsort(scores, descending) + the first nfeatures (src/XFextractor.cc:285-295), validity score > 0
+(:313) and the lapping-area placement (:310-343).  The keys are unique, so the expected output is simply the sorted prefix; the
+cases are the distributions that steer the kernel's bucket ranking and its fallbacks (xfeatslam_amd/csrc/kernels_misc.hip)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+W = 640
+
+
+def make_keys(scores, idx):
+    u = np.asarray(scores, np.float32).view(np.uint32).astype(np.uint64)
+    ordv = np.where(u >> 31 == 1, u ^ 0xFFFFFFFF, u ^ 0x80000000)
+    return ((~ordv & 0xFFFFFFFF) << np.uint64(32)) | np.asarray(idx, np.uint64)
+
+
+def cases():
+    r = np.random.default_rng(7)
+
+    def idx(n):
+        return r.choice(480 * 640 - 1, n, replace=False) + 1
+    out = {}
+    out["log_uniform_9000"] = (np.exp(r.uniform(np.log(1e-3), 0.0, 9000)), idx(9000))
+    out["fewer_than_nfeatures"] = (r.uniform(0.01, 1.0, 300), idx(300))
+    out["empty"] = (np.zeros(0), np.zeros(0, np.int64))
+    out["one"] = (np.array([0.5]), np.array([77]))
+    out["more_than_the_registers_hold_20000"] = (np.exp(r.uniform(np.log(1e-4), 0.0, 20000)), idx(20000))
+    s = np.exp(r.uniform(np.log(1e-2), 0.0, 7000)); s[:6000] = 0.25                       # 6000 equal scores: one bucket, the fallback
+    out["six_thousand_ties"] = (s, idx(7000))
+    s = np.exp(r.uniform(np.log(1e-3), 0.0, 8000)); s[0] = -1.0; s[1] = 1e-30; s[2] = 0.0; s[3] = -0.0   # the (0,0) candidate's -1, outliers
+    i = idx(8000); i[0] = 0
+    out["negative_zero_and_tiny_outliers"] = (s, i)
+    out["narrow_range"] = (np.float32(0.5) + np.arange(6000, dtype=np.float32) * np.float32(2.0 ** -24), idx(6000))
+    out["all_equal_scores"] = (np.full(5000, 0.125), idx(5000))
+    out["mostly_invalid"] = (np.concatenate([r.uniform(0.1, 1.0, 50), -r.uniform(0.1, 1.0, 5000)]), idx(5050))
+    return out
+
+
+CASES = cases()
+
+
+@pytest.mark.parametrize("nfeatures", [4096, 1000])
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_select_stage_on_crafted_candidates(name, nfeatures):
+    from xfeatslam_amd import capi
+    from xfeatslam_amd.extractor import Context
+    lib = capi.lib()
+    scores, idx = CASES[name]
+    keys = make_keys(scores, idx)
+    assert len(np.unique(keys)) == len(keys)
+    order = np.sort(keys)
+    N = min(len(keys), nfeatures)
+    want = order[:N]
+    sc = (~(want >> np.uint64(32)) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    sc = np.where(sc >> 31 == 1, sc ^ 0x80000000, sc ^ 0xFFFFFFFF).astype(np.uint32).view(np.float32)
+    lap0, lap1 = 100, 300
+    x = (want & np.uint64(0xFFFFFFFF)).astype(np.int64) % W
+    valid = sc > 0
+    back = valid & (x >= lap0) & (x <= lap1)
+    ctx = Context(nfeatures=nfeatures, max_height=480, max_width=640, max_batch=1)
+    try:
+        for form in (0, 1, 2):
+            sel = np.zeros(nfeatures, np.uint64); n_out = C.c_int(-1); hdr = np.zeros(4, np.int32)
+            kbuf = np.ascontiguousarray(keys)
+            capi.check(lib.xfh_debug_select(ctx.h, kbuf.ctypes.data_as(C.c_void_p), len(keys), W, lap0, lap1, form,
+                                            sel.ctypes.data_as(C.c_void_p), C.byref(n_out), hdr.ctypes.data_as(C.c_void_p)), ctx.h)
+            assert n_out.value == N, (name, form)
+            assert np.array_equal(sel[:N], want), (name, form, int(np.argmax(sel[:N] != want)))
+            assert hdr.tolist() == [int(valid.sum()), int((valid & ~back).sum()), len(keys), 0], (name, form)
+    finally:
+        ctx.close()
+
+
+def test_select_forms_agree_on_frames():
+    """whole extraction with k_select forced to its radix + bitonic form == the default (bucket ranking) records"""
+    import os
+    from conftest import records_equal
+    from xfeatslam_amd import capi, synth, weights as WT
+    from xfeatslam_amd.extractor import Context
+    lib = capi.lib()
+    frames = synth.frames(3, 480, 640, seed=11)
+    blob = WT.pack_blob(WT.make_synthetic(1234, 3.0))
+    raws = []
+    for legacy in ("0", "1"):
+        os.environ["XFH_SELECT_LEGACY"] = legacy
+        try:
+            ctx = Context(nfeatures=4096, max_height=480, max_width=640, max_batch=3)
+        finally:
+            del os.environ["XFH_SELECT_LEGACY"]
+        ctx.load_weights(blob)
+        din = capi.DeviceBuffer(frames.nbytes).upload(frames); rec = capi.DeviceBuffer(3 * ctx.rec_bytes)
+        capi.check(lib.xfh_extract_batch_device(ctx.h, din.ptr, 3, 480, 640, 150, 400, rec.ptr), ctx.h)
+        ctx.synchronize()
+        raws.append((ctx, rec.download(np.uint8, 3 * ctx.rec_bytes)))
+    try:
+        assert records_equal(raws[0][0], raws[0][1], raws[1][1], 3)
+    finally:
+        for c, _ in raws:
+            c.close()

@@ -2,7 +2,7 @@
 # timeline of ONE single-frame extraction (B=1): start offset, duration, queue of every kernel
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; R=$(pwd); O=$R/gpurun_out; mkdir -p $O; export TMPDIR=/tmp
 rm -rf $O/prof_b1
-( cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/prof_b1 -o b1 -- python $R/bench.py --batch 1 --streams 1 --steps 60 --warmup 5 --match-iters 1 --cpu-frames 0 ) > $O/b1.json 2> $O/b1.err
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/prof_b1 -o b1 -- python $R/bench.py --batch 1 --streams 1 --steps 60 --warmup 5 --no-legs ) > $O/b1.json 2> $O/b1.err
 python - <<'PY'
 import csv, glob, os
 f = glob.glob(os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "gpurun_out/prof_b1/*kernel_trace.csv"))[0]

@@ -112,6 +112,7 @@ SYMBOLS = [
     ("xfh_bench_calib", _i, [_vp, _i, _sz, _i]),
     ("xfh_kernel_name", C.c_char_p, [_i]),
     ("xfh_debug_tensor", _i, [_vp, _i, _i, _vp, _sz, C.POINTER(_sz)]),
+    ("xfh_debug_select", _i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
 ]
 
 _lib = None

@@ -117,6 +117,7 @@ int xfh_create(const xfh_config* cfg, xfh_ctx** out) {
     c->cfg = *cfg;
     if (c->cfg.nms_threshold <= 0.f) c->cfg.nms_threshold = 0.05f;
     c->Hmax = (cfg->max_height / 32) * 32; c->Wmax = (cfg->max_width / 32) * 32;
+    if (const char* e = getenv("XFH_SELECT_LEGACY")) c->select_legacy = e[0] == '1';      // test knob: k_select's fallback form for every frame
     const int B = cfg->max_batch;
     int rc = XFH_OK;
     auto fail = [&](int code) { xfh_destroy(c); return code; };
@@ -345,6 +346,8 @@ int xfh_load_weights(xfh_ctx* c, const void* blob, size_t nbytes) {
                 rc = upload(c, &c->w.alt2[i], pack_mfma(wp, L.cout, L.cin, L.ks, coutp, 64, 3));
             if (rc == XFH_OK && L.ks == 3 && L.cin >= 64)                                                // 7, 9-14, 16, 17: single-frame form
                 rc = upload(c, &c->w.m16[i], pack_mfma(wp, L.cout, L.cin, L.ks, L.cout, 64, 1, true));
+            if (rc == XFH_OK && L.ks == 3 && L.cin == 24 && L.cout == 64)                              // 6 (block3.0): three taps per chunk for batches <= 8
+                rc = upload(c, &c->w.alt[i], pack_mfma(wp, L.cout, L.cin, L.ks, coutp, 64, 3));
             if (rc == XFH_OK && L.ks == 3 && L.cin <= 24 && L.cout == 24)                              // 3, 4, 5: all nine taps in one chunk (persistent kernels, block1.3)
                 rc = upload(c, &c->w.alt[i], pack_mfma(wp, L.cout, L.cin, L.ks, coutp, 64, 9));
         }

@@ -51,25 +51,28 @@ __host__ __device__ inline float ord2f(unsigned u) {
 // every workgroup of the CONSUMING convolution (which saves the dependent finalize launch); the
 // order does not depend on the number of threads, so all callers produce the same bits.
 // red: >= 512 doubles of LDS; stat: 2*C floats (LDS or global); C <= 256.  Ends with a barrier.
+#define BN_FOLD_BATCH 16
 __device__ __forceinline__ void bn_fold(const double* __restrict__ p, int npart, int C, double count, float* stat, double* red, int t, int nthr) {
     const int SL = 256 / C;
     for (int idx = t; idx < SL * C; idx += nthr) {
         const int c = idx % C, j = idx / C;
         double s = 0.0, ss = 0.0;
-        int q = j;
-        for (; q + 7 * SL < npart; q += 8 * SL) {       // 16 independent loads in flight, summed in index order
-            double v[8], w[8];
+        // BN_FOLD_BATCH pairs of loads in flight, summed in index order.  The last batch is padded with clamped addresses whose values are
+        // replaced by +0.0 (x + 0.0 == x bit for bit): a remainder loop would walk its loads one memory round trip after the other, and at
+        // small batches this fold is on the critical path of every kernel (20 partials = 5 dependent trips before, 1 now)
+        for (int q = j; q < npart; q += BN_FOLD_BATCH * SL) {
+            double v[BN_FOLD_BATCH], w[BN_FOLD_BATCH];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                v[u] = p[((size_t)(q + u * SL) * C + c) * 2 + 0];
-                w[u] = p[((size_t)(q + u * SL) * C + c) * 2 + 1];
+            for (int u = 0; u < BN_FOLD_BATCH; ++u) {
+                const int qq = min(q + u * SL, npart - 1);
+                v[u] = p[((size_t)qq * C + c) * 2 + 0];
+                w[u] = p[((size_t)qq * C + c) * 2 + 1];
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { s += v[u]; ss += w[u]; }
-        }
-        for (; q < npart; q += SL) {
-            s += p[((size_t)q * C + c) * 2 + 0];
-            ss += p[((size_t)q * C + c) * 2 + 1];
+            for (int u = 0; u < BN_FOLD_BATCH; ++u) {
+                const bool in = q + u * SL < npart;
+                s += in ? v[u] : 0.0; ss += in ? w[u] : 0.0;
+            }
         }
         red[idx * 2 + 0] = s;
         red[idx * 2 + 1] = ss;

@@ -43,6 +43,7 @@ struct ConvArgs {
     // PRO_L0 (block1.1: its input relu(bn(block1.0)) is recomputed from the image while staging): `in` = image X, st = statistics of
     // block1.0, xstat = InstanceNorm statistics [B][2], w0 = block1.0 weights [9][4], bias0 = its folded-BN bias (EPI_BIAS_RELU) or null
     const float* xstat; const float* w0; const float* bias0;
+    int dbg;                                                   // layer index (XFH_STAMPS builds)
 };
 
 // PRO_PLAIN: input used as is; PRO_BN: relu((x - mean) * rstd) of the producer; PRO_IN: InstanceNorm of the image;
@@ -54,6 +55,15 @@ enum { PRO_PLAIN = 0, PRO_BN = 1, PRO_IN = 2, PRO_B2IN = 3, PRO_FUSE = 4, PRO_L0
 // (block_fusion.2); EPI_BIAS_RELU: relu(. + bias) -- a BasicLayer whose BatchNorm was folded into weights and bias at load
 // (XFH_BN_RUNNING_FOLDED): the stored map is already activated and its consumers see identity statistics
 enum { EPI_STATS = 0, EPI_BIAS = 1, EPI_BIAS_RELU = 2 };
+
+// development only (make STAMPS=1, tools/phase_stamps.py): wall-clock stamps (100 MHz) of the phases of one workgroup per layer
+#ifdef XFH_STAMPS
+__device__ unsigned long long g_stamps[32 * 8];
+#define XFH_STAMP(a, ph) do { if (blockIdx.x == gridDim.x / 2 && blockIdx.z == 0 && threadIdx.x == 0) g_stamps[((a).dbg & 31) * 8 + (ph)] = wall_clock64(); } while (0)
+extern "C" int xfh_debug_stamps(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof g_stamps); }
+#else
+#define XFH_STAMP(a, ph) do { } while (0)
+#endif
 
 // ATen upsample_bilinear2d (align_corners=false) source index / weights; see oracle lin_coeff
 __device__ __forceinline__ void lin_coeff_c(int in, int out, int d, int& i0, int& i1, float& l0, float& l1) {
@@ -463,6 +473,7 @@ void k_conv_mfma(ConvArgs a) {
     const int tile = blockIdx.x, tx0 = (tile % a.tiles_x) * TW, ty0 = (tile / a.tiles_x) * TH;
     const float* in = a.in + (size_t)b * a.in_stride;
 
+    XFH_STAMP(a, 0);
     // ---- issue the first weight chunk, stage producer statistics ------------------------
     f32x4 wreg[NWLD];
 #pragma unroll
@@ -489,6 +500,7 @@ void k_conv_mfma(ConvArgs a) {
             if constexpr (PRO == PRO_B2IN) rp[k] = a.pool[(size_t)b * a.pool_stride + (size_t)gy * a.Win + gx];
         }
     }
+    XFH_STAMP(a, 1);
     // producer statistics -> LDS (folded here for small batches; s_in is still free and serves as fp64 scratch)
     if constexpr (PRO == PRO_BN || PRO == PRO_B2IN || PRO == PRO_FUSE) stage_stat(a.st, b, CIN, tile == 0, s_stat, (double*)s_in, t, NTHR);
     if constexpr (PRO == PRO_B2IN) {
@@ -499,6 +511,7 @@ void k_conv_mfma(ConvArgs a) {
         stage_stat(a.st4, b, 64, tile == 0, s_stat + 128, (double*)s_in, t, NTHR);
         stage_stat(a.st5, b, 64, tile == 0, s_stat + 256, (double*)s_in, t, NTHR);
     }
+    XFH_STAMP(a, 2);
     // ---- stage the activated input tile (zero padding outside the image) ----------------
     if constexpr (BATCHED) {
 #pragma unroll
@@ -573,6 +586,7 @@ void k_conv_mfma(ConvArgs a) {
         }
     }
     __syncthreads();
+    XFH_STAMP(a, 3);
 
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, i = lane & 31, h = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
@@ -628,6 +642,7 @@ void k_conv_mfma(ConvArgs a) {
         __syncthreads();
     }
 
+    XFH_STAMP(a, 4);
     // ---- epilogue ---------------------------------------------------------------------
     double sum[NT], sq[NT];
     {
@@ -656,6 +671,7 @@ void k_conv_mfma(ConvArgs a) {
             p[0] = S; p[1] = SS;
         }
     }
+    XFH_STAMP(a, 5);
 }
 
 // ------------------------------------------------------------------------------------
@@ -865,8 +881,8 @@ void k_conv_mfma_p(ConvArgs a, int ntile, int total) {
 //   LDS rows (pixels / weight rows) keep their channels permuted inside each group of 16 (channel 4j + q at position 4q + j), so one
 //   ds_read_b128 per operand feeds four consecutive MFMAs; D: register r = pixel 4q + r, lane column p = channel.
 // Workgroup = PGY pixel groups (GW x 16/GW pixels each, stacked vertically) x COUT/16 channel groups; staging, weight streaming
-// (one tap x 64 channels per chunk, double buffered) and statistics partials as in k_conv_mfma.
-template <int CIN, int COUT, int ST, int GW, int PGY, int PRO, int EPI>
+// (one tap x 64 channels per chunk through two LDS buffers, PD chunks in flight in registers) and statistics partials as in k_conv_mfma.
+template <int CIN, int COUT, int ST, int GW, int PGY, int PRO, int EPI, int PD = 3>
 __global__ __launch_bounds__(64 * PGY * (COUT / 16))
 void k_conv_mfma16(ConvArgs a) {
     static_assert(PRO == PRO_BN || PRO == PRO_FUSE, "3x3 layers behind a BatchNorm (block_fusion.0: + the pyramid sum)");
@@ -888,12 +904,17 @@ void k_conv_mfma16(ConvArgs a) {
     const int tile = blockIdx.x, tx0 = (tile % a.tiles_x) * TW, ty0 = (tile / a.tiles_x) * TH;
     const float* in = a.in + (size_t)b * a.in_stride;
 
-    f32x4 wreg[NWLD];
+    XFH_STAMP(a, 0);
+    // weight chunks in flight: PD of them, in a ring of register sets (chunk c in set c % PD).  With one chunk ahead the K loop of a
+    // single frame ran at one memory round trip per chunk (0.7 us against 0.3 us of MFMA chain): 18 of them in the 128-channel layers.
+    f32x4 wreg[PD][NWLD];
 #pragma unroll
-    for (int q = 0; q < NWLD; ++q) {
-        const int f = t + q * NTHR;
-        if (f < WCH / 4) wreg[q] = *(const f32x4*)(a.w + (size_t)f * 4);
-    }
+    for (int c = 0; c < PD; ++c)
+#pragma unroll
+        for (int q = 0; q < NWLD; ++q) {
+            const int f = t + q * NTHR;
+            if (c < NCHUNK && f < WCH / 4) wreg[c][q] = *(const f32x4*)(a.w + (size_t)c * WCH + (size_t)f * 4);
+        }
     f32x4 r0[NIT], r1[NIT];
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
@@ -903,11 +924,13 @@ void k_conv_mfma16(ConvArgs a) {
         r0[k] = *(const f32x4*)p;
         r1[k] = *(const f32x4*)(p + 4);
     }
+    XFH_STAMP(a, 1);
     stage_stat(a.st, b, CIN, tile == 0, s_stat, (double*)s_in, t, NTHR);
     if constexpr (PRO == PRO_FUSE) {
         stage_stat(a.st4, b, 64, tile == 0, s_stat + 128, (double*)s_in, t, NTHR);
         stage_stat(a.st5, b, 64, tile == 0, s_stat + 256, (double*)s_in, t, NTHR);
     }
+    XFH_STAMP(a, 2);
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
         const int item = t + k * NTHR, pix = item / G, g = item % G;
@@ -940,9 +963,14 @@ void k_conv_mfma16(ConvArgs a) {
 #pragma unroll
     for (int q = 0; q < NWLD; ++q) {
         const int f = t + q * NTHR;
-        if (f < WCH / 4) { const int n = f / (KC / 4), c4 = f % (KC / 4); *(f32x4*)(s_w + n * WS + c4 * 4) = wreg[q]; }
+        if (f < WCH / 4) {
+            const int n = f / (KC / 4), c4 = f % (KC / 4);
+            *(f32x4*)(s_w + n * WS + c4 * 4) = wreg[0][q];
+            if (PD < NCHUNK) wreg[0][q] = *(const f32x4*)(a.w + (size_t)PD * WCH + (size_t)f * 4);
+        }
     }
     __syncthreads();
+    XFH_STAMP(a, 3);
 
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, p = lane & 15, q = lane >> 4;
     const int pg = wave / CG, cg = wave % CG;
@@ -950,15 +978,8 @@ void k_conv_mfma16(ConvArgs a) {
     float biasv = 0.f;
     if constexpr (EPI != EPI_STATS) biasv = a.bias[cg * 16 + p];
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int ch = 0; ch < NCHUNK; ++ch) {
-        if (ch + 1 < NCHUNK) {
-            const float* wsrc = a.w + (size_t)(ch + 1) * WCH;
 #pragma unroll
-            for (int u = 0; u < NWLD; ++u) {
-                const int f = t + u * NTHR;
-                if (f < WCH / 4) wreg[u] = *(const f32x4*)(wsrc + (size_t)f * 4);
-            }
-        }
+    for (int ch = 0; ch < NCHUNK; ++ch) {
         {
             const int tap = ch / NCB, cb = ch % NCB, ky = tap / 3, kx = tap % 3;
             const float* pa = s_in + ((ly * ST + ky) * TIW + lx * ST + kx) * CP + cb * CB + 4 * q;
@@ -970,17 +991,23 @@ void k_conv_mfma16(ConvArgs a) {
                 for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[j], acc, 0, 0, 0);
             }
         }
-        if (ch + 1 < NCHUNK) {
+        if (ch + 1 < NCHUNK) {                              // chunk ch + 1 (issued PD chunks ago) -> the other LDS buffer; its register set takes chunk ch + 1 + PD
             float* wd = s_w + ((ch + 1) & 1) * W_FLOATS;
+            const float* wsrc = a.w + (size_t)(ch + 1 + PD) * WCH;
 #pragma unroll
             for (int u = 0; u < NWLD; ++u) {
                 const int f = t + u * NTHR;
-                if (f < WCH / 4) { const int n = f / (KC / 4), c4 = f % (KC / 4); *(f32x4*)(wd + n * WS + c4 * 4) = wreg[u]; }
+                if (f < WCH / 4) {
+                    const int n = f / (KC / 4), c4 = f % (KC / 4);
+                    *(f32x4*)(wd + n * WS + c4 * 4) = wreg[(ch + 1) % PD][u];
+                    if (ch + 1 + PD < NCHUNK) wreg[(ch + 1) % PD][u] = *(const f32x4*)(wsrc + (size_t)f * 4);
+                }
             }
         }
         __syncthreads();
     }
     XFH_MFMA_SETTLE();
+    XFH_STAMP(a, 4);
     // ---- epilogue: register r = pixel 4q + r of the group, lane column p = channel cg*16 + p
     double sum = 0.0, sq = 0.0;
     float* out = a.out + (size_t)b * a.out_stride + cg * 16 + p;
@@ -1009,6 +1036,7 @@ void k_conv_mfma16(ConvArgs a) {
             pp[0] = S; pp[1] = SS;
         }
     }
+    XFH_STAMP(a, 5);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1209,6 +1237,7 @@ static hipError_t conv_mfma_launch(xfh_ctx* c, const ConvArgs& a, int B, int* np
     static_assert(sizeof(double) * WM * COUTP * 2 <= LDS, "stat scratch");
     static_assert(sizeof(double) * 512 <= sizeof(float) * (size_t)TIH * TIW * (CIN + 4), "bn_fold scratch in the input tile");
     ConvArgs aa = a;
+    aa.dbg = layer;
     aa.tiles_x = (a.Wout + TW - 1) / TW;
     const int tiles_y = (a.Hout + TH - 1) / TH;
     const int ntile = aa.tiles_x * tiles_y;
@@ -1225,6 +1254,7 @@ static hipError_t conv_mfma16_launch(xfh_ctx* c, const ConvArgs& a, int B, int* 
     constexpr size_t LDS = sizeof(float) * ((size_t)((TH - 1) * ST + 3) * ((TW - 1) * ST + 3) * (CIN + 4) + 2 * (size_t)COUT * 68 + (PRO == PRO_FUSE ? 384 : 2 * CIN));
     static_assert(LDS <= 160 * 1024, "LDS budget");
     ConvArgs aa = a;
+    aa.dbg = layer;
     aa.tiles_x = (a.Wout + TW - 1) / TW;
     const int ntile = aa.tiles_x * ((a.Hout + TH - 1) / TH);
     if (npart_out) *npart_out = ntile;
@@ -1242,6 +1272,7 @@ static hipError_t conv_mfma_p_launch(xfh_ctx* c, const ConvArgs& a, int B, int* 
     constexpr size_t LDS = sizeof(float) * ((size_t)TIH * TIW * (CIN + 4) + (size_t)COUTP * (KS * KS * CIN + 4)) + sizeof(double) * WM * COUTP * 2;
     static_assert(LDS <= 160 * 1024, "LDS budget");
     ConvArgs aa = a;
+    aa.dbg = layer;
     aa.tiles_x = (a.Wout + TW - 1) / TW;
     const int ntile = aa.tiles_x * ((a.Hout + TH - 1) / TH);
     if (npart_out) *npart_out = ntile;
@@ -1346,13 +1377,16 @@ static hipError_t launch_basic_layer_t(xfh_ctx* c, int li, const float* in, size
             break;
         case 4:                                                                                                 // input = relu(bn(block1.3)) + skip1(x), computed while staging
             if (persistent(B)) { a.w = c->w.alt[li]; e = conv_mfma_p_launch<24, 24, 3, 1, 4, 1, 1, 16, PRO_B2IN, EPI>(c, a, B, &np, li); }
-            else e = conv_mfma_launch<24, 24, 3, 1, 4, 1, 1, 16, PRO_B2IN, EPI>(c, a, B, &np, li);
+            else { a.w = c->w.alt[li]; e = conv_mfma_launch<24, 24, 3, 1, 4, 1, 1, 16, PRO_B2IN, EPI, 64, 9>(c, a, B, &np, li); }      // B <= 8: all nine taps in one chunk -- one weight round trip, no barrier in the K loop
             break;
         case 5:
             if (persistent(B)) { a.w = c->w.alt[li]; e = conv_mfma_p_launch<24, 24, 3, 1, 4, 1, 1, 16, PRO_BN, EPI>(c, a, B, &np, li); }
-            else e = conv_mfma_launch<24, 24, 3, 1, 4, 1, 1, 16, PRO_BN, EPI>(c, a, B, &np, li);
+            else { a.w = c->w.alt[li]; e = conv_mfma_launch<24, 24, 3, 1, 4, 1, 1, 16, PRO_BN, EPI, 64, 9>(c, a, B, &np, li); }
             break;
-        case 6: e = conv_mfma_launch<24, 64, 3, 2, 4, 1, 2, 16, PRO_BN, EPI>(c, a, B, &np, li); break;      // 8x16 pixels; 8x8 pixels (46 KB, three workgroups per CU) measured 526 -> 757 us at B = 256
+        case 6:
+            if (consumer_fold(B)) { a.w = c->w.alt[li]; e = conv_mfma_launch<24, 64, 3, 2, 4, 1, 2, 16, PRO_BN, EPI, 64, 3>(c, a, B, &np, li); }   // three taps per chunk: 3 weight round trips instead of 9
+            else e = conv_mfma_launch<24, 64, 3, 2, 4, 1, 2, 16, PRO_BN, EPI>(c, a, B, &np, li);
+            break;      // 8x16 pixels; 8x8 pixels (46 KB, three workgroups per CU) measured 526 -> 757 us at B = 256
         case 7: case 17: case 16:
             // the dominant 3x3 64->64 instance: 8x16 pixels x 64 channels per workgroup, 8 waves (4 x 2), 32-channel weight
             // chunks (67 KB LDS -> 2 workgroups per CU); measured 70 us vs 77 us for the 4-wave / 64-channel-chunk form at

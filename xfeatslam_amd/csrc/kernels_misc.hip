@@ -227,6 +227,123 @@ void k_heads_kp(const float* __restrict__ rawK, StatSrc sK,      // keypoint_hea
     }
 }
 
+// k_heads_kp4: the small-batch form (B <= 8) of k_heads_kp.  One frame gives k_heads_kp 38 workgroups of two waves, and every lane
+// walks 64 x 65 dependent-free but sequentially issued fmas plus 65 expf and 64 quotients: 35 us of a 0.37-ms frame on a mostly
+// idle GPU.  Here FOUR lanes share a pixel (lane j takes outputs 16 j .. 16 j + 15, lane 3 also the dustbin), a workgroup is 32
+// pixels, so four times as many waves run chains a quarter as long.  Every output is the same fma chain over k, the maximum is exact
+// in any order, and the softmax sum keeps the reference order n = 0 .. 64: the running sum travels from lane j to lane j + 1 by shuffle
+// before lane j + 1 adds its terms -- the result is bit for bit k_heads_kp's (tests/test_gpu_extract.py::test_batch_is_per_frame
+// compares the two).  The weights are lane-dependent now, so they come from LDS ([k][68], broadcast over the pixels) instead of the
+// scalar cache.
+#define HK4_PX 32
+#define HK4_LD 33
+__global__ __launch_bounds__(4 * HK4_PX)
+void k_heads_kp4(const float* __restrict__ rawK, StatSrc sK,     // keypoint_head.2
+                 size_t raw_stride, const float* __restrict__ wk /* [64][68] */, const float* __restrict__ bk /* [65] */,
+                 int Hh, int Wh, float* __restrict__ K1h, size_t k1h_stride) {
+    __shared__ __attribute__((aligned(16))) float sW[64 * 68];
+    __shared__ float sA[64 * HK4_LD];
+    __shared__ float st[128];
+    __shared__ double red[512];
+    const int t = threadIdx.x, b = blockIdx.z;
+    const int npix = Hh * Wh, p0 = blockIdx.x * HK4_PX;
+    const int lp = t >> 2, j = t & 3, pix = p0 + lp;
+    // raw values of the 32 pixels (4 float4 per thread) and the weights, all loads in flight before the statistics are staged
+    f32x4 rv[4], wv[9];
+    {
+        const float* rp = rawK + (size_t)b * raw_stride;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int item = t + k * 4 * HK4_PX, ip = item >> 4, g = item & 15;
+            rv[k] = *(const f32x4*)(rp + (size_t)min(p0 + ip, npix - 1) * 64 + g * 4);
+        }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { const int f = t + k * 4 * HK4_PX; wv[k] = *(const f32x4*)(wk + (size_t)min(f, 64 * 17 - 1) * 4); }
+    }
+    stage_stat(sK, b, 64, blockIdx.x == 0, st, red, t, 4 * HK4_PX);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int item = t + k * 4 * HK4_PX, ip = item >> 4, g = item & 15;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sA[(g * 4 + q) * HK4_LD + ip] = fmaxf((rv[k][q] - st[g * 4 + q]) * st[64 + g * 4 + q], 0.f);
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { const int f = t + k * 4 * HK4_PX; if (f < 64 * 17) *(f32x4*)(sW + f * 4) = wv[k]; }
+    __syncthreads();
+    float acc[17];
+#pragma unroll
+    for (int n = 0; n < 17; ++n) acc[n] = 0.f;
+    const float* wj = sW + 16 * j;
+#pragma unroll 2
+    for (int k = 0; k < 64; ++k) {
+        const float a = sA[k * HK4_LD + lp];
+        const f32x4 w0 = *(const f32x4*)(wj + k * 68), w1 = *(const f32x4*)(wj + k * 68 + 4), w2 = *(const f32x4*)(wj + k * 68 + 8), w3 = *(const f32x4*)(wj + k * 68 + 12);
+        const float wd = sW[k * 68 + 64];                // the dustbin column (used by lane 3)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            acc[q] = fmaf(a, w0[q], acc[q]); acc[4 + q] = fmaf(a, w1[q], acc[4 + q]);
+            acc[8 + q] = fmaf(a, w2[q], acc[8 + q]); acc[12 + q] = fmaf(a, w3[q], acc[12 + q]);
+        }
+        acc[16] = fmaf(a, wd, acc[16]);
+    }
+    const int nown = j == 3 ? 17 : 16;                   // lane 3: outputs 48 .. 64
+    float mx = -__builtin_huge_valf();
+#pragma unroll
+    for (int n = 0; n < 17; ++n) {
+        acc[n] += bk[min(16 * j + n, 64)];
+        if (n < nown) mx = fmaxf(mx, acc[n]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 1)); mx = fmaxf(mx, __shfl_xor(mx, 2));
+#pragma unroll
+    for (int n = 0; n < 17; ++n) acc[n] = expf(acc[n] - mx);
+    // sum over n = 0 .. 64 in that order: lane r continues the sum lane r - 1 has reached
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float sr = __shfl(sum, (t & ~3) | (r > 0 ? r - 1 : 0));       // (round 0 starts from 0)
+        if (r == 0) sr = 0.f;
+#pragma unroll
+        for (int n = 0; n < 17; ++n) if (n < 16 || r == 3) sr += acc[n];
+        if (j == r) sum = sr;
+    }
+    sum = __shfl(sum, t | 3);                            // the total sits in lane 3
+    const Recip ks = recip_of(sum);                      // 64 softmax quotients share the divisor
+    if (pix < npix) {
+        const int y = pix / Wh, x = pix % Wh;
+        // outputs 16 j .. 16 j + 15 = rows 2 j, 2 j + 1 of the pixel's 8 x 8 cell (depth-to-space)
+        float* o = K1h + (size_t)b * k1h_stride + (size_t)(8 * y + 2 * j) * (8 * Wh) + 8 * x;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *(f32x4*)(o + (size_t)i * 8 * Wh) = f32x4{div_by(acc[i * 8], ks), div_by(acc[i * 8 + 1], ks), div_by(acc[i * 8 + 2], ks), div_by(acc[i * 8 + 3], ks)};
+            *(f32x4*)(o + (size_t)i * 8 * Wh + 4) = f32x4{div_by(acc[i * 8 + 4], ks), div_by(acc[i * 8 + 5], ks), div_by(acc[i * 8 + 6], ks), div_by(acc[i * 8 + 7], ks)};
+        }
+    }
+}
+
+// ---- k_feat_norm: ||feats(p)||_2 of every feature pixel, one thread per pixel -------------------
+// F::normalize(M1, dim=1) (XFextractor.cc:273) divides every pixel of the feature map by max(||.||_2, 1e-12): the norm is the
+// oracle's expression (fp64 sum of squares over the channels in order, fp32 sqrt, max) and is all that is stored -- the
+// normalised map itself is never written, k_desc divides the four pixels a sample touches.  A thread walks the 64 channels
+// of its pixel: 128 fp64 operations per pixel, where a cross-lane reduction per sampled pixel cost ten times that.
+// For batches <= 8 the same blocks ride on the k_nms_score launch instead (its grid is extended by fn_blocks workgroups that take
+// this path): the norms depend on feats only, and a launch of their own was 5 us on the critical path of a single frame.
+__device__ __forceinline__ void feat_norm_px(const float* __restrict__ feats, size_t m_stride, int npix, float* __restrict__ nrm, size_t n_stride, int b, int p) {
+    if (p >= npix) return;
+    const float* m = feats + (size_t)b * m_stride + (size_t)p * 64;
+    double ss = 0.0;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+        const f32x4 v = *(const f32x4*)(m + g * 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ss = fma((double)v[q], (double)v[q], ss);
+    }
+    nrm[(size_t)b * n_stride + p] = fmaxf((float)sqrt(ss), 1e-12f);
+}
+__global__ __launch_bounds__(256)
+void k_feat_norm(const float* __restrict__ feats, size_t m_stride, int npix, float* __restrict__ nrm, size_t n_stride) {
+    feat_norm_px(feats, m_stride, npix, nrm, n_stride, blockIdx.z, blockIdx.x * 256 + threadIdx.x);
+}
+
 // ---- k_nms_score: 64x16 pixels per workgroup ---------------------------------------------------
 // phase 1: the tile (+2 halo, fetched as aligned float4 with -inf outside the image, as max_pool2d
 // pads) goes to LDS; every thread owns 4 consecutive pixels of one row and evaluates the 5x5 maximum
@@ -238,12 +355,17 @@ void k_heads_kp(const float* __restrict__ rawK, StatSrc sK,      // keypoint_hea
 #define NMS_LD 72
 __global__ __launch_bounds__(256)
 void k_nms_score(const float* __restrict__ K1h, size_t k_stride, const float* __restrict__ H1, size_t h_stride,
-                 int H, int W, float thr, u64* __restrict__ cand, size_t cand_cap, int* __restrict__ cand_count) {
+                 int H, int W, float thr, u64* __restrict__ cand, size_t cand_cap, int* __restrict__ cand_count,
+                 int nms_blocks, const float* __restrict__ fn_feats, size_t fn_m_stride, int fn_npix, float* __restrict__ fn_nrm, size_t fn_n_stride) {
     __shared__ __attribute__((aligned(16))) float s[(NMS_TH + 4) * NMS_LD];
     __shared__ u64 keys[1024];
     __shared__ unsigned short cpx[1024];
     __shared__ int cnt, base;
     const int t = threadIdx.x, b = blockIdx.z;
+    if ((int)blockIdx.x >= nms_blocks) {          // riding feat-norm blocks (batches <= 8, see k_feat_norm)
+        feat_norm_px(fn_feats, fn_m_stride, fn_npix, fn_nrm, fn_n_stride, b, ((int)blockIdx.x - nms_blocks) * 256 + t);
+        return;
+    }
     const int tiles_x = (W + NMS_TW - 1) / NMS_TW;
     const int tx0 = (blockIdx.x % tiles_x) * NMS_TW, ty0 = (blockIdx.x / tiles_x) * NMS_TH;
     const float* k = K1h + (size_t)b * k_stride;
@@ -504,20 +626,12 @@ __device__ __forceinline__ void place_sorted(const u64 (&key)[KPT], int t, int b
     }
 }
 
-__global__ __launch_bounds__(1024)
-void k_select(const u64* __restrict__ cand, size_t cand_cap, const int* __restrict__ cand_count, int W, int nfeatures,
+// the radix-select + bitonic form: any candidate distribution (the fallback of k_select, and what it was before the bucket ranking)
+__device__ __forceinline__ void select_radix_bitonic(const u64* __restrict__ gk, int C, int N, int n_cand, int W, int nfeatures,
               int lap0, int lap1, float rw, int* __restrict__ slot_src, u64* __restrict__ sel_key, int* __restrict__ sel_n,
-              uint8_t* __restrict__ records, size_t rec_bytes) {
-    extern __shared__ __attribute__((aligned(16))) u64 sk[];        // 16384 keys
-    __shared__ int hist[256];
-    __shared__ int wsumF[16], wsumB[16];
-    __shared__ int s_digit, s_need, s_done, s_cnt;
+              uint8_t* __restrict__ records, size_t rec_bytes, u64* sk /* 16384 keys */, int* hist /* 256 */, int* wsumF, int* wsumB, int* s_misc /* 4 */) {
+    int& s_digit = s_misc[0]; int& s_need = s_misc[1]; int& s_done = s_misc[2]; int& s_cnt = s_misc[3];
     const int t = threadIdx.x, b = blockIdx.x, lane = t & 63, wave = t >> 6;
-    const u64* gk = cand + (size_t)b * cand_cap;
-    const int n_cand = cand_count[b * CAND_CNT_STRIDE];
-    int C = n_cand;
-    if ((size_t)C > cand_cap) C = (int)cand_cap;
-    const int N = C < nfeatures ? C : nfeatures;
 
     // Sort size: 4096 keys on 1024 threads, or -- when at most 1024 keypoints are wanted (TUM1.yaml asks for 1000) or the frame has at
     // most 1024 candidates -- 1024 keys on the first 256 threads: three LDS exchange stages between four waves instead of ten between
@@ -595,24 +709,173 @@ void k_select(const u64* __restrict__ cand, size_t cand_cap, const int* __restri
     sort_and_place(true);
 }
 
-// ---- k_feat_norm: ||feats(p)||_2 of every feature pixel, one thread per pixel -------------------
-// F::normalize(M1, dim=1) (XFextractor.cc:273) divides every pixel of the feature map by max(||.||_2, 1e-12): the norm is the
-// oracle's expression (fp64 sum of squares over the channels in order, fp32 sqrt, max) and is all that is stored -- the
-// normalised map itself is never written, k_desc divides the four pixels a sample touches.  A thread walks the 64 channels
-// of its pixel: 128 fp64 operations per pixel, where a cross-lane reduction per sampled pixel cost ten times that.
-__global__ __launch_bounds__(256)
-void k_feat_norm(const float* __restrict__ feats, size_t m_stride, int npix, float* __restrict__ nrm, size_t n_stride) {
-    const int b = blockIdx.z, p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= npix) return;
-    const float* m = feats + (size_t)b * m_stride + (size_t)p * 64;
-    double ss = 0.0;
+
+// ---- k_select: top-k for nfeatures <= 4096, one workgroup of 1024 threads per frame ---------------
+// Bucket ranking.  The keys are unique, so a key's output slot is its RANK, and the rank is
+//     (number of keys in lower buckets) + (number of smaller keys in its own bucket)
+// for any order-preserving bucket function.  Here: 4096 buckets over the 12 bits below the highest bit in which the candidates differ
+// (for scores spread over ten binades that is 256 buckets per binade, a few keys per bucket).
+//   A  every thread takes up to 16 candidates into registers (more: re-read from memory); OR / AND of the keys give the window;
+//   B  LDS histogram;  C  scan -> first key of every bucket, and the bucket T in which rank N falls;
+//   D  the keys of buckets <= T go to their bucket's segment of an LDS array (order inside a segment: arbitrary);
+//   E  every such key counts the smaller keys of its segment -> its final slot (slots >= N are dropped);  F  placement as before.
+// One pass over the candidates and no sorting network: 47 -> 17 us for 9 000 candidates / 4096 keypoints on one CU (the bitonic network
+// alone was 35 us).  The result is the same array whatever the method (a sort of unique keys); distributions the buckets cannot split
+// (a bucket > 256 keys: thousands of equal scores) or that overflow the segment array take select_radix_bitonic instead
+// (XFH_SELECT_LEGACY=1 forces it, tests/test_gpu_extract.py runs both).  Negative scores (the (0,0) candidate's -1, XFextractor.cc:281)
+// would stretch the window by 30 bits: they share the last bucket and are left out of the window.
+#define SEL_NB 4096
+#define SEL_SEGCAP 8192
+#define SEL_BUCKET_MAX 256
+#define SEL_BUCKET_FINE 8           // no selected bucket above this: the second level would cost more than it saves
+#define SEL_KREG 16
+#define SEL_LDS_BYTES (SEL_LDS_KEYS * 8 + 64)
+__device__ __forceinline__ u64 wave_or64(u64 v) {
 #pragma unroll
-    for (int g = 0; g < 16; ++g) {
-        const f32x4 v = *(const f32x4*)(m + g * 4);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) ss = fma((double)v[q], (double)v[q], ss);
+    for (int d = 1; d < 64; d <<= 1) v |= __shfl_xor(v, d);
+    return v;
+}
+__global__ __launch_bounds__(1024)
+void k_select(const u64* __restrict__ cand, size_t cand_cap, const int* __restrict__ cand_count, int W, int nfeatures,
+              int lap0, int lap1, float rw, int* __restrict__ slot_src, u64* __restrict__ sel_key, int* __restrict__ sel_n,
+              uint8_t* __restrict__ records, size_t rec_bytes, int legacy) {
+    extern __shared__ __attribute__((aligned(16))) u64 sk[];        // legacy: 16384 keys; bucket path: bykey[8192] | sorted[4096] | hist[4096] | cum[4097]
+    __shared__ int hist256[256];
+    __shared__ int wsumF[16], wsumB[16];
+    __shared__ int s_misc[4];
+    __shared__ unsigned s_or[2], s_nand[2];
+    __shared__ int s_T, s_segtot, s_maxb, s_bmin, wtot[16];
+    const int t = threadIdx.x, b = blockIdx.x, lane = t & 63, wave = t >> 6;
+    const u64* gk = cand + (size_t)b * cand_cap;
+    const int n_cand = cand_count[b * CAND_CNT_STRIDE];
+    int C = n_cand;
+    if ((size_t)C > cand_cap) C = (int)cand_cap;
+    const int N = C < nfeatures ? C : nfeatures;
+    if (legacy) {
+        select_radix_bitonic(gk, C, N, n_cand, W, nfeatures, lap0, lap1, rw, slot_src, sel_key, sel_n, records, rec_bytes, sk, hist256, wsumF, wsumB, s_misc);
+        return;
     }
-    nrm[(size_t)b * n_stride + p] = fmaxf((float)sqrt(ss), 1e-12f);
+    u64* bykey = sk;
+    u64* sorted = sk + SEL_SEGCAP;
+    int* hist = (int*)(sk + SEL_SEGCAP + SEL_FAST_MAX);
+    int* cum = hist + SEL_NB;                                       // SEL_NB + 1 entries
+    // ---- A: candidates -> registers, window
+    u64 key[SEL_KREG];
+    u64 acc_or = 0ull, acc_and = ~0ull;
+#pragma unroll
+    for (int q = 0; q < SEL_KREG; ++q) {
+        const int e = q * 1024 + t;
+        key[q] = e < C ? gk[e] : ~0ull;
+    }
+    for (int e = t; e < SEL_NB; e += 1024) hist[e] = 0;
+    if (t < 2) { s_or[t] = 0u; s_nand[t] = 0u; }
+    if (t == 0) { s_T = 0; s_segtot = 0; s_maxb = 0; s_bmin = 0; }
+#pragma unroll
+    for (int q = 0; q < SEL_KREG; ++q)
+        if (q * 1024 + t < C && !(key[q] >> 63)) { acc_or |= key[q]; acc_and &= key[q]; }
+    for (int e = SEL_KREG * 1024 + t; e < C; e += 1024) { const u64 k = gk[e]; if (!(k >> 63)) { acc_or |= k; acc_and &= k; } }
+    acc_or = wave_or64(acc_or); acc_and = ~wave_or64(~acc_and);
+    __syncthreads();
+    if (lane == 0) {
+        atomicOr(&s_or[0], (unsigned)acc_or); atomicOr(&s_or[1], (unsigned)(acc_or >> 32));
+        atomicOr(&s_nand[0], (unsigned)~acc_and); atomicOr(&s_nand[1], (unsigned)(~acc_and >> 32));
+    }
+    __syncthreads();
+    int shift = 0;
+    {
+        const u64 o = ((u64)s_or[1] << 32) | s_or[0], na = ((u64)s_nand[1] << 32) | s_nand[0];
+        const u64 d = o & na;                                       // bits in which two non-negative keys differ
+        if (d) { const int hb = 63 - __builtin_clzll(d); shift = hb > 11 ? hb - 11 : 0; }
+    }
+    // bucket of a key at the current level: level 0 = the 12 bits from the highest differing bit of ALL candidates; level 1 = the
+    // selected buckets [bmin, T0] of level 0 split 2^r ways (the top nfeatures of 10 000 candidates usually span a fraction of the
+    // window: one more histogram over them buys 2^r times finer buckets, and step E is quadratic in the bucket size)
+    int sh = shift, base = 0, sh0 = shift, T0 = SEL_NB - 1;
+    u64 msk = (u64)(SEL_NB - 1);
+    auto bucket = [&](u64 k) -> int { return (k >> 63) ? SEL_NB - 1 : (int)((k >> sh) & msk) - base; };
+    auto chosen = [&](u64 k) -> bool { return ((k >> 63) ? SEL_NB - 1 : (int)((k >> sh0) & (u64)(SEL_NB - 1))) <= T0; };
+    int T = 0, segtot = 0;
+    for (int level = 0; level < 2; ++level) {
+        // ---- B: histogram
+#pragma unroll
+        for (int q = 0; q < SEL_KREG; ++q)
+            if (q * 1024 + t < C && chosen(key[q])) atomicAdd(&hist[bucket(key[q])], 1);
+        for (int e = SEL_KREG * 1024 + t; e < C; e += 1024) { const u64 k = gk[e]; if (chosen(k)) atomicAdd(&hist[bucket(k)], 1); }
+        __syncthreads();
+        // ---- C: exclusive scan (thread t owns buckets 4t .. 4t+3), the bucket of rank N, the first occupied bucket
+        int h[4];
+        int s4 = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { h[i] = hist[4 * t + i]; s4 += h[i]; }
+        int incl = s4;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+        if (lane == 63) wtot[wave] = incl;
+        __syncthreads();
+        int run = incl - s4;
+        for (int w = 0; w < wave; ++w) run += wtot[w];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            cum[4 * t + i] = run;
+            if (run < N && N <= run + h[i]) { s_T = 4 * t + i; s_segtot = run + h[i]; }
+            if (run == 0 && h[i] > 0) s_bmin = 4 * t + i;
+            run += h[i];
+        }
+        if (t == 1023) cum[SEL_NB] = run;
+        __syncthreads();
+        T = s_T; segtot = s_segtot;
+        const int bmin = s_bmin;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (4 * t + i <= T && h[i] > SEL_BUCKET_FINE) atomicMax(&s_maxb, h[i]);
+        int r = 0;
+        if (level == 0 && N > 0) {
+            const int span = T - bmin + 1;
+            while ((span << (r + 1)) <= SEL_NB && r < sh) ++r;
+        }
+        __syncthreads();                                            // s_maxb complete; every thread has read s_T / s_segtot / s_bmin
+        if (r == 0 || s_maxb <= SEL_BUCKET_FINE) break;             // (s_maxb is 0 unless a selected bucket holds more than SEL_BUCKET_FINE keys)
+        // refine: level 1 over the keys of buckets <= T
+        T0 = T; sh = sh0 - r; msk = ((u64)SEL_NB << r) - 1ull; base = bmin << r;
+        for (int e = t; e < SEL_NB; e += 1024) hist[e] = 0;
+        if (t == 0) { s_T = 0; s_segtot = 0; s_maxb = 0; s_bmin = 0; }
+        __syncthreads();
+    }
+    if (segtot > SEL_SEGCAP || s_maxb > SEL_BUCKET_MAX) {            // (uniform) not a distribution for buckets
+        __syncthreads();
+        select_radix_bitonic(gk, C, N, n_cand, W, nfeatures, lap0, lap1, rw, slot_src, sel_key, sel_n, records, rec_bytes, sk, hist256, wsumF, wsumB, s_misc);
+        return;
+    }
+    // ---- D: keys of the buckets <= T into their segments
+    if (N > 0) {
+#pragma unroll
+        for (int q = 0; q < SEL_KREG; ++q)
+            if (q * 1024 + t < C && chosen(key[q])) {
+                const int bk = bucket(key[q]);
+                if (bk <= T) bykey[cum[bk] + atomicSub(&hist[bk], 1) - 1] = key[q];
+            }
+        for (int e = SEL_KREG * 1024 + t; e < C; e += 1024) {
+            const u64 k = gk[e];
+            if (!chosen(k)) continue;
+            const int bk = bucket(k);
+            if (bk <= T) bykey[cum[bk] + atomicSub(&hist[bk], 1) - 1] = k;
+        }
+    }
+    __syncthreads();
+    // ---- E: rank inside the segment -> final slot
+    for (int i = t; i < (N > 0 ? segtot : 0); i += 1024) {
+        const u64 k = bykey[i];
+        const int bk = bucket(k), s0 = cum[bk], s1 = cum[bk + 1];
+        int r = 0;
+        for (int j = s0; j < s1; ++j) r += bykey[j] < k ? 1 : 0;
+        if (s0 + r < N) sorted[s0 + r] = k;
+    }
+    __syncthreads();
+    // ---- F: validity, lapping placement, header
+    u64 k4[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) k4[q] = (4 * t + q < N) ? sorted[4 * t + q] : ~0ull;
+    place_sorted<4>(k4, t, b, N, W, nfeatures, lap0, lap1, rw, slot_src, sel_key, sel_n, records, rec_bytes, n_cand, wsumF, wsumB);
 }
 
 // ---- k_desc: 16 lanes per output slot (4 slots per wave), a lane owns 4 descriptor channels -------
@@ -736,6 +999,10 @@ hipError_t run_extract(xfh_ctx* c, const uint8_t* d_gray, int B, int H0, int W0,
         if (e == hipSuccess) e = launch_basic_layer(c, 21, c->raw[20], c->raw_stride[20], 20, PRO_BN, h8, w8, B);
         if (e == hipSuccess) e = launch_basic_layer(c, 22, c->raw[21], c->raw_stride[21], 21, PRO_BN, h8, w8, B);
         if (e == hipSuccess) {
+            if (consumer_fold(B))        // small batches: four lanes per pixel (k_heads_kp4), the same bits
+                launch_k(c, XFH_K_HEADS, -1, k_heads_kp4, dim3((h8 * w8 + HK4_PX - 1) / HK4_PX, 1, B), dim3(4 * HK4_PX), 0,
+                         (const float*)c->raw[22], stat_src(c, 22, B), c->raw_stride[22], (const float*)c->w.kp3_w, (const float*)c->w.kp3_b, h8, w8, c->K1h, xs);
+            else
             launch_k(c, XFH_K_HEADS, -1, k_heads_kp, dim3((h8 * w8 + HF_PX - 1) / HF_PX, 1, B), dim3(HF_PX), 0,
                      (const float*)c->raw[22], stat_src(c, 22, B), c->raw_stride[22], (const float*)c->w.kp3_w, (const float*)c->w.kp3_b, h8, w8, c->K1h, xs);
             e = hipGetLastError();
@@ -784,24 +1051,54 @@ hipError_t run_extract(xfh_ctx* c, const uint8_t* d_gray, int B, int H0, int W0,
         CK(eb); CK(ej);
     }
     // NMS + score, top-k + placement, descriptors
-    launch_k(c, XFH_K_NMS, -1, k_nms_score, dim3(((W + NMS_TW - 1) / NMS_TW) * ((H + NMS_TH - 1) / NMS_TH), 1, B), dim3(256), 0, c->K1h, xs, c->H1, xs / 64,
-                       H, W, c->cfg.nms_threshold, c->cand, c->cand_cap, c->cand_count);
+    const int nms_blocks = ((W + NMS_TW - 1) / NMS_TW) * ((H + NMS_TH - 1) / NMS_TH);
+    const int fn_blocks = consumer_fold(B) ? (h8 * w8 + 255) / 256 : 0;          // small batches: the feature norms ride on this launch
+    launch_k(c, XFH_K_NMS, -1, k_nms_score, dim3(nms_blocks + fn_blocks, 1, B), dim3(256), 0, c->K1h, xs, c->H1, xs / 64,
+                       H, W, c->cfg.nms_threshold, c->cand, c->cand_cap, c->cand_count,
+                       nms_blocks, (const float*)c->feats, c->raw_stride[17], h8 * w8, c->feat_nrm, xs / 64);
     CK(hipGetLastError());
     if (nf <= SEL_FAST_MAX) {
-        XFH_SET_LDS_ATTR_ONCE(c, k_select, SEL_LDS_KEYS * 8);
-        launch_k(c, XFH_K_SELECT, -1, k_select, dim3(B), dim3(1024), SEL_LDS_KEYS * 8, (const u64*)c->cand, c->cand_cap, (const int*)c->cand_count, W, nf,
-                 lap0, lap1, rw, c->slot_src, c->sel_key, c->sel_n, d_records, rec);
+        XFH_SET_LDS_ATTR_ONCE(c, k_select, SEL_LDS_BYTES);
+        launch_k(c, XFH_K_SELECT, -1, k_select, dim3(B), dim3(1024), SEL_LDS_BYTES, (const u64*)c->cand, c->cand_cap, (const int*)c->cand_count, W, nf,
+                 lap0, lap1, rw, c->slot_src, c->sel_key, c->sel_n, d_records, rec, c->select_legacy ? 1 : 0);
     } else {
         XFH_SET_LDS_ATTR_ONCE(c, k_select_generic, SEL_LDS_KEYS * 8);
         launch_k(c, XFH_K_SELECT, -1, k_select_generic, dim3(B), dim3(1024), SEL_LDS_KEYS * 8, c->cand, c->cand_cap, (const int*)c->cand_count, W, nf,
                  lap0, lap1, rw, c->slot_src, c->sel_key, c->sel_n, d_records, rec);
     }
     CK(hipGetLastError());
-    hipLaunchKernelGGL(k_feat_norm, dim3((h8 * w8 + 255) / 256, 1, B), dim3(256), 0, s, (const float*)c->feats, c->raw_stride[17], h8 * w8, c->feat_nrm, xs / 64);
-    CK(hipGetLastError());
+    if (!fn_blocks) {
+        hipLaunchKernelGGL(k_feat_norm, dim3((h8 * w8 + 255) / 256, 1, B), dim3(256), 0, s, (const float*)c->feats, c->raw_stride[17], h8 * w8, c->feat_nrm, xs / 64);
+        CK(hipGetLastError());
+    }
     const int dslots = d_images ? (nf + MNN_PANEL - 1) / MNN_PANEL * MNN_PANEL : nf;      // image rows run to the panel boundary
     launch_k(c, XFH_K_DESC, -1, k_desc, dim3((dslots + 15) / 16, 1, B), dim3(256), 0, c->feats, c->raw_stride[17], (const float*)c->feat_nrm, xs / 64, c->slot_src, c->sel_key, H, W, nf, rw, rh,
                        d_records, rec, xfh_record_kps_offset(), xfh_record_desc_offset(nf), write_padding ? 1 : 0,
              d_images, (size_t)(dslots / MNN_PANEL) * MNN_PANEL_FLOATS);
     return hipGetLastError();
+}
+
+// ---- development / tests: k_select on a caller-made candidate set (frame 0 of the ctx) ---------------
+#define HIPCK(c, x) do { hipError_t _e = (x); if (_e != hipSuccess) { (c)->hip_err = std::string(#x) + ": " + hipGetErrorString(_e); return XFH_ERR_HIP; } } while (0)
+// keys: n unique (score, pixel) keys as k_nms_score writes them; sel_out: the selected keys in output order (capacity nfeatures);
+// hdr_out: n_valid, mono_index, n_candidates, reserved.  form: 0 = as configured, 1 = bucket ranking (with its own fallback), 2 = radix + bitonic
+extern "C" int xfh_debug_select(xfh_ctx* c, const unsigned long long* keys, int n, int width, int lap0, int lap1, int form, unsigned long long* sel_out, int* n_out, int* hdr_out) {
+    if (!c || !keys || n < 0 || (size_t)n > c->cand_cap || width <= 0 || !sel_out || !n_out || !hdr_out || c->cfg.nfeatures > SEL_FAST_MAX) return XFH_ERR_INVALID_ARG;
+    HIPCK(c, hipSetDevice(c->cfg.device));
+    const int nf = c->cfg.nfeatures;
+    const size_t rec = xfh_record_bytes(nf);
+    HIPCK(c, hipMemcpyAsync(c->cand, keys, sizeof(u64) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(c->cand_count, &n, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    XFH_SET_LDS_ATTR_ONCE(c, k_select, SEL_LDS_BYTES);
+    const int legacy = form == 0 ? (c->select_legacy ? 1 : 0) : (form == 2 ? 1 : 0);
+    hipLaunchKernelGGL(k_select, dim3(1), dim3(1024), SEL_LDS_BYTES, c->stream, (const u64*)c->cand, c->cand_cap, (const int*)c->cand_count, width, nf,
+                       lap0, lap1, 1.0f, c->slot_src, c->sel_key, c->sel_n, c->d_records, rec, legacy);
+    HIPCK(c, hipGetLastError());
+    HIPCK(c, hipMemcpyAsync(n_out, c->sel_n, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipMemcpyAsync(hdr_out, c->d_records, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    const int N = *n_out;
+    if (N < 0 || N > nf) return XFH_ERR_HIP;
+    if (N) HIPCK(c, hipMemcpy(sel_out, c->sel_key, sizeof(u64) * (size_t)N, hipMemcpyDeviceToHost));
+    return XFH_OK;
 }
