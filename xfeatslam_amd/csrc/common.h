@@ -51,7 +51,16 @@ __host__ __device__ inline float ord2f(unsigned u) {
 // every workgroup of the CONSUMING convolution (which saves the dependent finalize launch); the
 // order does not depend on the number of threads, so all callers produce the same bits.
 // red: >= 512 doubles of LDS; stat: 2*C floats (LDS or global); C <= 256.  Ends with a barrier.
-#define BN_FOLD_BATCH 16
+// Weights that a whole wave reads at the same address go through the CONSTANT address space: the compiler then fetches them with
+// scalar loads (SGPR operands of the FMAs).  Through a plain global pointer it cannot prove the memory read-only and issues one
+// global_load_dwordx4 per weight quad with 64 identical lane addresses -- in k_conv_direct 144 of them per wave, which kept the
+// texture address unit busy for longer than the 576 FMAs took (5 -> 2 us of the kernel's single-frame time).  Only for memory that no
+// kernel writes (the weight blob, uploaded at xfh_load_weights).
+#define XFH_CONST __attribute__((address_space(4)))
+// BN_FOLD_BATCH: 8 costs the registers of the loop it replaces (kernels that also serve large batches sit at an occupancy edge:
+// k_conv_mfma's PRO_FUSE instance went from 118 to 130 VGPRs with 16, i.e. from two workgroups per CU to one); the single-frame
+// kernels take 16
+template <int BN_FOLD_BATCH = 8>
 __device__ __forceinline__ void bn_fold(const double* __restrict__ p, int npart, int C, double count, float* stat, double* red, int t, int nthr) {
     const int SL = 256 / C;
     for (int idx = t; idx < SL * C; idx += nthr) {
@@ -101,9 +110,10 @@ struct StatSrc {
 
 // statistics of frame b into LDS (2*C floats): folded here from the partials, or copied.  `red`: >= 512 doubles of LDS
 // scratch (only touched when folding).  Ends with a barrier.
+template <int BATCH = 8>
 __device__ __forceinline__ void stage_stat(const StatSrc& st, int b, int C, bool publish, float* s_stat, double* red, int t, int nthr) {
     if (st.part) {
-        bn_fold(st.part + (size_t)b * st.part_stride, st.npart, C, st.count, s_stat, red, t, nthr);
+        bn_fold<BATCH>(st.part + (size_t)b * st.part_stride, st.npart, C, st.count, s_stat, red, t, nthr);
         if (publish) for (int q = t; q < 2 * C; q += nthr) st.stat_out[(size_t)b * 2 * C + q] = s_stat[q];
     } else {
         const float* g = st.stat + (size_t)b * 2 * C;

@@ -59,10 +59,12 @@ enum { EPI_STATS = 0, EPI_BIAS = 1, EPI_BIAS_RELU = 2 };
 // development only (make STAMPS=1, tools/phase_stamps.py): wall-clock stamps (100 MHz) of the phases of one workgroup per layer
 #ifdef XFH_STAMPS
 __device__ unsigned long long g_stamps[32 * 8];
-#define XFH_STAMP(a, ph) do { if (blockIdx.x == gridDim.x / 2 && blockIdx.z == 0 && threadIdx.x == 0) g_stamps[((a).dbg & 31) * 8 + (ph)] = wall_clock64(); } while (0)
+#define XFH_STAMP(a, ph) do { if (blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) g_stamps[((a).dbg & 31) * 8 + (ph)] = wall_clock64(); } while (0)
 extern "C" int xfh_debug_stamps(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof g_stamps); }
+#define XFH_STAMP_ROW(row, ph) do { if (blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) g_stamps[(row) * 8 + (ph)] = wall_clock64(); } while (0)
 #else
 #define XFH_STAMP(a, ph) do { } while (0)
+#define XFH_STAMP_ROW(row, ph) do { } while (0)
 #endif
 
 // ATen upsample_bilinear2d (align_corners=false) source index / weights; see oracle lin_coeff
@@ -111,7 +113,7 @@ void k_bn_finalize(const double* __restrict__ part, size_t part_stride, int npar
                    float* __restrict__ stat /* [B][2*C] */) {
     __shared__ double red[256 * 2];
     const int b = blockIdx.x;
-    bn_fold(part + (size_t)b * part_stride, npart, C, count, stat + (size_t)b * 2 * C, red, threadIdx.x, 256);
+    bn_fold<16>(part + (size_t)b * part_stride, npart, C, count, stat + (size_t)b * 2 * C, red, threadIdx.x, 256);
 }
 
 // ------------------------------------------------------------------------------------
@@ -128,7 +130,7 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 // win: 3x3 window of the normalised image (zero outside: Conv2d padding); w: [9][4], wave-uniform.  Two channels per
 // v_pk_fma_f32 (the same IEEE fma per channel as the scalar chain, in the same tap order).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void l0_conv(const float (&win)[9], const float* __restrict__ w, float (&acc)[4]) {
+__device__ __forceinline__ void l0_conv(const float (&win)[9], const XFH_CONST float* __restrict__ w, float (&acc)[4]) {
     f32x2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
@@ -152,32 +154,43 @@ void k_block1_stats(const float* __restrict__ X, size_t x_stride, StatSrc xs, in
     __shared__ double s_red[512];
     __shared__ float s_xst[2];
     const int t = threadIdx.x, b = blockIdx.z, tile = blockIdx.x;
-    stage_stat(xs, b, 1, tile == 0, s_xst, s_red, t, 256);
+    XFH_STAMP_ROW(0, 0);
     const int gx = (tile % tiles_x) * L0S_TW + (t & 31) * 4, gy0 = (tile / tiles_x) * L0S_TH + (t >> 5) * L0S_R;
     const float* x = X + (size_t)b * x_stride;
-    const float m = s_xst[0], r = s_xst[1];
-    // row gy of the normalised, zero-padded image at columns gx-1 .. gx+4 (W % 4 == 0: the 16-byte load is all in or all out)
-    auto load_row = [&](int gy, float (&row)[6]) {
+    // the thread's L0S_R + 2 rows of the raw image, columns gx-1 .. gx+4: every load is issued here, before the statistics are folded
+    // and without a branch around it (clamped addresses; what lies outside the image is zeroed below) -- behind the fold and a branch per
+    // row they ran as seven dependent memory round trips, most of this kernel's single-frame time
+    f32x4 rv[L0S_R + 2]; float rl[L0S_R + 2], rr[L0S_R + 2];
+    {
+        const int cx = min(gx, W - 4), cl = max(min(gx, W) - 1, 0), cr = min(gx + 4, W - 1);
 #pragma unroll
-        for (int j = 0; j < 6; ++j) row[j] = 0.f;
-        if (gy >= 0 && gy < H) {
-            const float* p = x + (size_t)gy * W + gx;
-            if (gx < W) {
-                const f32x4 v = *(const f32x4*)p;
-                row[1] = (v.x - m) * r; row[2] = (v.y - m) * r; row[3] = (v.z - m) * r; row[4] = (v.w - m) * r;
-            }
-            if (gx > 0 && gx - 1 < W) row[0] = (p[-1] - m) * r;
-            if (gx + 4 < W) row[5] = (p[4] - m) * r;
+        for (int i = 0; i < L0S_R + 2; ++i) {
+            const float* p = x + (size_t)min(max(gy0 - 1 + i, 0), H - 1) * W;
+            rv[i] = *(const f32x4*)(p + cx); rl[i] = p[cl]; rr[i] = p[cr];
         }
+    }
+    XFH_STAMP_ROW(0, 1);
+    stage_stat<16>(xs, b, 1, tile == 0, s_xst, s_red, t, 256);
+    XFH_STAMP_ROW(0, 2);
+    const float m = s_xst[0], r = s_xst[1];
+    // row i (image row gy0 - 1 + i) of the normalised, zero-padded image at columns gx-1 .. gx+4 (W % 4 == 0: the 16-byte load is all in or all out)
+    auto load_row = [&](int i, float (&row)[6]) {
+        const int gy = gy0 - 1 + i;
+        const bool iny = gy >= 0 && gy < H;
+        const f32x4 v = rv[i];
+        const bool inx = iny && gx < W;
+        row[1] = inx ? (v.x - m) * r : 0.f; row[2] = inx ? (v.y - m) * r : 0.f; row[3] = inx ? (v.z - m) * r : 0.f; row[4] = inx ? (v.w - m) * r : 0.f;
+        row[0] = (iny && gx > 0 && gx - 1 < W) ? (rl[i] - m) * r : 0.f;
+        row[5] = (iny && gx + 4 < W) ? (rr[i] - m) * r : 0.f;
     };
     float win[3][6];
-    load_row(gy0 - 1, win[0]);
-    load_row(gy0, win[1]);
+    load_row(0, win[0]);
+    load_row(1, win[1]);
     double sum[4] = {0.0, 0.0, 0.0, 0.0}, sq[4] = {0.0, 0.0, 0.0, 0.0};
     float ps = 0.f;
 #pragma unroll
     for (int i = 0; i < L0S_R; ++i) {
-        load_row(gy0 + i + 1, win[(i + 2) % 3]);
+        load_row(i + 2, win[(i + 2) % 3]);
         const float (&r0)[6] = win[i % 3], (&r1)[6] = win[(i + 1) % 3], (&r2)[6] = win[(i + 2) % 3];
 #pragma unroll
         for (int q = 0; q < 4; ++q) ps += r1[q + 1];
@@ -185,13 +198,14 @@ void k_block1_stats(const float* __restrict__ X, size_t x_stride, StatSrc xs, in
         for (int q = 0; q < 4; ++q) {
             const float wq[9] = {r0[q], r0[q + 1], r0[q + 2], r1[q], r1[q + 1], r1[q + 2], r2[q], r2[q + 1], r2[q + 2]};
             float acc[4];
-            l0_conv(wq, w0, acc);
+            l0_conv(wq, (const XFH_CONST float*)w0, acc);
             if (gy0 + i < H && gx + q < W) {
 #pragma unroll
                 for (int co = 0; co < 4; ++co) { const double d = (double)acc[co]; sum[co] += d; sq[co] = fma(d, d, sq[co]); }
             }
         }
     }
+    XFH_STAMP_ROW(0, 4);
 #pragma unroll
     for (int co = 0; co < 4; ++co) { sum[co] = wave_sum_f64(sum[co]); sq[co] = wave_sum_f64(sq[co]); }
     if (gy0 < H && gx < W) pool[(size_t)b * pool_stride + (size_t)(gy0 >> 2) * (W >> 2) + (gx >> 2)] = ps / 16.0f;
@@ -202,6 +216,7 @@ void k_block1_stats(const float* __restrict__ X, size_t x_stride, StatSrc xs, in
     __syncthreads();
     if (t < 8)
         part[(size_t)b * part_stride + (size_t)tile * 8 + t] = (s_red[t] + s_red[8 + t]) + (s_red[16 + t] + s_red[24 + t]);
+    XFH_STAMP_ROW(0, 5);
 }
 
 // ------------------------------------------------------------------------------------
@@ -229,7 +244,16 @@ void k_conv_direct(ConvArgs a) {
     float* s_out = s_in;
     __shared__ __attribute__((aligned(16))) float s_xwin[PRO == PRO_L0 ? XW * XS : 1];
     __shared__ double s_red[FOLD ? 512 : 8 * COUT];
+    // FOLD (batches <= 8, latency bound): the 9 x CIN x COUT weights in LDS -- every lane reads the same address (a broadcast), operands
+    // arrive as registers.  Through a plain global pointer each weight quad is a 64-lane global_load with identical addresses, 144 per
+    // wave: 5 us of address-unit time in a single frame (as scalar loads the SGPR file holds an eighth of them at a time and the FMAs wait
+    // for every batch: 1 us slower than LDS).  Large batches keep the global loads: there the kernel is bound by the image traffic, the
+    // weight quads hit the vector L1, and the LDS reads measured 340 -> 540 us at 256 frames.
+    constexpr bool WLDS = FOLD;
+    constexpr int NWQ = 9 * CIN * COUT / 4;
+    __shared__ __attribute__((aligned(16))) float s_wt[WLDS ? NWQ * 4 : 4];
     const int t = threadIdx.x, b = blockIdx.z;
+    XFH_STAMP(a, 0);
     // XCD-aware tile order.  Workgroups go round robin over the eight XCDs (each with its own L2), so with the plain order two
     // neighbouring tiles never share an L2 and every halo line is fetched twice from the fabric: calibrated counters
     // (profiles/pmc_traffic.json) read 2.55x the algorithmic fetch bytes for block1.2, and at that traffic the kernel sits at 84 % of the
@@ -237,7 +261,10 @@ void k_conv_direct(ConvArgs a) {
     const int tile = xcd_tile(blockIdx.x, gridDim.x), tx0 = (tile % a.tiles_x) * 16, ty0 = (tile / a.tiles_x) * 16;
     const float* in = a.in + (size_t)b * a.in_stride;
     __shared__ float s_stat[FOLD ? 2 * CIN : 1];
-    if constexpr (FOLD) stage_stat(a.st, b, CIN, tile == 0, s_stat, s_red, t, 256);                // s_red is free until the epilogue
+    static_assert(NWQ <= 256, "one weight quad per thread");
+    f32x4 wq4 = {0.f, 0.f, 0.f, 0.f};
+    if (WLDS && t < NWQ) wq4 = *(const f32x4*)(a.w + t * 4);
+    // (FOLD: the producer's statistics are folded below, AFTER this workgroup's input loads are in flight -- one memory round trip, not two)
     const float* st = a.st.stat + (size_t)b * 2 * (PRO == PRO_IN ? 1 : CIN);                      // wave-uniform: scalar loads
 
     // stage the activated input tile, zero outside the image (Conv2d zero padding)
@@ -256,6 +283,7 @@ void k_conv_direct(ConvArgs a) {
             const int gy = ty0 * ST - 2 + iy, gx = tx0 * ST - 2 + ix;
             xv[k] = in[(size_t)min(max(gy, 0), a.Hin - 1) * a.Win + min(max(gx, 0), a.Win - 1)];
         }
+        if constexpr (FOLD) stage_stat<16>(a.st, b, CIN, tile == 0, s_stat, s_red, t, 256);            // s_red is free until the epilogue
 #pragma unroll
         for (int k = 0; k < NX; ++k) {
             const int item = t + k * 256, iy = item / XW, ix = item % XW;
@@ -272,7 +300,7 @@ void k_conv_direct(ConvArgs a) {
                 const float* sp = s_x + iy * XS + ix;
                 const float win[9] = {sp[0], sp[1], sp[2], sp[XS], sp[XS + 1], sp[XS + 2], sp[2 * XS], sp[2 * XS + 1], sp[2 * XS + 2]};
                 float acc[4];
-                l0_conv(win, a.w0, acc);
+                l0_conv(win, (const XFH_CONST float*)a.w0, acc);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     if constexpr (EPI == EPI_BIAS_RELU) v[q] = fmaxf(acc[q] + a.bias0[q], 0.f);
@@ -301,6 +329,7 @@ void k_conv_direct(ConvArgs a) {
                 else iv[k][g].x = p[0];
             }
         }
+        if constexpr (FOLD) stage_stat<16>(a.st, b, CIN, tile == 0, s_stat, s_red, t, 256);            // s_red is free until the epilogue
 #pragma unroll
         for (int k = 0; k < NI; ++k) {
             const int pix = t + k * 256;
@@ -323,12 +352,17 @@ void k_conv_direct(ConvArgs a) {
             }
         }
     }
+    if (WLDS && t < NWQ) *(f32x4*)(s_wt + t * 4) = wq4;
     __syncthreads();
+    XFH_STAMP(a, 3);
 
     const int tx = t & 15, ty = t >> 4;
     float acc[COUT];
 #pragma unroll
     for (int co = 0; co < COUT; ++co) acc[co] = 0.f;
+#if defined(XFH_ABL) && (XFH_ABL & 2)
+    if (a.Hin < 0)                    // ablation: no compute
+#endif
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -346,12 +380,23 @@ void k_conv_direct(ConvArgs a) {
             }
 #pragma unroll
             for (int ci = 0; ci < CIN; ++ci) {
-                const float* wr = a.w + ((ky * 3 + kx) * CIN + ci) * COUT;     // wave-uniform: scalar loads
+                if constexpr (WLDS) {
+                    const float* wr = s_wt + ((ky * 3 + kx) * CIN + ci) * COUT;
 #pragma unroll
-                for (int co = 0; co < COUT; ++co) acc[co] = fmaf(v[ci], wr[co], acc[co]);
+                    for (int g4 = 0; g4 < COUT / 4; ++g4) {
+                        const f32x4 w4 = *(const f32x4*)(wr + g4 * 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[g4 * 4 + e] = fmaf(v[ci], w4[e], acc[g4 * 4 + e]);
+                    }
+                } else {
+                    const float* wr = a.w + ((ky * 3 + kx) * CIN + ci) * COUT;     // wave-uniform (scalar loads through XFH_CONST measured the same at 256 frames)
+#pragma unroll
+                    for (int co = 0; co < COUT; ++co) acc[co] = fmaf(v[ci], wr[co], acc[co]);
+                }
             }
         }
 
+    XFH_STAMP(a, 4);
     const int oy = ty0 + ty, ox = tx0 + tx;
     const bool valid = oy < a.Hout && ox < a.Wout;
     if constexpr (EPI == EPI_BIAS_RELU) {
@@ -365,6 +410,9 @@ void k_conv_direct(ConvArgs a) {
             *(f32x4*)(o + g * 4) = f32x4{acc[g * 4], acc[g * 4 + 1], acc[g * 4 + 2], acc[g * 4 + 3]};
     }
     if constexpr (EPI != EPI_STATS) return;
+#if defined(XFH_ABL) && (XFH_ABL & 1)
+    if (a.Hin > 0) return;          // ablation: no statistics epilogue
+#endif
     // per-channel fp64 partial sums of this tile: thread (c, j) adds the pixels j, j + SL, ... of channel c, the slices
     // of a wave are folded with shuffles and the four waves through LDS -- a fixed order, and no serial chain
     __syncthreads();                                      // every thread is done with the input tile: its memory becomes s_out
@@ -386,6 +434,7 @@ void k_conv_direct(ConvArgs a) {
     __syncthreads();
     if (t < 2 * COUT)
         a.part[(size_t)b * a.part_stride + (size_t)tile * COUT * 2 + t] = (s_red[t] + s_red[2 * COUT + t]) + (s_red[4 * COUT + t] + s_red[6 * COUT + t]);
+    XFH_STAMP(a, 5);
 }
 
 // Epilogue shared by k_conv_mfma and k_conv_mfma_p.  C/D layout of v_mfma_f32_32x32x2_f32: a lane holds channel (lane&31) of
@@ -882,27 +931,33 @@ void k_conv_mfma_p(ConvArgs a, int ntile, int total) {
 //   ds_read_b128 per operand feeds four consecutive MFMAs; D: register r = pixel 4q + r, lane column p = channel.
 // Workgroup = PGY pixel groups (GW x 16/GW pixels each, stacked vertically) x COUT/16 channel groups; staging, weight streaming
 // (one tap x 64 channels per chunk through two LDS buffers, PD chunks in flight in registers) and statistics partials as in k_conv_mfma.
-template <int CIN, int COUT, int ST, int GW, int PGY, int PRO, int EPI, int PD = 3>
-__global__ __launch_bounds__(64 * PGY * (COUT / 16))
+template <int CIN, int COUT, int ST, int GW, int PGY, int PRO, int EPI, int PD = 3, int CGS = 1>
+__global__ __launch_bounds__(64 * PGY * (COUT / 16 / CGS))
 void k_conv_mfma16(ConvArgs a) {
     static_assert(PRO == PRO_BN || PRO == PRO_FUSE, "3x3 layers behind a BatchNorm (block_fusion.0: + the pyramid sum)");
-    constexpr int GH = 16 / GW, CG = COUT / 16, NW = PGY * CG, NTHR = 64 * NW;
+    // CGS: the output channels are split over CGS workgroups (blockIdx.y) of CG = COUT / 16 / CGS channel groups each -- same tiles, same
+    // partials, more SIMDs: a single frame's 20-150 tiles x 8 waves put two dependent MFMA chains on every SIMD they touch (the f32
+    // MFMA pipe runs one at a time: 38 ns per step instead of 17) while most of the 1024 SIMDs have nothing to do
+    constexpr int GH = 16 / GW, CG = COUT / 16 / CGS, COUTW = CG * 16, NW = PGY * CG, NTHR = 64 * NW;
+    static_assert(COUT % (16 * CGS) == 0, "channel split");
     constexpr int TH = GH * PGY, TW = GW, TIH = (TH - 1) * ST + 3, TIW = (TW - 1) * ST + 3, CP = CIN + 4;
     constexpr int CB = 64, NCB = CIN / CB, NCHUNK = 9 * NCB, KC = CB, WS = KC + 4;
-    constexpr int WCH = COUT * KC, NWLD = (WCH / 4 + NTHR - 1) / NTHR;
+    constexpr int WCH = COUT * KC /* a chunk in memory */, WCW = COUTW * KC /* this workgroup's rows of it */, NWLD = (WCW / 4 + NTHR - 1) / NTHR;
     constexpr int G = CIN / 8, NITEM = TIH * TIW * G, NIT = (NITEM + NTHR - 1) / NTHR;
-    constexpr int IN_FLOATS = TIH * TIW * CP, W_FLOATS = COUT * WS;
+    constexpr int IN_FLOATS = TIH * TIW * CP, W_FLOATS = COUTW * WS;
     static_assert(sizeof(double) * 512 <= sizeof(float) * IN_FLOATS, "bn_fold scratch in the input tile");
-    static_assert(sizeof(double) * PGY * COUT * 2 <= sizeof(float) * IN_FLOATS, "statistics scratch in the input tile");
+    static_assert(sizeof(double) * PGY * COUTW * 2 <= sizeof(float) * IN_FLOATS, "statistics scratch in the input tile");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_in = smem;
-    float* s_w = smem + IN_FLOATS;               // two buffers of W_FLOATS
-    float* s_stat = s_w + 2 * W_FLOATS;          // 2 * CIN (PRO_FUSE: 3 * 128)
+    float* s_w = smem + IN_FLOATS;               // three buffers of W_FLOATS
+    float* s_stat = s_w + 3 * W_FLOATS;          // 2 * CIN (PRO_FUSE: 3 * 128)
 
     const int t = threadIdx.x, b = blockIdx.z;
     const int tile = blockIdx.x, tx0 = (tile % a.tiles_x) * TW, ty0 = (tile / a.tiles_x) * TH;
     const float* in = a.in + (size_t)b * a.in_stride;
+    const int co0 = blockIdx.y * COUTW;                    // first output channel of this workgroup
+    const float* wg = a.w + (size_t)co0 * KC;              // its rows of chunk 0
 
     XFH_STAMP(a, 0);
     // weight chunks in flight: PD of them, in a ring of register sets (chunk c in set c % PD).  With one chunk ahead the K loop of a
@@ -913,7 +968,7 @@ void k_conv_mfma16(ConvArgs a) {
 #pragma unroll
         for (int q = 0; q < NWLD; ++q) {
             const int f = t + q * NTHR;
-            if (c < NCHUNK && f < WCH / 4) wreg[c][q] = *(const f32x4*)(a.w + (size_t)c * WCH + (size_t)f * 4);
+            if (c < NCHUNK && f < WCW / 4) wreg[c][q] = *(const f32x4*)(wg + (size_t)c * WCH + (size_t)f * 4);
         }
     f32x4 r0[NIT], r1[NIT];
 #pragma unroll
@@ -925,10 +980,10 @@ void k_conv_mfma16(ConvArgs a) {
         r1[k] = *(const f32x4*)(p + 4);
     }
     XFH_STAMP(a, 1);
-    stage_stat(a.st, b, CIN, tile == 0, s_stat, (double*)s_in, t, NTHR);
+    stage_stat<16>(a.st, b, CIN, tile == 0, s_stat, (double*)s_in, t, NTHR);
     if constexpr (PRO == PRO_FUSE) {
-        stage_stat(a.st4, b, 64, tile == 0, s_stat + 128, (double*)s_in, t, NTHR);
-        stage_stat(a.st5, b, 64, tile == 0, s_stat + 256, (double*)s_in, t, NTHR);
+        stage_stat<16>(a.st4, b, 64, tile == 0, s_stat + 128, (double*)s_in, t, NTHR);
+        stage_stat<16>(a.st5, b, 64, tile == 0, s_stat + 256, (double*)s_in, t, NTHR);
     }
     XFH_STAMP(a, 2);
 #pragma unroll
@@ -946,13 +1001,14 @@ void k_conv_mfma16(ConvArgs a) {
             v1[e] = fmaxf((v1[e] - m1[e]) * q1[e], 0.f);
         }
         if constexpr (PRO == PRO_FUSE) {                // x3 + up2(x4) + up4(x5) with ATen's bilinear arithmetic (XFeat.cc:159-166)
-            if (ok) {
-                f32x4 u0, u1, w0, w1;
-                up_bilinear8(a.r4 + (size_t)b * a.s4, s_stat + 128, a.H4, a.W4, a.Hin, a.Win, gy, gx, g, u0, u1);
-                up_bilinear8(a.r5 + (size_t)b * a.s5, s_stat + 256, a.H5, a.W5, a.Hin, a.Win, gy, gx, g, w0, w1);
+            // no branch around the sixteen tap loads of an item (clamped coordinates; what lies outside the image is zeroed below): behind
+            // `if (ok)` the items of a thread fetched their taps one memory round trip after the other
+            const int cy = min(max(gy, 0), a.Hin - 1), cx = min(max(gx, 0), a.Win - 1);
+            f32x4 u0, u1, w0, w1;
+            up_bilinear8(a.r4 + (size_t)b * a.s4, s_stat + 128, a.H4, a.W4, a.Hin, a.Win, cy, cx, g, u0, u1);
+            up_bilinear8(a.r5 + (size_t)b * a.s5, s_stat + 256, a.H5, a.W5, a.Hin, a.Win, cy, cx, g, w0, w1);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { v0[e] = (v0[e] + u0[e]) + w0[e]; v1[e] = (v1[e] + u1[e]) + w1[e]; }
-            }
+            for (int e = 0; e < 4; ++e) { v0[e] = (v0[e] + u0[e]) + w0[e]; v1[e] = (v1[e] + u1[e]) + w1[e]; }
         }
         if (!ok) { v0 = f32x4{0.f, 0.f, 0.f, 0.f}; v1 = v0; }
         // channels 8g + e and 8g + 4 + e sit next to each other in the group-of-16 permutation: position 4e + 2(g & 1) (+ 1)
@@ -960,15 +1016,18 @@ void k_conv_mfma16(ConvArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) *(f32x2*)(d + 4 * e) = f32x2{v0[e], v1[e]};
     }
+    static_assert(PD >= 2 && NCHUNK >= 3, "two chunks go to LDS before the loop");
 #pragma unroll
-    for (int q = 0; q < NWLD; ++q) {
-        const int f = t + q * NTHR;
-        if (f < WCH / 4) {
-            const int n = f / (KC / 4), c4 = f % (KC / 4);
-            *(f32x4*)(s_w + n * WS + c4 * 4) = wreg[0][q];
-            if (PD < NCHUNK) wreg[0][q] = *(const f32x4*)(a.w + (size_t)PD * WCH + (size_t)f * 4);
+    for (int c = 0; c < 2; ++c)                                 // chunks 0 and 1 -> LDS buffers 0 and 1; their register sets take chunks PD and PD + 1
+#pragma unroll
+        for (int q = 0; q < NWLD; ++q) {
+            const int f = t + q * NTHR;
+            if (f < WCW / 4) {
+                const int n = f / (KC / 4), c4 = f % (KC / 4);
+                *(f32x4*)(s_w + c * W_FLOATS + n * WS + c4 * 4) = wreg[c][q];
+                if (c + PD < NCHUNK) wreg[c][q] = *(const f32x4*)(wg + (size_t)(c + PD) * WCH + (size_t)f * 4);
+            }
         }
-    }
     __syncthreads();
     XFH_STAMP(a, 3);
 
@@ -976,41 +1035,53 @@ void k_conv_mfma16(ConvArgs a) {
     const int pg = wave / CG, cg = wave % CG;
     const int ly = pg * GH + p / GW, lx = p % GW;               // this lane's output pixel inside the tile (A operand row)
     float biasv = 0.f;
-    if constexpr (EPI != EPI_STATS) biasv = a.bias[cg * 16 + p];
+    if constexpr (EPI != EPI_STATS) biasv = a.bias[co0 + cg * 16 + p];
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    // K loop, software pipelined over the chunks: while the 16 MFMAs of chunk ch run (one dependent chain: the k order is the numerics
+    // contract), the operands of chunk ch + 1 are read from LDS (its weights were written one iteration earlier, before the last
+    // barrier) and the weights of chunk ch + 2 go from their registers to the third buffer.  With two buffers the chain stopped at
+    // every barrier for the write -> barrier -> read round trip: 0.6 us per chunk against 0.32 us of MFMA.
+    auto read_ops = [&](int ch, f32x4 (&av)[CB / 16], f32x4 (&bv)[CB / 16]) {
+        const int tap = ch / NCB, cb = ch % NCB, ky = tap / 3, kx = tap % 3;
+        const float* pa = s_in + ((ly * ST + ky) * TIW + lx * ST + kx) * CP + cb * CB + 4 * q;
+        const float* pw = s_w + (ch % 3) * W_FLOATS + (cg * 16 + p) * WS + 4 * q;
+#pragma unroll
+        for (int kb = 0; kb < CB / 16; ++kb) { av[kb] = *(const f32x4*)(pa + kb * 16); bv[kb] = *(const f32x4*)(pw + kb * 16); }
+    };
+    f32x4 av[CB / 16], bv[CB / 16], avn[CB / 16], bvn[CB / 16];
+    read_ops(0, av, bv);
 #pragma unroll
     for (int ch = 0; ch < NCHUNK; ++ch) {
-        {
-            const int tap = ch / NCB, cb = ch % NCB, ky = tap / 3, kx = tap % 3;
-            const float* pa = s_in + ((ly * ST + ky) * TIW + lx * ST + kx) * CP + cb * CB + 4 * q;
-            const float* pw = s_w + (ch & 1) * W_FLOATS + (cg * 16 + p) * WS + 4 * q;
+        if (ch + 1 < NCHUNK) read_ops(ch + 1, avn, bvn);
 #pragma unroll
-            for (int kb = 0; kb < CB / 16; ++kb) {
-                const f32x4 av = *(const f32x4*)(pa + kb * 16), bv = *(const f32x4*)(pw + kb * 16);
+        for (int kb = 0; kb < CB / 16; ++kb)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[j], acc, 0, 0, 0);
-            }
-        }
-        if (ch + 1 < NCHUNK) {                              // chunk ch + 1 (issued PD chunks ago) -> the other LDS buffer; its register set takes chunk ch + 1 + PD
-            float* wd = s_w + ((ch + 1) & 1) * W_FLOATS;
-            const float* wsrc = a.w + (size_t)(ch + 1 + PD) * WCH;
+            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kb][j], bv[kb][j], acc, 0, 0, 0);
+        if (ch + 2 < NCHUNK) {                              // chunk ch + 2 (issued PD chunks ago) -> the buffer chunk ch - 1 was read from; its register set takes chunk ch + 2 + PD
+            float* wd = s_w + ((ch + 2) % 3) * W_FLOATS;
+            const float* wsrc = wg + (size_t)(ch + 2 + PD) * WCH;
 #pragma unroll
             for (int u = 0; u < NWLD; ++u) {
                 const int f = t + u * NTHR;
-                if (f < WCH / 4) {
+                if (f < WCW / 4) {
                     const int n = f / (KC / 4), c4 = f % (KC / 4);
-                    *(f32x4*)(wd + n * WS + c4 * 4) = wreg[(ch + 1) % PD][u];
-                    if (ch + 1 + PD < NCHUNK) wreg[(ch + 1) % PD][u] = *(const f32x4*)(wsrc + (size_t)f * 4);
+                    *(f32x4*)(wd + n * WS + c4 * 4) = wreg[(ch + 2) % PD][u];
+                    if (ch + 2 + PD < NCHUNK) wreg[(ch + 2) % PD][u] = *(const f32x4*)(wsrc + (size_t)f * 4);
                 }
             }
         }
-        __syncthreads();
+        if (ch + 1 < NCHUNK) {
+            __syncthreads();
+#pragma unroll
+            for (int kb = 0; kb < CB / 16; ++kb) { av[kb] = avn[kb]; bv[kb] = bvn[kb]; }
+        }
     }
+    __syncthreads();
     XFH_MFMA_SETTLE();
     XFH_STAMP(a, 4);
     // ---- epilogue: register r = pixel 4q + r of the group, lane column p = channel cg*16 + p
     double sum = 0.0, sq = 0.0;
-    float* out = a.out + (size_t)b * a.out_stride + cg * 16 + p;
+    float* out = a.out + (size_t)b * a.out_stride + co0 + cg * 16 + p;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int pi = 4 * q + r, oy = ty0 + pg * GH + pi / GW, ox = tx0 + pi % GW;
@@ -1026,13 +1097,13 @@ void k_conv_mfma16(ConvArgs a) {
         sum += __shfl_xor(sum, 16); sq += __shfl_xor(sq, 16);
         sum += __shfl_xor(sum, 32); sq += __shfl_xor(sq, 32);
         double* s_red = (double*)smem;                 // the tiles are no longer needed (all waves passed the last barrier)
-        if (q == 0) { s_red[(pg * COUT + cg * 16 + p) * 2] = sum; s_red[(pg * COUT + cg * 16 + p) * 2 + 1] = sq; }
+        if (q == 0) { s_red[(pg * COUTW + cg * 16 + p) * 2] = sum; s_red[(pg * COUTW + cg * 16 + p) * 2 + 1] = sq; }
         __syncthreads();
-        for (int co = t; co < COUT; co += NTHR) {
+        for (int co = t; co < COUTW; co += NTHR) {
             double S = 0.0, SS = 0.0;
 #pragma unroll
-            for (int m = 0; m < PGY; ++m) { S += s_red[(m * COUT + co) * 2]; SS += s_red[(m * COUT + co) * 2 + 1]; }
-            double* pp = a.part + (size_t)b * a.part_stride + ((size_t)tile * COUT + co) * 2;
+            for (int m = 0; m < PGY; ++m) { S += s_red[(m * COUTW + co) * 2]; SS += s_red[(m * COUTW + co) * 2 + 1]; }
+            double* pp = a.part + (size_t)b * a.part_stride + ((size_t)tile * COUT + co0 + co) * 2;
             pp[0] = S; pp[1] = SS;
         }
     }
@@ -1248,19 +1319,19 @@ static hipError_t conv_mfma_launch(xfh_ctx* c, const ConvArgs& a, int B, int* np
     return hipGetLastError();
 }
 
-template <int CIN, int COUT, int ST, int GW, int PGY, int PRO, int EPI>
+template <int CIN, int COUT, int ST, int GW, int PGY, int PRO, int EPI, int CGS = 1>
 static hipError_t conv_mfma16_launch(xfh_ctx* c, const ConvArgs& a, int B, int* npart_out, int layer) {
-    constexpr int GH = 16 / GW, TH = GH * PGY, TW = GW, NW = PGY * (COUT / 16);
-    constexpr size_t LDS = sizeof(float) * ((size_t)((TH - 1) * ST + 3) * ((TW - 1) * ST + 3) * (CIN + 4) + 2 * (size_t)COUT * 68 + (PRO == PRO_FUSE ? 384 : 2 * CIN));
+    constexpr int GH = 16 / GW, TH = GH * PGY, TW = GW, NW = PGY * (COUT / 16 / CGS);
+    constexpr size_t LDS = sizeof(float) * ((size_t)((TH - 1) * ST + 3) * ((TW - 1) * ST + 3) * (CIN + 4) + 3 * (size_t)(COUT / CGS) * 68 + (PRO == PRO_FUSE ? 384 : 2 * CIN));
     static_assert(LDS <= 160 * 1024, "LDS budget");
     ConvArgs aa = a;
     aa.dbg = layer;
     aa.tiles_x = (a.Wout + TW - 1) / TW;
     const int ntile = aa.tiles_x * ((a.Hout + TH - 1) / TH);
     if (npart_out) *npart_out = ntile;
-    auto kern = k_conv_mfma16<CIN, COUT, ST, GW, PGY, PRO, EPI>;
+    auto kern = k_conv_mfma16<CIN, COUT, ST, GW, PGY, PRO, EPI, 3, CGS>;
     XFH_SET_LDS_ATTR_ONCE(c, kern, LDS);
-    launch_k(c, XFH_K_CONV_MFMA, layer, kern, dim3(ntile, 1, B), dim3(64 * NW), LDS, aa);
+    launch_k(c, XFH_K_CONV_MFMA, layer, kern, dim3(ntile, CGS, B), dim3(64 * NW), LDS, aa);
     return hipGetLastError();
 }
 
@@ -1295,11 +1366,13 @@ static hipError_t conv_mfma_p_launch(xfh_ctx* c, const ConvArgs& a, int B, int* 
 //           the 8x16 form cannot fill 256 CUs, and at one wave per SIMD the K loop otherwise waits on each weight chunk).
 static bool persistent(int B) { return B > 8; }
 bool consumer_fold(int B) { return B <= 8; }
+static bool one_frame(int B) { return B <= 2; }          // k_conv_mfma16 splits its output channels over two workgroups: one wave per SIMD (see the kernel)
 static bool small_batch(int B) { return B <= 32; }      // k_conv_mfma16 for the 3x3 layers with >= 64 input channels: +23 % at B = 9, +3 % at B = 32, even at 48, -3 % at 64 (A/B on one box)
 
 template <int CIN, int COUT, int ST, int PRO>
 static hipError_t conv_direct_launch(xfh_ctx* c, const ConvArgs& a, int B, int* npart_out, int layer) {
     ConvArgs aa = a;
+    aa.dbg = layer;
     aa.tiles_x = (a.Wout + 15) / 16;
     const int ntile = aa.tiles_x * ((a.Hout + 15) / 16);
     if (npart_out) *npart_out = ntile;
@@ -1394,7 +1467,7 @@ static hipError_t launch_basic_layer_t(xfh_ctx* c, int li, const float* in, size
             // block_fusion.0 (16) builds its input x3 + up2(x4) + up4(x5) while staging.
             if (small_batch(B)) {
                 if (li == 16) { a.w = c->w.m16[li]; e = conv_mfma16_launch<64, 64, 1, 16, 2, PRO_FUSE, EPI>(c, a, B, &np, li); }
-                else { a.w = c->w.m16[li]; e = conv_mfma16_launch<64, 64, 1, 16, 2, PRO_BN, EPI>(c, a, B, &np, li); }      // 2x16 pixels, 8 waves of 16 x 16
+                else { a.w = c->w.m16[li]; e = conv_mfma16_launch<64, 64, 1, 16, 2, PRO_BN, EPI>(c, a, B, &np, li); }      // (150 tiles at VGA: split over two workgroups they no longer fit one round of 256 CUs -- measured slower)      // 2x16 pixels, 8 waves of 16 x 16
             } else {
                 a.w = c->w.alt[li];
                 if (li == 16) e = conv_mfma_launch<64, 64, 3, 1, 4, 2, 1, 16, PRO_FUSE, EPI, 32>(c, a, B, &np, li);
@@ -1409,19 +1482,19 @@ static hipError_t launch_basic_layer_t(xfh_ctx* c, int li, const float* in, size
             // stride 2 (4.5 input pixels per output pixel): 113 KB of LDS = one workgroup per CU.  Measured alternative: 4x8 pixels with
             // 32-channel chunks (60 KB, two workgroups per CU) 403 -> 558 us at B = 256 -- a workgroup streams the whole 147 KB weight
             // matrix from L2 for its tile, so halving the tile doubles that traffic; the small maps are bound by it
-            if (small_batch(B)) { a.w = c->w.m16[li]; e = conv_mfma16_launch<64, 64, 2, 8, 2, PRO_BN, EPI>(c, a, B, &np, li); }     // single frame: 4x8 pixels, 8 waves of 16 x 16
+            if (small_batch(B)) { a.w = c->w.m16[li]; e = one_frame(B) ? conv_mfma16_launch<64, 64, 2, 8, 2, PRO_BN, EPI, 2>(c, a, B, &np, li) : conv_mfma16_launch<64, 64, 2, 8, 2, PRO_BN, EPI>(c, a, B, &np, li); }     // single frame: 4x8 pixels, 8 waves of 16 x 16
             else e = conv_mfma_launch<64, 64, 3, 2, 2, 2, 1, 8, PRO_BN, EPI>(c, a, B, &np, li);
             break;
         case 10: case 11:
-            if (small_batch(B)) { a.w = c->w.m16[li]; e = conv_mfma16_launch<64, 64, 1, 8, 2, PRO_BN, EPI>(c, a, B, &np, li); }                    // 4x8 pixels, 8 waves of 16 x 16
+            if (small_batch(B)) { a.w = c->w.m16[li]; e = one_frame(B) ? conv_mfma16_launch<64, 64, 1, 8, 2, PRO_BN, EPI, 2>(c, a, B, &np, li) : conv_mfma16_launch<64, 64, 1, 8, 2, PRO_BN, EPI>(c, a, B, &np, li); }                    // 4x8 pixels, 8 waves of 16 x 16
             else { a.w = c->w.alt[li]; e = conv_mfma_launch<64, 64, 3, 1, 4, 2, 1, 8, PRO_BN, EPI, 32>(c, a, B, &np, li); }   // 16x8 pixels, 8 waves, 32-channel chunks (67 KB): half the weight streaming per pixel of the 8x8 form
             break;
         case 12:
-            if (small_batch(B)) { a.w = c->w.m16[li]; e = conv_mfma16_launch<64, 128, 2, 4, 1, PRO_BN, EPI>(c, a, B, &np, li); break; }     // single frame: 4x4 pixels, 8 waves of 16 x 16
+            if (small_batch(B)) { a.w = c->w.m16[li]; e = one_frame(B) ? conv_mfma16_launch<64, 128, 2, 4, 1, PRO_BN, EPI, 2>(c, a, B, &np, li) : conv_mfma16_launch<64, 128, 2, 4, 1, PRO_BN, EPI>(c, a, B, &np, li); break; }     // single frame: 4x4 pixels, 8 waves of 16 x 16
             a.w = c->w.alt[li]; e = conv_mfma_launch<64, 128, 3, 2, 1, 4, 1, 8, PRO_BN, EPI, 32>(c, a, B, &np, li); break;      // 32-channel chunks: 111 -> 78 KB of LDS, two workgroups per CU (212 -> 168 us at B = 256)
         case 13: case 14:       // 32-channel weight chunks: 69 KB LDS -> 2 workgroups per CU, 58 -> 50 us at B = 32
             if (!small_batch(B)) { a.w = c->w.alt[li]; e = conv_mfma_launch<128, 128, 3, 1, 4, 4, 1, 8, PRO_BN, EPI, 32>(c, a, B, &np, li); }   // 16x8 pixels x 128 channels, 16 waves (132 KB): the 590 KB weight matrix is streamed once per 128 pixels
-            else { a.w = c->w.m16[li]; e = conv_mfma16_launch<128, 128, 1, 4, 1, PRO_BN, EPI>(c, a, B, &np, li); }                                   // 4x4 pixels, 8 waves of 16 x 16
+            else { a.w = c->w.m16[li]; e = one_frame(B) ? conv_mfma16_launch<128, 128, 1, 4, 1, PRO_BN, EPI, 2>(c, a, B, &np, li) : conv_mfma16_launch<128, 128, 1, 4, 1, PRO_BN, EPI>(c, a, B, &np, li); }                                   // 4x4 pixels, 8 waves of 16 x 16
             break;
         case 15: e = conv_mfma_launch<128, 64, 1, 1, 1, 2, 1, 8, PRO_BN, EPI>(c, a, B, &np, li); break;
         case 18:                                                                                               // input: feats

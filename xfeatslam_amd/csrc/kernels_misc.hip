@@ -205,7 +205,7 @@ void k_heads_kp(const float* __restrict__ rawK, StatSrc sK,      // keypoint_hea
 #pragma unroll 2
     for (int k = 0; k < 64; ++k) {
         const float a = sA[k * HF_LD + t];
-        const float* wr = wk + k * 68;                 // wave-uniform row: scalar loads
+        const XFH_CONST float* wr = (const XFH_CONST float*)wk + k * 68;                 // wave-uniform row, constant address space: scalar loads
 #pragma unroll
         for (int n = 0; n < 65; ++n) acc[n] = fmaf(a, wr[n], acc[n]);
     }
@@ -353,14 +353,25 @@ void k_feat_norm(const float* __restrict__ feats, size_t m_stride, int npix, flo
 #define NMS_TW 64
 #define NMS_TH 16
 #define NMS_LD 72
+#define NMS_HCW (NMS_TW / 8 + 2)
+#define NMS_HCH (NMS_TH / 8 + 2)
+#define NMS_HC (NMS_HCW * NMS_HCH)
+template <bool HEAT>          // HEAT: the heatmap head is computed here (batches <= 8); otherwise k_heads_heat wrote H1 and none of its LDS is carried
 __global__ __launch_bounds__(256)
 void k_nms_score(const float* __restrict__ K1h, size_t k_stride, const float* __restrict__ H1, size_t h_stride,
                  int H, int W, float thr, u64* __restrict__ cand, size_t cand_cap, int* __restrict__ cand_count,
-                 int nms_blocks, const float* __restrict__ fn_feats, size_t fn_m_stride, int fn_npix, float* __restrict__ fn_nrm, size_t fn_n_stride) {
+                 int nms_blocks, const float* __restrict__ fn_feats, size_t fn_m_stride, int fn_npix, float* __restrict__ fn_nrm, size_t fn_n_stride,
+                 const float* __restrict__ rawH, StatSrc sH, size_t raw_stride, const float* __restrict__ wh, const float* __restrict__ bh, float* __restrict__ H1out) {
     __shared__ __attribute__((aligned(16))) float s[(NMS_TH + 4) * NMS_LD];
     __shared__ u64 keys[1024];
     __shared__ unsigned short cpx[1024];
     __shared__ int cnt, base;
+    // rawH != null (batches <= 8): heatmap_head.2 + sigmoid (k_heads_heat) computed HERE for the NMS_HC cells whose reliability this
+    // tile's scores can touch (the tile's 8 x 2 cells and a ring of one) -- 64 channels x 40 cells per workgroup, the same fma chain
+    // per cell, instead of a launch of its own in front of this one (8 us on the critical path of a single frame)
+    __shared__ float s_act[HEAT ? NMS_HC * 65 : 1];
+    __shared__ float s_hst[HEAT ? 128 : 1];
+    __shared__ float s_h1[HEAT ? NMS_HC : 1];
     const int t = threadIdx.x, b = blockIdx.z;
     if ((int)blockIdx.x >= nms_blocks) {          // riding feat-norm blocks (batches <= 8, see k_feat_norm)
         feat_norm_px(fn_feats, fn_m_stride, fn_npix, fn_nrm, fn_n_stride, b, ((int)blockIdx.x - nms_blocks) * 256 + t);
@@ -370,6 +381,19 @@ void k_nms_score(const float* __restrict__ K1h, size_t k_stride, const float* __
     const int tx0 = (blockIdx.x % tiles_x) * NMS_TW, ty0 = (blockIdx.x / tiles_x) * NMS_TH;
     const float* k = K1h + (size_t)b * k_stride;
     const float NEG = -__builtin_huge_valf();
+    const int Wh = W >> 3, Hh = H >> 3;
+    const int cxb = (tx0 >> 3) - 1, cyb = (ty0 >> 3) - 1;         // first cell column / row of the NMS_HCW x NMS_HCH cell window
+    constexpr int NHL = HEAT ? (NMS_HC * 16 + 255) / 256 : 1;
+    f32x4 hv[NHL];
+    if constexpr (HEAT) {
+        const float* rp = rawH + (size_t)b * raw_stride;
+#pragma unroll
+        for (int q = 0; q < NHL; ++q) {
+            const int item = min(t + q * 256, NMS_HC * 16 - 1), cell = item >> 4, g = item & 15;
+            const int cy = min(max(cyb + cell / NMS_HCW, 0), Hh - 1), cx = min(max(cxb + cell % NMS_HCW, 0), Wh - 1);
+            hv[q] = *(const f32x4*)(rp + ((size_t)cy * Wh + cx) * 64 + g * 4);
+        }
+    }
     if (t == 0) cnt = 0;
     for (int item = t; item < (NMS_TH + 4) * (NMS_LD / 4); item += 256) {
         const int iy = item / (NMS_LD / 4), c4 = item % (NMS_LD / 4);
@@ -378,7 +402,26 @@ void k_nms_score(const float* __restrict__ K1h, size_t k_stride, const float* __
         if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = *(const f32x4*)(k + (size_t)gy * W + gx);
         *(f32x4*)(s + iy * NMS_LD + 4 * c4) = v;
     }
+    if constexpr (HEAT) {
+        stage_stat(sH, b, 64, blockIdx.x == 0, s_hst, (double*)keys, t, 256);      // (keys: free until the scoring phase; ends with a barrier)
+#pragma unroll
+        for (int q = 0; q < NHL; ++q) {
+            const int item = t + q * 256, cell = item >> 4, g = item & 15;
+            if (item < NMS_HC * 16)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) s_act[cell * 65 + g * 4 + j] = fmaxf((hv[q][j] - s_hst[g * 4 + j]) * s_hst[64 + g * 4 + j], 0.f);
+        }
+    }
     __syncthreads();
+    if (HEAT && t < NMS_HC) {
+        float acc = 0.f;
+        for (int c = 0; c < 64; ++c) acc = fmaf(s_act[t * 65 + c], wh[c], acc);
+        acc += bh[0];
+        const float hval = 1.0f / (1.0f + expf(-acc));
+        s_h1[t] = hval;
+        const int r = t / NMS_HCW, c = t % NMS_HCW, cy = cyb + r, cx = cxb + c;
+        if (r >= 1 && r <= NMS_TH / 8 && c >= 1 && c <= NMS_TW / 8 && cy < Hh && cx < Wh) H1out[(size_t)b * h_stride + (size_t)cy * Wh + cx] = hval;   // the tile's own cells
+    }
     {
         const int tx = t & 15, ty = t >> 4;
         float m[4] = {NEG, NEG, NEG, NEG}, ctr[4] = {NEG, NEG, NEG, NEG};
@@ -401,8 +444,11 @@ void k_nms_score(const float* __restrict__ K1h, size_t k_stride, const float* __
     }
     __syncthreads();
     const int n = cnt;
-    const int Wh = W >> 3, Hh = H >> 3;
     const float* h1 = H1 + (size_t)b * h_stride;
+    auto h1_at = [&](int y, int x) -> float {        // valid cell (y, x): from the window computed above, or from the map k_heads_heat wrote
+        if constexpr (HEAT) return s_h1[min(max(y - cyb, 0), NMS_HCH - 1) * NMS_HCW + min(max(x - cxb, 0), NMS_HCW - 1)];
+        return h1[y * Wh + x];
+    };
     for (int e = t; e < n; e += 256) {
         const int ly = cpx[e] / NMS_TW, lx2 = cpx[e] % NMS_TW;
         const int gy = ty0 + ly, gx = tx0 + lx2;
@@ -417,8 +463,8 @@ void k_nms_score(const float* __restrict__ K1h, size_t k_stride, const float* __
         const float nw = ee * so, ne = w * so, sw = ee * nn, se = w * nn;
         const int x0 = (int)xw, y0 = (int)yn, x1 = x0 + 1, y1 = y0 + 1;
         const bool vx0 = x0 >= 0 && x0 < Wh, vx1 = x1 >= 0 && x1 < Wh, vy0 = y0 >= 0 && y0 < Hh, vy1 = y1 >= 0 && y1 < Hh;
-        const float a = (vx0 && vy0) ? h1[y0 * Wh + x0] : 0.f, bb = (vx1 && vy0) ? h1[y0 * Wh + x1] : 0.f;
-        const float d = (vx0 && vy1) ? h1[y1 * Wh + x0] : 0.f, g = (vx1 && vy1) ? h1[y1 * Wh + x1] : 0.f;
+        const float a = (vx0 && vy0) ? h1_at(y0, x0) : 0.f, bb = (vx1 && vy0) ? h1_at(y0, x1) : 0.f;
+        const float d = (vx0 && vy1) ? h1_at(y1, x0) : 0.f, g = (vx1 && vy1) ? h1_at(y1, x1) : 0.f;
         const float hb = ((a * nw + bb * ne) + d * sw) + g * se;
         float score = nv * hb;
         if (gx == 0 && gy == 0) score = -1.0f;                       // :281-282
@@ -1041,6 +1087,7 @@ hipError_t run_extract(xfh_ctx* c, const uint8_t* d_gray, int B, int H0, int W0,
     CK(launch_fusion_chain(c, h8, w8, B, &head_done));
     if (head_done < 1) CK(launch_basic_layer(c, 18, c->feats, c->raw_stride[17], -1, PRO_PLAIN, h8, w8, B));
     if (head_done < 2) CK(launch_basic_layer(c, 19, c->raw[18], c->raw_stride[18], 18, PRO_BN, h8, w8, B));
+    if (consumer_fold(B)) return hipGetLastError();           // small batches: heatmap_head.2 + sigmoid are computed inside k_nms_score
     hipLaunchKernelGGL(k_heads_heat, dim3((h8 * w8 + HF_PX - 1) / HF_PX, 1, B), dim3(HF_PX), 0, s,
                        (const float*)c->raw[19], stat_src(c, 19, B), c->raw_stride[19], (const float*)c->w.heat2_w, (const float*)c->w.heat2_b, h8 * w8, c->H1, xs / 64);
     return hipGetLastError();
@@ -1053,9 +1100,16 @@ hipError_t run_extract(xfh_ctx* c, const uint8_t* d_gray, int B, int H0, int W0,
     // NMS + score, top-k + placement, descriptors
     const int nms_blocks = ((W + NMS_TW - 1) / NMS_TW) * ((H + NMS_TH - 1) / NMS_TH);
     const int fn_blocks = consumer_fold(B) ? (h8 * w8 + 255) / 256 : 0;          // small batches: the feature norms ride on this launch
-    launch_k(c, XFH_K_NMS, -1, k_nms_score, dim3(nms_blocks + fn_blocks, 1, B), dim3(256), 0, c->K1h, xs, c->H1, xs / 64,
+    if (fn_blocks)
+        launch_k(c, XFH_K_NMS, -1, k_nms_score<true>, dim3(nms_blocks + fn_blocks, 1, B), dim3(256), 0, c->K1h, xs, c->H1, xs / 64,
                        H, W, c->cfg.nms_threshold, c->cand, c->cand_cap, c->cand_count,
-                       nms_blocks, (const float*)c->feats, c->raw_stride[17], h8 * w8, c->feat_nrm, xs / 64);
+                       nms_blocks, (const float*)c->feats, c->raw_stride[17], h8 * w8, c->feat_nrm, xs / 64,
+                       fn_blocks ? (const float*)c->raw[19] : (const float*)nullptr, stat_src(c, 19, B), c->raw_stride[19], (const float*)c->w.heat2_w, (const float*)c->w.heat2_b, c->H1);
+    else
+        launch_k(c, XFH_K_NMS, -1, k_nms_score<false>, dim3(nms_blocks + fn_blocks, 1, B), dim3(256), 0, c->K1h, xs, c->H1, xs / 64,
+                       H, W, c->cfg.nms_threshold, c->cand, c->cand_cap, c->cand_count,
+                       nms_blocks, (const float*)c->feats, c->raw_stride[17], h8 * w8, c->feat_nrm, xs / 64,
+                       fn_blocks ? (const float*)c->raw[19] : (const float*)nullptr, stat_src(c, 19, B), c->raw_stride[19], (const float*)c->w.heat2_w, (const float*)c->w.heat2_b, c->H1);
     CK(hipGetLastError());
     if (nf <= SEL_FAST_MAX) {
         XFH_SET_LDS_ATTR_ONCE(c, k_select, SEL_LDS_BYTES);
