@@ -1366,7 +1366,9 @@ static hipError_t conv_mfma_p_launch(xfh_ctx* c, const ConvArgs& a, int B, int* 
 //           the 8x16 form cannot fill 256 CUs, and at one wave per SIMD the K loop otherwise waits on each weight chunk).
 static bool persistent(int B) { return B > 8; }
 bool consumer_fold(int B) { return B <= 8; }
-static bool one_frame(int B) { return B <= 2; }          // k_conv_mfma16 splits its output channels over two workgroups: one wave per SIMD (see the kernel)
+// k_conv_mfma16 splits its output channels over two workgroups (one wave per SIMD, see the kernel) while the split grid still fits one
+// round of the 256 CUs; beyond that the extra staging costs more than the idle SIMDs it fills (150 tiles -> 300 workgroups: measured slower)
+static bool split_channels(int Hout, int Wout, int TH, int TW, int B) { return (long)((Hout + TH - 1) / TH) * ((Wout + TW - 1) / TW) * B <= 128; }
 static bool small_batch(int B) { return B <= 32; }      // k_conv_mfma16 for the 3x3 layers with >= 64 input channels: +23 % at B = 9, +3 % at B = 32, even at 48, -3 % at 64 (A/B on one box)
 
 template <int CIN, int COUT, int ST, int PRO>
@@ -1466,8 +1468,8 @@ static hipError_t launch_basic_layer_t(xfh_ctx* c, int li, const float* in, size
             // B = 16 (profiles/r01_conv_cfg.log).  Single frame: 2x16 pixels per workgroup, 2 waves, three taps per chunk.
             // block_fusion.0 (16) builds its input x3 + up2(x4) + up4(x5) while staging.
             if (small_batch(B)) {
-                if (li == 16) { a.w = c->w.m16[li]; e = conv_mfma16_launch<64, 64, 1, 16, 2, PRO_FUSE, EPI>(c, a, B, &np, li); }
-                else { a.w = c->w.m16[li]; e = conv_mfma16_launch<64, 64, 1, 16, 2, PRO_BN, EPI>(c, a, B, &np, li); }      // (150 tiles at VGA: split over two workgroups they no longer fit one round of 256 CUs -- measured slower)      // 2x16 pixels, 8 waves of 16 x 16
+                if (li == 16) { a.w = c->w.m16[li]; e = split_channels(Hout, Wout, 2, 16, B) ? conv_mfma16_launch<64, 64, 1, 16, 2, PRO_FUSE, EPI, 2>(c, a, B, &np, li) : conv_mfma16_launch<64, 64, 1, 16, 2, PRO_FUSE, EPI>(c, a, B, &np, li); }
+                else { a.w = c->w.m16[li]; e = split_channels(Hout, Wout, 2, 16, B) ? conv_mfma16_launch<64, 64, 1, 16, 2, PRO_BN, EPI, 2>(c, a, B, &np, li) : conv_mfma16_launch<64, 64, 1, 16, 2, PRO_BN, EPI>(c, a, B, &np, li); }      // (150 tiles at VGA: not split)      // 2x16 pixels, 8 waves of 16 x 16
             } else {
                 a.w = c->w.alt[li];
                 if (li == 16) e = conv_mfma_launch<64, 64, 3, 1, 4, 2, 1, 16, PRO_FUSE, EPI, 32>(c, a, B, &np, li);
@@ -1482,19 +1484,19 @@ static hipError_t launch_basic_layer_t(xfh_ctx* c, int li, const float* in, size
             // stride 2 (4.5 input pixels per output pixel): 113 KB of LDS = one workgroup per CU.  Measured alternative: 4x8 pixels with
             // 32-channel chunks (60 KB, two workgroups per CU) 403 -> 558 us at B = 256 -- a workgroup streams the whole 147 KB weight
             // matrix from L2 for its tile, so halving the tile doubles that traffic; the small maps are bound by it
-            if (small_batch(B)) { a.w = c->w.m16[li]; e = one_frame(B) ? conv_mfma16_launch<64, 64, 2, 8, 2, PRO_BN, EPI, 2>(c, a, B, &np, li) : conv_mfma16_launch<64, 64, 2, 8, 2, PRO_BN, EPI>(c, a, B, &np, li); }     // single frame: 4x8 pixels, 8 waves of 16 x 16
+            if (small_batch(B)) { a.w = c->w.m16[li]; e = split_channels(Hout, Wout, 4, 8, B) ? conv_mfma16_launch<64, 64, 2, 8, 2, PRO_BN, EPI, 2>(c, a, B, &np, li) : conv_mfma16_launch<64, 64, 2, 8, 2, PRO_BN, EPI>(c, a, B, &np, li); }     // single frame: 4x8 pixels, 8 waves of 16 x 16
             else e = conv_mfma_launch<64, 64, 3, 2, 2, 2, 1, 8, PRO_BN, EPI>(c, a, B, &np, li);
             break;
         case 10: case 11:
-            if (small_batch(B)) { a.w = c->w.m16[li]; e = one_frame(B) ? conv_mfma16_launch<64, 64, 1, 8, 2, PRO_BN, EPI, 2>(c, a, B, &np, li) : conv_mfma16_launch<64, 64, 1, 8, 2, PRO_BN, EPI>(c, a, B, &np, li); }                    // 4x8 pixels, 8 waves of 16 x 16
+            if (small_batch(B)) { a.w = c->w.m16[li]; e = split_channels(Hout, Wout, 4, 8, B) ? conv_mfma16_launch<64, 64, 1, 8, 2, PRO_BN, EPI, 2>(c, a, B, &np, li) : conv_mfma16_launch<64, 64, 1, 8, 2, PRO_BN, EPI>(c, a, B, &np, li); }                    // 4x8 pixels, 8 waves of 16 x 16
             else { a.w = c->w.alt[li]; e = conv_mfma_launch<64, 64, 3, 1, 4, 2, 1, 8, PRO_BN, EPI, 32>(c, a, B, &np, li); }   // 16x8 pixels, 8 waves, 32-channel chunks (67 KB): half the weight streaming per pixel of the 8x8 form
             break;
         case 12:
-            if (small_batch(B)) { a.w = c->w.m16[li]; e = one_frame(B) ? conv_mfma16_launch<64, 128, 2, 4, 1, PRO_BN, EPI, 2>(c, a, B, &np, li) : conv_mfma16_launch<64, 128, 2, 4, 1, PRO_BN, EPI>(c, a, B, &np, li); break; }     // single frame: 4x4 pixels, 8 waves of 16 x 16
+            if (small_batch(B)) { a.w = c->w.m16[li]; e = split_channels(Hout, Wout, 4, 4, B) ? conv_mfma16_launch<64, 128, 2, 4, 1, PRO_BN, EPI, 2>(c, a, B, &np, li) : conv_mfma16_launch<64, 128, 2, 4, 1, PRO_BN, EPI>(c, a, B, &np, li); break; }     // single frame: 4x4 pixels, 8 waves of 16 x 16
             a.w = c->w.alt[li]; e = conv_mfma_launch<64, 128, 3, 2, 1, 4, 1, 8, PRO_BN, EPI, 32>(c, a, B, &np, li); break;      // 32-channel chunks: 111 -> 78 KB of LDS, two workgroups per CU (212 -> 168 us at B = 256)
         case 13: case 14:       // 32-channel weight chunks: 69 KB LDS -> 2 workgroups per CU, 58 -> 50 us at B = 32
             if (!small_batch(B)) { a.w = c->w.alt[li]; e = conv_mfma_launch<128, 128, 3, 1, 4, 4, 1, 8, PRO_BN, EPI, 32>(c, a, B, &np, li); }   // 16x8 pixels x 128 channels, 16 waves (132 KB): the 590 KB weight matrix is streamed once per 128 pixels
-            else { a.w = c->w.m16[li]; e = one_frame(B) ? conv_mfma16_launch<128, 128, 1, 4, 1, PRO_BN, EPI, 2>(c, a, B, &np, li) : conv_mfma16_launch<128, 128, 1, 4, 1, PRO_BN, EPI>(c, a, B, &np, li); }                                   // 4x4 pixels, 8 waves of 16 x 16
+            else { a.w = c->w.m16[li]; e = split_channels(Hout, Wout, 4, 4, B) ? conv_mfma16_launch<128, 128, 1, 4, 1, PRO_BN, EPI, 2>(c, a, B, &np, li) : conv_mfma16_launch<128, 128, 1, 4, 1, PRO_BN, EPI>(c, a, B, &np, li); }                                   // 4x4 pixels, 8 waves of 16 x 16
             break;
         case 15: e = conv_mfma_launch<128, 64, 1, 1, 1, 2, 1, 8, PRO_BN, EPI>(c, a, B, &np, li); break;
         case 18:                                                                                               // input: feats
