@@ -490,7 +490,10 @@ __device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[NT], float* __
 // implicit-GEMM convolution on the f32 matrix cores.
 //   WM x WN waves per workgroup; each wave owns 32 output pixels (WH x WW) and NT tiles of 32
 //   output channels.  COUTP = WN*NT*32 >= COUT (padded weight rows are zero).
-template <int CIN, int COUT, int KS, int ST, int WM, int WN, int NT, int WW, int PRO, int EPI, int CBMAX = 64, int TPC = 1>
+#ifndef XFH_PD
+#define XFH_PD 3
+#endif
+template <int CIN, int COUT, int KS, int ST, int WM, int WN, int NT, int WW, int PRO, int EPI, int CBMAX = 64, int TPC = 1, int PD = XFH_PD>
 __global__ __launch_bounds__(64 * WM * WN)
 void k_conv_mfma(ConvArgs a) {
     constexpr int NTHR = 64 * WM * WN;
@@ -524,12 +527,17 @@ void k_conv_mfma(ConvArgs a) {
 
     XFH_STAMP(a, 0);
     // ---- issue the first weight chunk, stage producer statistics ------------------------
-    f32x4 wreg[NWLD];
+    // PD weight chunks are in flight in a ring of register sets (chunk c in set c % PD).  PD = 1 suffices when two or more workgroups
+    // share a CU; the kernels that run one workgroup of four waves per CU waited at every chunk for the next one's weights (1.6 us per
+    // chunk of 0.85 us of MFMAs in the stride-2 64 -> 64 layer at 256 frames)
+    f32x4 wreg[PD][NWLD];
 #pragma unroll
-    for (int q = 0; q < NWLD; ++q) {
-        const int f = t + q * NTHR;
-        if (f < WCH / 4) wreg[q] = *(const f32x4*)(a.w + (size_t)f * 4);
-    }
+    for (int c = 0; c < PD; ++c)
+#pragma unroll
+        for (int q = 0; q < NWLD; ++q) {
+            const int f = t + q * NTHR;
+            if (c < NCHUNK && f < WCH / 4) wreg[c][q] = *(const f32x4*)(a.w + (size_t)c * WCH + (size_t)f * 4);
+        }
     // ---- the raw input tile: every load of a thread is issued here, before the statistics are staged and before the first use
     // (clamped addresses, no branches around the loads: behind a per-item branch they run one memory round trip after the other,
     // and with one or two workgroups per CU nothing else covers that).  PRO_FUSE gathers its taps per item below.
@@ -631,7 +639,8 @@ void k_conv_mfma(ConvArgs a) {
         const int f = t + q * NTHR;
         if (f < WCH / 4) {
             const int n = f / (KC / 4), c4 = f % (KC / 4);
-            *(f32x4*)(s_w + n * WS + c4 * 4) = wreg[q];
+            *(f32x4*)(s_w + n * WS + c4 * 4) = wreg[0][q];
+            if (PD < NCHUNK) wreg[0][q] = *(const f32x4*)(a.w + (size_t)PD * WCH + (size_t)f * 4);
         }
     }
     __syncthreads();
@@ -650,15 +659,8 @@ void k_conv_mfma(ConvArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
 
-    for (int ch = 0; ch < NCHUNK; ++ch) {
-        if (ch + 1 < NCHUNK) {
-            const float* wsrc = a.w + (size_t)(ch + 1) * WCH;
 #pragma unroll
-            for (int q = 0; q < NWLD; ++q) {
-                const int f = t + q * NTHR;
-                if (f < WCH / 4) wreg[q] = *(const f32x4*)(wsrc + (size_t)f * 4);
-            }
-        }
+    for (int ch = 0; ch < NCHUNK; ++ch) {
 #pragma unroll
         for (int tt = 0; tt < TPC; ++tt) {
             const int tap = TPC == 1 ? ch / NCB : ch * TPC + tt, cb = TPC == 1 ? ch % NCB : 0;
@@ -677,14 +679,16 @@ void k_conv_mfma(ConvArgs a) {
                 }
             }
         }
-        if (ch + 1 < NCHUNK) {
+        if (ch + 1 < NCHUNK) {                              // chunk ch + 1 (issued PD chunks ago) -> the other LDS buffer; its register set takes chunk ch + 1 + PD
             float* wd = s_w + ((ch + 1) & 1) * W_FLOATS;
+            const float* wsrc = a.w + (size_t)(ch + 1 + PD) * WCH;
 #pragma unroll
             for (int q = 0; q < NWLD; ++q) {
                 const int f = t + q * NTHR;
                 if (f < WCH / 4) {
                     const int n = f / (KC / 4), c4 = f % (KC / 4);
-                    *(f32x4*)(wd + n * WS + c4 * 4) = wreg[q];
+                    *(f32x4*)(wd + n * WS + c4 * 4) = wreg[(ch + 1) % PD][q];
+                    if (ch + 1 + PD < NCHUNK) wreg[(ch + 1) % PD][q] = *(const f32x4*)(wsrc + (size_t)f * 4);
                 }
             }
         }
