@@ -146,5 +146,7 @@ inline void launch_k(xfh_ctx* c, int kernel_id, int layer, K kern, dim3 grid, di
     } while (0)
 
 // launchers (kernels_*.hip)
+bool ride_mode(const xfh_ctx* c, int B);      // batches <= 8, batch statistics: the keypoint branch rides on block1.3 .. block3.0 (kernels_conv.hip)
+hipError_t launch_layer_with_rider(xfh_ctx* c, int li, const float* in, size_t in_stride, int src, int pro, int Hin, int Win, int B, const float* K1h, size_t k1h_stride);
 hipError_t run_extract(xfh_ctx* c, const uint8_t* d_gray, int B, int H0, int W0, int lap0, int lap1, uint8_t* d_records, bool write_padding = true,
                        float* d_images = nullptr);

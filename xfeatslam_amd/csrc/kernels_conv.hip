@@ -20,6 +20,7 @@
 // exactly what the f32 MFMA computes when K is walked in order with a single accumulator,
 // and what oracle/xfeat_oracle.c does; statistics are fp64.
 #include "ctx.h"
+#include "heads_kp4.hip.h"
 #include <stdlib.h>
 
 struct ConvArgs {
@@ -493,9 +494,9 @@ __device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[NT], float* __
 #ifndef XFH_PD
 #define XFH_PD 3
 #endif
+// The body is a device function of (tile, frame) so that it can also run as a RIDER in another layer's launch (k_conv_mfma_ride below).
 template <int CIN, int COUT, int KS, int ST, int WM, int WN, int NT, int WW, int PRO, int EPI, int CBMAX = 64, int TPC = 1, int PD = XFH_PD>
-__global__ __launch_bounds__(64 * WM * WN)
-void k_conv_mfma(ConvArgs a) {
+__device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, const int tile, const int b, float* smem) {
     constexpr int NTHR = 64 * WM * WN;
     constexpr int WH = 32 / WW, TH = WM * WH, TW = WW;
     constexpr int COUTP = WN * NT * 32;
@@ -516,13 +517,12 @@ void k_conv_mfma(ConvArgs a) {
     constexpr int IN_FLOATS = TIH * TIW * CP;
     constexpr int W_FLOATS = COUTP * WS;
 
-    extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_in = smem;
     float* s_w = smem + IN_FLOATS;               // two buffers of W_FLOATS
     float* s_stat = s_w + NWBUF * W_FLOATS;      // 2*CIN floats (PRO_BN), 4*CIN (PRO_B2IN: + skip weights / bias), 3*128 (PRO_FUSE)
 
-    const int t = threadIdx.x, b = blockIdx.z;
-    const int tile = blockIdx.x, tx0 = (tile % a.tiles_x) * TW, ty0 = (tile / a.tiles_x) * TH;
+    const int t = threadIdx.x;
+    const int tx0 = (tile % a.tiles_x) * TW, ty0 = (tile / a.tiles_x) * TH;
     const float* in = a.in + (size_t)b * a.in_stride;
 
     XFH_STAMP(a, 0);
@@ -725,6 +725,33 @@ void k_conv_mfma(ConvArgs a) {
         }
     }
     XFH_STAMP(a, 5);
+}
+
+template <int CIN, int COUT, int KS, int ST, int WM, int WN, int NT, int WW, int PRO, int EPI, int CBMAX = 64, int TPC = 1, int PD = XFH_PD>
+__global__ __launch_bounds__(64 * WM * WN)
+void k_conv_mfma(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    conv_mfma_body<CIN, COUT, KS, ST, WM, WN, NT, WW, PRO, EPI, CBMAX, TPC, PD>(a, blockIdx.x, blockIdx.z, smem);
+}
+
+// k_conv_mfma_ride: a backbone layer (the HOST: its tiles are the workgroups below n_host) and, in the same launch, one step of the
+// keypoint branch (the RIDER: the workgroups from n_host on).  For batches <= 8 in the reference's batch-statistics mode the branch
+// -- keypoint_head.0-2 (1x1 convolutions on unfold2d(x-hat)) and keypoint_head.3 + softmax + depth-to-space -- does not get a stream of
+// its own: its four dependent steps ride on block1.3, block2.0, block2.1 and block3.0, which follow each other on the one stream
+// anyway.  Forking a second stream costs the main queue 7-11 us (a hipEventRecord there is a barrier packet with a signal; attaching
+// the event to a kernel's completion signal measured the same) and any wait on another queue as much; a rider costs nothing but CUs
+// that the host's 150 tiles leave idle.  Host and rider never touch each other's tensors.  256 threads: the kp4 rider uses the first 128
+// (the other two waves leave at once; a terminated wave does not take part in s_barrier).
+enum { RIDE_UNFOLD = 0 /* keypoint_head.0 */, RIDE_BN = 1 /* keypoint_head.1 / .2 */, RIDE_KP4 = 2 /* keypoint_head.3 + softmax */ };
+template <int CIN, int COUT, int KS, int ST, int WM, int WN, int NT, int WW, int PRO, int CBMAX, int TPC, int RIDER>
+__global__ __launch_bounds__(256)
+void k_conv_mfma_ride(ConvArgs a, int n_host, ConvArgs r, Kp4Args k) {
+    static_assert(WM * WN == 4, "256 threads");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int blk = blockIdx.x;
+    if (blk < n_host) conv_mfma_body<CIN, COUT, KS, ST, WM, WN, NT, WW, PRO, EPI_STATS, CBMAX, TPC>(a, blk, blockIdx.z, smem);
+    else if constexpr (RIDER == RIDE_KP4) { if (threadIdx.x < 4 * HK4_PX) heads_kp4_body(k, blk - n_host, blockIdx.z, smem); }
+    else conv_mfma_body<64, 64, 1, 1, 4, 1, 2, 16, RIDER == RIDE_UNFOLD ? PRO_UNFOLD : PRO_BN, EPI_STATS>(r, blk - n_host, blockIdx.z, smem);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1524,6 +1551,82 @@ static hipError_t launch_basic_layer_t(xfh_ctx* c, int li, const float* in, size
     hipLaunchKernelGGL(k_bn_finalize, dim3(B), dim3(256), 0, c->stream, (const double*)c->part[li], c->part_stride[li], np,
                        L.cout, (double)Hout * (double)Wout, c->stat[li]);
     return hipGetLastError();
+}
+
+// ---- a backbone layer with a rider (k_conv_mfma_ride): batches <= 8, batch-statistics mode -------------------------------------
+// ConvArgs of BasicLayer li in the batch-statistics mode (the part of launch_basic_layer_t that does not depend on the kernel form)
+static ConvArgs stats_layer_args(xfh_ctx* c, int li, const float* in, size_t in_stride, int src, int pro, int Hin, int Win, int B, int TH, int TW, int* ntile) {
+    const LayerSpec& L = XFH_LAYERS[li];
+    const int pad = L.ks / 2;
+    const int Hout = (Hin + 2 * pad - L.ks) / L.stride + 1, Wout = (Win + 2 * pad - L.ks) / L.stride + 1;
+    c->lh[li] = Hout; c->lw[li] = Wout;
+    ConvArgs a{};
+    a.in = in; a.in_stride = in_stride; a.Hin = Hin; a.Win = Win;
+    if (src >= 0) a.st = stat_src(c, src, B);
+    a.w = c->w.mfma[li];
+    a.out = c->raw[li]; a.out_stride = c->raw_stride[li]; a.Hout = Hout; a.Wout = Wout;
+    a.part = c->part[li]; a.part_stride = c->part_stride[li];
+    a.xstat = c->xstat;
+    if (pro == PRO_B2IN) {
+        const size_t xs = (size_t)c->Hmax * c->Wmax;
+        a.pool = c->skip_pool; a.pool_stride = xs / 16; a.skip_w = c->w.skip_w; a.skip_b = c->w.skip_b;
+    }
+    a.dbg = li;
+    a.tiles_x = (Wout + TW - 1) / TW;
+    *ntile = a.tiles_x * ((Hout + TH - 1) / TH);
+    c->npart[li] = *ntile;
+    return a;
+}
+template <int CIN, int COUT, int KS, int ST, int WM, int WN, int NT, int WW, int PRO, int CBMAX, int TPC, int RIDER>
+static hipError_t ride_launch(xfh_ctx* c, const ConvArgs& a, int n_host, const ConvArgs& r, const Kp4Args& k, int n_rider, int B, int layer) {
+    constexpr int WH = 32 / WW, TH = WM * WH, TW = WW, COUTP = WN * NT * 32;
+    constexpr int TIH = (TH - 1) * ST + KS, TIW = (TW - 1) * ST + KS;
+    constexpr int CB = CIN > CBMAX ? CBMAX : CIN;
+    constexpr int NWBUF = (KS * KS * (CIN / CB) / TPC) > 1 ? 2 : 1;
+    constexpr int STATF = PRO == PRO_B2IN ? 4 * CIN : 2 * CIN;
+    constexpr size_t LDS_HOST = sizeof(float) * ((size_t)TIH * TIW * (CIN + 4) + NWBUF * (size_t)COUTP * (TPC * CB + 4) + STATF);
+    constexpr size_t LDS_1X1 = sizeof(float) * ((size_t)8 * 16 * 68 + (size_t)64 * 68 + 128);      // k_conv_mfma<64, 64, 1, 1, 4, 1, 2, 16>
+    constexpr size_t LDS_RIDER = RIDER == RIDE_KP4 ? sizeof(float) * HK4_LDS_FLOATS : LDS_1X1;
+    constexpr size_t LDS = LDS_HOST > LDS_RIDER ? LDS_HOST : LDS_RIDER;
+    static_assert(LDS <= 160 * 1024, "LDS budget");
+    static_assert(sizeof(double) * WM * COUTP * 2 <= LDS_HOST && sizeof(double) * 512 <= sizeof(float) * (size_t)TIH * TIW * (CIN + 4), "scratch");
+    auto kern = k_conv_mfma_ride<CIN, COUT, KS, ST, WM, WN, NT, WW, PRO, CBMAX, TPC, RIDER>;
+    XFH_SET_LDS_ATTR_ONCE(c, kern, LDS);
+    launch_k(c, XFH_K_CONV_MFMA, layer, kern, dim3(n_host + n_rider, 1, B), dim3(256), LDS, a, n_host, r, k);
+    return hipGetLastError();
+}
+bool ride_mode(const xfh_ctx* c, int B) { return consumer_fold(B) && c->cfg.bn_mode == XFH_BN_BATCH_STATS; }      // (A/B on one box: +9.5 % at 2 frames, +5.5 % at 4, even at 8)
+// host: BasicLayer li in 3 .. 6 (block1.3, block2.0, block2.1, block3.0); rider: step li - 3 of the keypoint branch
+hipError_t launch_layer_with_rider(xfh_ctx* c, int li, const float* in, size_t in_stride, int src, int pro, int Hin, int Win, int B,
+                                   const float* K1h, size_t k1h_stride) {
+    const int h8 = c->H / 8, w8 = c->W / 8;
+    const size_t xs = (size_t)c->Hmax * c->Wmax;
+    int nh = 0, nr = 0;
+    ConvArgs r{}; Kp4Args k{};
+    switch (li) {
+        case 3: {
+            ConvArgs a = stats_layer_args(c, li, in, in_stride, src, pro, Hin, Win, B, 8, 16, &nh); a.w = c->w.alt[li];
+            r = stats_layer_args(c, 20, c->X, xs, -1, PRO_UNFOLD, h8, w8, B, 8, 16, &nr);
+            return ride_launch<8, 24, 3, 2, 4, 1, 1, 16, PRO_BN, 64, 9, RIDE_UNFOLD>(c, a, nh, r, k, nr, B, li);
+        }
+        case 4: {
+            ConvArgs a = stats_layer_args(c, li, in, in_stride, src, pro, Hin, Win, B, 8, 16, &nh); a.w = c->w.alt[li];
+            r = stats_layer_args(c, 21, c->raw[20], c->raw_stride[20], 20, PRO_BN, h8, w8, B, 8, 16, &nr);
+            return ride_launch<24, 24, 3, 1, 4, 1, 1, 16, PRO_B2IN, 64, 9, RIDE_BN>(c, a, nh, r, k, nr, B, li);
+        }
+        case 5: {
+            ConvArgs a = stats_layer_args(c, li, in, in_stride, src, pro, Hin, Win, B, 8, 16, &nh); a.w = c->w.alt[li];
+            r = stats_layer_args(c, 22, c->raw[21], c->raw_stride[21], 21, PRO_BN, h8, w8, B, 8, 16, &nr);
+            return ride_launch<24, 24, 3, 1, 4, 1, 1, 16, PRO_BN, 64, 9, RIDE_BN>(c, a, nh, r, k, nr, B, li);
+        }
+        case 6: {
+            ConvArgs a = stats_layer_args(c, li, in, in_stride, src, pro, Hin, Win, B, 8, 16, &nh); a.w = c->w.alt[li];
+            k = Kp4Args{(const float*)c->raw[22], stat_src(c, 22, B), c->raw_stride[22], (const float*)c->w.kp3_w, (const float*)c->w.kp3_b, h8, w8, const_cast<float*>(K1h), k1h_stride};
+            nr = (h8 * w8 + HK4_PX - 1) / HK4_PX;
+            return ride_launch<24, 64, 3, 2, 4, 1, 2, 16, PRO_BN, 64, 3, RIDE_KP4>(c, a, nh, r, k, nr, B, li);
+        }
+        default: return hipErrorInvalidValue;
+    }
 }
 
 hipError_t launch_basic_layer(xfh_ctx* c, int li, const float* in, size_t in_stride, int src, int pro, int Hin, int Win, int B) {

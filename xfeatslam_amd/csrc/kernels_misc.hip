@@ -13,6 +13,7 @@
 // Compiled with -ffp-contract=off: every fused multiply-add below is written as fmaf().
 #include "ctx.h"
 #include "mnn_layout.h"
+#include "heads_kp4.hip.h"
 #include <stdlib.h>
 
 // ---- small helpers -----------------------------------------------------------------------
@@ -20,22 +21,6 @@ __device__ __forceinline__ double wave_sum(double v) {
     v += __shfl_xor(v, 32); v += __shfl_xor(v, 16); v += __shfl_xor(v, 8);
     v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
     return v;
-}
-
-// IEEE a / d for several a and one d: the refined reciprocal and the quotient correction of the compiler's own division
-// expansion (v_rcp + Newton step, q = a*r, two residual corrections), with the reciprocal shared.  Bit-identical to a / d
-// whenever the expansion's scaling stage is the identity: d in [1e-12, 1e6], |a| <= 1e6 and either zero or above 1e-20
-// (k_desc: always; k_heads_kp: softmax terms below 1e-20 may differ in their last denormal bits).
-struct Recip { float d, r; };
-__device__ __forceinline__ Recip recip_of(float d) {
-    float r = __builtin_amdgcn_rcpf(d);
-    r = fmaf(fmaf(-d, r, 1.0f), r, r);
-    return Recip{d, r};
-}
-__device__ __forceinline__ float div_by(float a, const Recip& k) {
-    float q = a * k.r;
-    q = fmaf(fmaf(-k.d, q, a), k.r, q);
-    return fmaf(fmaf(-k.d, q, a), k.r, q);
 }
 
 // ATen upsample_bilinear2d (align_corners=false) source index / weights; see oracle lin_coeff
@@ -227,97 +212,12 @@ void k_heads_kp(const float* __restrict__ rawK, StatSrc sK,      // keypoint_hea
     }
 }
 
-// k_heads_kp4: the small-batch form (B <= 8) of k_heads_kp.  One frame gives k_heads_kp 38 workgroups of two waves, and every lane
-// walks 64 x 65 dependent-free but sequentially issued fmas plus 65 expf and 64 quotients: 35 us of a 0.37-ms frame on a mostly
-// idle GPU.  Here FOUR lanes share a pixel (lane j takes outputs 16 j .. 16 j + 15, lane 3 also the dustbin), a workgroup is 32
-// pixels, so four times as many waves run chains a quarter as long.  Every output is the same fma chain over k, the maximum is exact
-// in any order, and the softmax sum keeps the reference order n = 0 .. 64: the running sum travels from lane j to lane j + 1 by shuffle
-// before lane j + 1 adds its terms -- the result is bit for bit k_heads_kp's (tests/test_gpu_extract.py::test_batch_is_per_frame
-// compares the two).  The weights are lane-dependent now, so they come from LDS ([k][68], broadcast over the pixels) instead of the
-// scalar cache.
-#define HK4_PX 32
-#define HK4_LD 33
+// k_heads_kp4 (heads_kp4.hip.h): the small-batch form of k_heads_kp as a kernel of its own (eval()-BatchNorm modes; in the reference's
+// batch-statistics mode the same body rides on block3.0's launch, kernels_conv.hip)
 __global__ __launch_bounds__(4 * HK4_PX)
-void k_heads_kp4(const float* __restrict__ rawK, StatSrc sK,     // keypoint_head.2
-                 size_t raw_stride, const float* __restrict__ wk /* [64][68] */, const float* __restrict__ bk /* [65] */,
-                 int Hh, int Wh, float* __restrict__ K1h, size_t k1h_stride) {
-    __shared__ __attribute__((aligned(16))) float sW[64 * 68];
-    __shared__ float sA[64 * HK4_LD];
-    __shared__ float st[128];
-    __shared__ double red[512];
-    const int t = threadIdx.x, b = blockIdx.z;
-    const int npix = Hh * Wh, p0 = blockIdx.x * HK4_PX;
-    const int lp = t >> 2, j = t & 3, pix = p0 + lp;
-    // raw values of the 32 pixels (4 float4 per thread) and the weights, all loads in flight before the statistics are staged
-    f32x4 rv[4], wv[9];
-    {
-        const float* rp = rawK + (size_t)b * raw_stride;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int item = t + k * 4 * HK4_PX, ip = item >> 4, g = item & 15;
-            rv[k] = *(const f32x4*)(rp + (size_t)min(p0 + ip, npix - 1) * 64 + g * 4);
-        }
-#pragma unroll
-        for (int k = 0; k < 9; ++k) { const int f = t + k * 4 * HK4_PX; wv[k] = *(const f32x4*)(wk + (size_t)min(f, 64 * 17 - 1) * 4); }
-    }
-    stage_stat(sK, b, 64, blockIdx.x == 0, st, red, t, 4 * HK4_PX);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int item = t + k * 4 * HK4_PX, ip = item >> 4, g = item & 15;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) sA[(g * 4 + q) * HK4_LD + ip] = fmaxf((rv[k][q] - st[g * 4 + q]) * st[64 + g * 4 + q], 0.f);
-    }
-#pragma unroll
-    for (int k = 0; k < 9; ++k) { const int f = t + k * 4 * HK4_PX; if (f < 64 * 17) *(f32x4*)(sW + f * 4) = wv[k]; }
-    __syncthreads();
-    float acc[17];
-#pragma unroll
-    for (int n = 0; n < 17; ++n) acc[n] = 0.f;
-    const float* wj = sW + 16 * j;
-#pragma unroll 2
-    for (int k = 0; k < 64; ++k) {
-        const float a = sA[k * HK4_LD + lp];
-        const f32x4 w0 = *(const f32x4*)(wj + k * 68), w1 = *(const f32x4*)(wj + k * 68 + 4), w2 = *(const f32x4*)(wj + k * 68 + 8), w3 = *(const f32x4*)(wj + k * 68 + 12);
-        const float wd = sW[k * 68 + 64];                // the dustbin column (used by lane 3)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            acc[q] = fmaf(a, w0[q], acc[q]); acc[4 + q] = fmaf(a, w1[q], acc[4 + q]);
-            acc[8 + q] = fmaf(a, w2[q], acc[8 + q]); acc[12 + q] = fmaf(a, w3[q], acc[12 + q]);
-        }
-        acc[16] = fmaf(a, wd, acc[16]);
-    }
-    const int nown = j == 3 ? 17 : 16;                   // lane 3: outputs 48 .. 64
-    float mx = -__builtin_huge_valf();
-#pragma unroll
-    for (int n = 0; n < 17; ++n) {
-        acc[n] += bk[min(16 * j + n, 64)];
-        if (n < nown) mx = fmaxf(mx, acc[n]);
-    }
-    mx = fmaxf(mx, __shfl_xor(mx, 1)); mx = fmaxf(mx, __shfl_xor(mx, 2));
-#pragma unroll
-    for (int n = 0; n < 17; ++n) acc[n] = expf(acc[n] - mx);
-    // sum over n = 0 .. 64 in that order: lane r continues the sum lane r - 1 has reached
-    float sum = 0.f;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        float sr = __shfl(sum, (t & ~3) | (r > 0 ? r - 1 : 0));       // (round 0 starts from 0)
-        if (r == 0) sr = 0.f;
-#pragma unroll
-        for (int n = 0; n < 17; ++n) if (n < 16 || r == 3) sr += acc[n];
-        if (j == r) sum = sr;
-    }
-    sum = __shfl(sum, t | 3);                            // the total sits in lane 3
-    const Recip ks = recip_of(sum);                      // 64 softmax quotients share the divisor
-    if (pix < npix) {
-        const int y = pix / Wh, x = pix % Wh;
-        // outputs 16 j .. 16 j + 15 = rows 2 j, 2 j + 1 of the pixel's 8 x 8 cell (depth-to-space)
-        float* o = K1h + (size_t)b * k1h_stride + (size_t)(8 * y + 2 * j) * (8 * Wh) + 8 * x;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            *(f32x4*)(o + (size_t)i * 8 * Wh) = f32x4{div_by(acc[i * 8], ks), div_by(acc[i * 8 + 1], ks), div_by(acc[i * 8 + 2], ks), div_by(acc[i * 8 + 3], ks)};
-            *(f32x4*)(o + (size_t)i * 8 * Wh + 4) = f32x4{div_by(acc[i * 8 + 4], ks), div_by(acc[i * 8 + 5], ks), div_by(acc[i * 8 + 6], ks), div_by(acc[i * 8 + 7], ks)};
-        }
-    }
+void k_heads_kp4(Kp4Args k) {
+    __shared__ __attribute__((aligned(16))) float smem_kp4[HK4_LDS_FLOATS];
+    heads_kp4_body(k, blockIdx.x, blockIdx.z, smem_kp4);
 }
 
 // ---- k_feat_norm: ||feats(p)||_2 of every feature pixel, one thread per pixel -------------------
@@ -1034,7 +934,8 @@ hipError_t run_extract(xfh_ctx* c, const uint8_t* d_gray, int B, int H0, int W0,
     }
     // keypoint branch (keypoint_head.0-3 on unfold2d(x), softmax, depth-to-space) on the second stream: it only needs
     // the normalised image, so it runs beside the backbone (memory-bound 1x1 layers next to MFMA-bound 3x3 layers)
-    {
+    const bool ride = ride_mode(c, B);        // the branch rides on block1.3 .. block3.0 instead (k_conv_mfma_ride): no second stream, no fork, no join
+    if (!ride) {
         const bool two = !(c->cfg.flags & XFH_FLAG_SERIAL_BRANCH);
         hipStream_t branch = two ? c->aux_stream : s;
         hipError_t e = hipEventRecord(c->ev_fork, s);
@@ -1047,7 +948,7 @@ hipError_t run_extract(xfh_ctx* c, const uint8_t* d_gray, int B, int H0, int W0,
         if (e == hipSuccess) {
             if (consumer_fold(B))        // small batches (at 256 frames it measured 287 vs 263 us): four lanes per pixel (k_heads_kp4), the same bits
                 launch_k(c, XFH_K_HEADS, -1, k_heads_kp4, dim3((h8 * w8 + HK4_PX - 1) / HK4_PX, 1, B), dim3(4 * HK4_PX), 0,
-                         (const float*)c->raw[22], stat_src(c, 22, B), c->raw_stride[22], (const float*)c->w.kp3_w, (const float*)c->w.kp3_b, h8, w8, c->K1h, xs);
+                         Kp4Args{(const float*)c->raw[22], stat_src(c, 22, B), c->raw_stride[22], (const float*)c->w.kp3_w, (const float*)c->w.kp3_b, h8, w8, c->K1h, xs});
             else
             launch_k(c, XFH_K_HEADS, -1, k_heads_kp, dim3((h8 * w8 + HF_PX - 1) / HF_PX, 1, B), dim3(HF_PX), 0,
                      (const float*)c->raw[22], stat_src(c, 22, B), c->raw_stride[22], (const float*)c->w.kp3_w, (const float*)c->w.kp3_b, h8, w8, c->K1h, xs);
@@ -1064,11 +965,18 @@ hipError_t run_extract(xfh_ctx* c, const uint8_t* d_gray, int B, int H0, int W0,
     // block1
     CK(launch_basic_layer(c, 1, c->X, xs, 0, PRO_L0, H, W, B));               // block1.0 is recomputed from the image while staging
     CK(launch_basic_layer(c, 2, c->raw[1], c->raw_stride[1], 1, PRO_BN, c->lh[1], c->lw[1], B));
+    if (ride) {                                 // + keypoint_head.0, .1, .2 and .3 / softmax as riders
+        CK(launch_layer_with_rider(c, 3, c->raw[2], c->raw_stride[2], 2, PRO_BN, c->lh[2], c->lw[2], B, c->K1h, xs));
+        CK(launch_layer_with_rider(c, 4, c->raw[3], c->raw_stride[3], 3, PRO_B2IN, h4, w4, B, c->K1h, xs));
+        CK(launch_layer_with_rider(c, 5, c->raw[4], c->raw_stride[4], 4, PRO_BN, h4, w4, B, c->K1h, xs));
+        CK(launch_layer_with_rider(c, 6, c->raw[5], c->raw_stride[5], 5, PRO_BN, h4, w4, B, c->K1h, xs));
+    } else {
     CK(launch_basic_layer(c, 3, c->raw[2], c->raw_stride[2], 2, PRO_BN, c->lh[2], c->lw[2], B));
     // block2 (block2.0 adds skip1(x) to x1 while staging), block3
     CK(launch_basic_layer(c, 4, c->raw[3], c->raw_stride[3], 3, PRO_B2IN, h4, w4, B));
     CK(launch_basic_layer(c, 5, c->raw[4], c->raw_stride[4], 4, PRO_BN, h4, w4, B));
     CK(launch_basic_layer(c, 6, c->raw[5], c->raw_stride[5], 5, PRO_BN, h4, w4, B));
+    }
     CK(launch_basic_layer(c, 7, c->raw[6], c->raw_stride[6], 6, PRO_BN, h8, w8, B));
     CK(launch_basic_layer(c, 8, c->raw[7], c->raw_stride[7], 7, PRO_BN, h8, w8, B));
     // block4, block5
@@ -1094,7 +1002,7 @@ hipError_t run_extract(xfh_ctx* c, const uint8_t* d_gray, int B, int H0, int W0,
     };
     {
         const hipError_t eb = backbone();
-        const hipError_t ej = hipStreamWaitEvent(s, c->ev_join, 0);          // K1h of the keypoint branch
+        const hipError_t ej = ride ? hipSuccess : hipStreamWaitEvent(s, c->ev_join, 0);          // K1h of the keypoint branch
         CK(eb); CK(ej);
     }
     // NMS + score, top-k + placement, descriptors
