@@ -38,7 +38,7 @@ struct Kp4Args {
 #define HK4_LD 33
 #define HK4_LDS_FLOATS (64 * 68 + 64 * HK4_LD + 128 + 1024)
 // the first 4 * HK4_PX threads of the workgroup (any others must have left the kernel); lds: HK4_LDS_FLOATS floats, 16-byte aligned
-__device__ __forceinline__ void heads_kp4_body(const Kp4Args& ka, int block, int b, float* lds) {
+__device__ __forceinline__ void heads_kp4_body(const Kp4Args ka, int block, int b, float* lds) {      // (by value: through a reference the kernel arguments stop being scalar loads)
     const float* __restrict__ rawK = ka.rawK; const StatSrc& sK = ka.sK; const size_t raw_stride = ka.raw_stride;
     const float* __restrict__ wk = ka.wk; const float* __restrict__ bk = ka.bk;
     const int Hh = ka.Hh, Wh = ka.Wh; float* __restrict__ K1h = ka.K1h; const size_t k1h_stride = ka.k1h_stride;

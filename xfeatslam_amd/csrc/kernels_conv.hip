@@ -495,8 +495,10 @@ __device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[NT], float* __
 #define XFH_PD 3
 #endif
 // The body is a device function of (tile, frame) so that it can also run as a RIDER in another layer's launch (k_conv_mfma_ride below).
+// `a` is taken BY VALUE: through a `const ConvArgs&` the compiler no longer reads the kernel arguments with scalar loads -- the PRO_FUSE
+// instance went from 127 to 166 VGPRs (two workgroups per CU to one: 950 -> 1230 us at 256 frames).
 template <int CIN, int COUT, int KS, int ST, int WM, int WN, int NT, int WW, int PRO, int EPI, int CBMAX = 64, int TPC = 1, int PD = XFH_PD>
-__device__ __forceinline__ void conv_mfma_body(const ConvArgs& a, const int tile, const int b, float* smem) {
+__device__ __forceinline__ void conv_mfma_body(const ConvArgs a, const int tile, const int b, float* smem) {
     constexpr int NTHR = 64 * WM * WN;
     constexpr int WH = 32 / WW, TH = WM * WH, TW = WW;
     constexpr int COUTP = WN * NT * 32;
