@@ -361,9 +361,6 @@ void k_conv_direct(ConvArgs a) {
     float acc[COUT];
 #pragma unroll
     for (int co = 0; co < COUT; ++co) acc[co] = 0.f;
-#if defined(XFH_ABL) && (XFH_ABL & 2)
-    if (a.Hin < 0)                    // ablation: no compute
-#endif
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -411,9 +408,6 @@ void k_conv_direct(ConvArgs a) {
             *(f32x4*)(o + g * 4) = f32x4{acc[g * 4], acc[g * 4 + 1], acc[g * 4 + 2], acc[g * 4 + 3]};
     }
     if constexpr (EPI != EPI_STATS) return;
-#if defined(XFH_ABL) && (XFH_ABL & 1)
-    if (a.Hin > 0) return;          // ablation: no statistics epilogue
-#endif
     // per-channel fp64 partial sums of this tile: thread (c, j) adds the pixels j, j + SL, ... of channel c, the slices
     // of a wave are folded with shuffles and the four waves through LDS -- a fixed order, and no serial chain
     __syncthreads();                                      // every thread is done with the input tile: its memory becomes s_out
