@@ -980,6 +980,7 @@ void k_conv_mfma16(ConvArgs a) {
     float* s_w = smem + IN_FLOATS;               // three buffers of W_FLOATS
     float* s_stat = s_w + 3 * W_FLOATS;          // 2 * CIN (PRO_FUSE: 3 * 128)
 
+    constexpr int FB = NTHR > 512 ? 8 : 16;      // fold batch (bn_fold): the 16-wave form has 128 registers per thread
     const int t = threadIdx.x, b = blockIdx.z;
     const int tile = blockIdx.x, tx0 = (tile % a.tiles_x) * TW, ty0 = (tile / a.tiles_x) * TH;
     const float* in = a.in + (size_t)b * a.in_stride;
@@ -1007,10 +1008,10 @@ void k_conv_mfma16(ConvArgs a) {
         r1[k] = *(const f32x4*)(p + 4);
     }
     XFH_STAMP(a, 1);
-    stage_stat<16>(a.st, b, CIN, tile == 0, s_stat, (double*)s_in, t, NTHR);
+    stage_stat<FB>(a.st, b, CIN, tile == 0, s_stat, (double*)s_in, t, NTHR);
     if constexpr (PRO == PRO_FUSE) {
-        stage_stat<16>(a.st4, b, 64, tile == 0, s_stat + 128, (double*)s_in, t, NTHR);
-        stage_stat<16>(a.st5, b, 64, tile == 0, s_stat + 256, (double*)s_in, t, NTHR);
+        stage_stat<FB>(a.st4, b, 64, tile == 0, s_stat + 128, (double*)s_in, t, NTHR);
+        stage_stat<FB>(a.st5, b, 64, tile == 0, s_stat + 256, (double*)s_in, t, NTHR);
     }
     XFH_STAMP(a, 2);
 #pragma unroll
@@ -1346,7 +1347,7 @@ static hipError_t conv_mfma_launch(xfh_ctx* c, const ConvArgs& a, int B, int* np
     return hipGetLastError();
 }
 
-template <int CIN, int COUT, int ST, int GW, int PGY, int PRO, int EPI, int CGS = 1>
+template <int CIN, int COUT, int ST, int GW, int PGY, int PRO, int EPI, int CGS = 1, int PD = 3>
 static hipError_t conv_mfma16_launch(xfh_ctx* c, const ConvArgs& a, int B, int* npart_out, int layer) {
     constexpr int GH = 16 / GW, TH = GH * PGY, TW = GW, NW = PGY * (COUT / 16 / CGS);
     constexpr size_t LDS = sizeof(float) * ((size_t)((TH - 1) * ST + 3) * ((TW - 1) * ST + 3) * (CIN + 4) + 3 * (size_t)(COUT / CGS) * 68 + (PRO == PRO_FUSE ? 384 : 2 * CIN));
@@ -1356,7 +1357,7 @@ static hipError_t conv_mfma16_launch(xfh_ctx* c, const ConvArgs& a, int B, int* 
     aa.tiles_x = (a.Wout + TW - 1) / TW;
     const int ntile = aa.tiles_x * ((a.Hout + TH - 1) / TH);
     if (npart_out) *npart_out = ntile;
-    auto kern = k_conv_mfma16<CIN, COUT, ST, GW, PGY, PRO, EPI, 3, CGS>;
+    auto kern = k_conv_mfma16<CIN, COUT, ST, GW, PGY, PRO, EPI, PD, CGS>;
     XFH_SET_LDS_ATTR_ONCE(c, kern, LDS);
     launch_k(c, XFH_K_CONV_MFMA, layer, kern, dim3(ntile, CGS, B), dim3(64 * NW), LDS, aa);
     return hipGetLastError();
@@ -1391,6 +1392,9 @@ static hipError_t conv_mfma_p_launch(xfh_ctx* c, const ConvArgs& a, int B, int* 
 //           more than the launch;
 //   B == 1: additionally 2x16-pixel tiles with three taps per weight chunk for the 3x3 64->64 layers (40 workgroups of
 //           the 8x16 form cannot fill 256 CUs, and at one wave per SIMD the K loop otherwise waits on each weight chunk).
+#ifndef XFH_M16_TALL
+#define XFH_M16_TALL 256
+#endif
 static bool persistent(int B) { return B > 8; }
 bool consumer_fold(int B) { return B <= 8; }
 // k_conv_mfma16 splits its output channels over two workgroups (one wave per SIMD, see the kernel) while the split grid still fits one
@@ -1495,8 +1499,14 @@ static hipError_t launch_basic_layer_t(xfh_ctx* c, int li, const float* in, size
             // B = 16 (profiles/r01_conv_cfg.log).  Single frame: 2x16 pixels per workgroup, 2 waves, three taps per chunk.
             // block_fusion.0 (16) builds its input x3 + up2(x4) + up4(x5) while staging.
             if (small_batch(B)) {
-                if (li == 16) { a.w = c->w.m16[li]; e = split_channels(Hout, Wout, 2, 16, B) ? conv_mfma16_launch<64, 64, 1, 16, 2, PRO_FUSE, EPI, 2>(c, a, B, &np, li) : conv_mfma16_launch<64, 64, 1, 16, 2, PRO_FUSE, EPI>(c, a, B, &np, li); }
-                else { a.w = c->w.m16[li]; e = split_channels(Hout, Wout, 2, 16, B) ? conv_mfma16_launch<64, 64, 1, 16, 2, PRO_BN, EPI, 2>(c, a, B, &np, li) : conv_mfma16_launch<64, 64, 1, 16, 2, PRO_BN, EPI>(c, a, B, &np, li); }      // (150 tiles at VGA: not split)      // 2x16 pixels, 8 waves of 16 x 16
+                a.w = c->w.m16[li];
+                // 2x16 pixels, 8 waves of 16 x 16 (channels split over two workgroups while that fits one round of the CUs; 150 tiles at VGA:
+                // not split); from XFH_M16_TALL tiles on (a 1280x720 frame: 440), 4x16 pixels on 16 waves: less halo per staged pixel
+                const long t2 = (long)((Hout + 1) / 2) * ((Wout + 15) / 16) * B;
+                if (li == 16) e = split_channels(Hout, Wout, 2, 16, B) ? conv_mfma16_launch<64, 64, 1, 16, 2, PRO_FUSE, EPI, 2>(c, a, B, &np, li)
+                                : t2 > XFH_M16_TALL ? conv_mfma16_launch<64, 64, 1, 16, 4, PRO_FUSE, EPI>(c, a, B, &np, li) : conv_mfma16_launch<64, 64, 1, 16, 2, PRO_FUSE, EPI>(c, a, B, &np, li);
+                else e = split_channels(Hout, Wout, 2, 16, B) ? conv_mfma16_launch<64, 64, 1, 16, 2, PRO_BN, EPI, 2>(c, a, B, &np, li)
+                       : t2 > XFH_M16_TALL ? conv_mfma16_launch<64, 64, 1, 16, 4, PRO_BN, EPI>(c, a, B, &np, li) : conv_mfma16_launch<64, 64, 1, 16, 2, PRO_BN, EPI>(c, a, B, &np, li);
             } else {
                 a.w = c->w.alt[li];
                 if (li == 16) e = conv_mfma_launch<64, 64, 3, 1, 4, 2, 1, 16, PRO_FUSE, EPI, 32>(c, a, B, &np, li);
