@@ -1385,13 +1385,16 @@ static hipError_t conv_mfma_p_launch(xfh_ctx* c, const ConvArgs& a, int B, int* 
 }
 
 // Batch regimes (tests/test_gpu_extract.py::test_batch_is_per_frame checks that they agree bit for bit):
-//   B > 8 : persistent kernels for the short-K layers (k_conv_mfma_p), k_bn_finalize after every layer;
-//   B <= 8: a dependent launch costs ~5 us on this GPU whatever it does, so EVERY consumer folds the statistics of its
-//           producer itself (bn_fold in each workgroup: same order, same bits, ~2 us of latency instead of a launch) and
-//           k_bn_finalize is never launched -- at large batches the per-workgroup re-read of the partials would cost
-//           more than the launch;
-//   B == 1: additionally 2x16-pixel tiles with three taps per weight chunk for the 3x3 64->64 layers (40 workgroups of
-//           the 8x16 form cannot fill 256 CUs, and at one wave per SIMD the K loop otherwise waits on each weight chunk).
+//   B > 8 : persistent kernels for the short-K layers (k_conv_mfma_p), k_bn_finalize after every layer, the keypoint branch on the
+//           ctx's second stream;
+//   B <= 8: a dependent launch costs ~3 us on this GPU whatever it does (and a dependency on ANOTHER queue 7-11 us), so EVERY consumer
+//           folds the statistics of its producer itself (bn_fold in each workgroup: same order, same bits) and k_bn_finalize is never
+//           launched -- at large batches the per-workgroup re-read of the partials would cost more than the launch (A/B: the threshold
+//           at 4 or at 16 is slower on either side); in the batch-statistics mode the keypoint branch RIDES on block1.3 .. block3.0
+//           (k_conv_mfma_ride) and everything runs on one stream; the 24-channel layers take all nine / three taps per weight chunk;
+//   B <= 32: the 3x3 layers with >= 64 input channels on 16x16x4 MFMAs (k_conv_mfma16); by tile count (not by batch size) their
+//           output channels are split over two workgroups (split_channels) or, for the 1/8-resolution layers, the tiles grow from
+//           2x16 to 4x16 pixels (XFH_M16_TALL).
 #ifndef XFH_M16_TALL
 #define XFH_M16_TALL 256
 #endif
