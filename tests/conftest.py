@@ -67,7 +67,11 @@ def records_equal(ctx, raw_a, raw_b, n):
     """two byte blobs of n records hold the same records: header fields, keypoints and descriptors (the alignment gaps between
     the sections of a record are never written by the kernels, so whole-blob comparison would compare uninitialised bytes)"""
     a = ctx.parse_records(np.ascontiguousarray(raw_a).reshape(-1), n); b = ctx.parse_records(np.ascontiguousarray(raw_b).reshape(-1), n)
+    ok = True
     for i, (x, y) in enumerate(zip(a, b)):
         if x[2:] != y[2:] or not np.array_equal(x[0], y[0]) or not np.array_equal(x[1], y[1]):
-            return False
-    return True
+            nk = int((x[0] != y[0]).sum()) if x[0].shape == y[0].shape else -1
+            nd = int((x[1] != y[1]).any(axis=1).sum()) if x[1].shape == y[1].shape else -1
+            print(f"records_equal: record {i} of {n} differs: header {x[2:]} vs {y[2:]}, {nk} keypoint rows, {nd} descriptor rows", flush=True)
+            ok = False
+    return ok

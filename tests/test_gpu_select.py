@@ -101,3 +101,27 @@ def test_select_forms_agree_on_frames():
     finally:
         for c, _ in raws:
             c.close()
+
+
+def test_select_stage_is_stable_over_many_launches():
+    """the same candidate set 400 times through the bucket ranking (a set that takes its second level): every launch must give the
+    sorted prefix.  Round 3 had a barrier missing between a read and a reset of an LDS flag there: one launch in some hundred, on some
+    boxes only, left the level loop with part of its waves and returned a wrong selection for that frame."""
+    from xfeatslam_amd import capi
+    from xfeatslam_amd.extractor import Context
+    lib = capi.lib()
+    r = np.random.default_rng(3)
+    for n, nfeatures in ((440, 256), (9000, 4096)):
+        scores = np.exp(r.uniform(np.log(2e-2), np.log(0.2), n))            # a narrow spread: crowded buckets at the first level
+        idx = r.choice(96 * 128 - 1, n, replace=False) + 1 if n < 96 * 128 else r.choice(480 * 640 - 1, n, replace=False) + 1
+        keys = np.ascontiguousarray(make_keys(scores, idx))
+        want = np.sort(keys)[:min(n, nfeatures)]
+        ctx = Context(nfeatures=nfeatures, max_height=480, max_width=640, max_batch=1)
+        try:
+            sel = np.zeros(nfeatures, np.uint64); n_out = C.c_int(-1); hdr = np.zeros(4, np.int32)
+            for it in range(400):
+                capi.check(lib.xfh_debug_select(ctx.h, keys.ctypes.data_as(C.c_void_p), n, W, 0, 0, 1,
+                                                sel.ctypes.data_as(C.c_void_p), C.byref(n_out), hdr.ctypes.data_as(C.c_void_p)), ctx.h)
+                assert n_out.value == len(want) and np.array_equal(sel[:len(want)], want), (n, it)
+        finally:
+            ctx.close()

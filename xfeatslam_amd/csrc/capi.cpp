@@ -118,6 +118,8 @@ int xfh_create(const xfh_config* cfg, xfh_ctx** out) {
     if (c->cfg.nms_threshold <= 0.f) c->cfg.nms_threshold = 0.05f;
     c->Hmax = (cfg->max_height / 32) * 32; c->Wmax = (cfg->max_width / 32) * 32;
     if (const char* e = getenv("XFH_SELECT_LEGACY")) c->select_legacy = e[0] == '1';      // test knob: k_select's fallback form for every frame
+    if (const char* e = getenv("XFH_NO_NMS_HEAT")) c->no_nms_heat = e[0] == '1';          // test knob: k_heads_heat as a launch of its own for every batch size
+    if (const char* e = getenv("XFH_NO_RIDE")) c->no_ride = e[0] == '1';                  // test knob: the keypoint branch on the second stream for every batch size
     const int B = cfg->max_batch;
     int rc = XFH_OK;
     auto fail = [&](int code) { xfh_destroy(c); return code; };

@@ -75,6 +75,8 @@ struct xfh_ctx {
     size_t part_stride[XFH_NUM_LAYERS] = {};    // doubles per frame
     float* skip_pool = nullptr; float* feats = nullptr;
     float* H1 = nullptr; float* K1h = nullptr;
+    bool no_nms_heat = false;                   // XFH_NO_NMS_HEAT=1 (tests)
+    bool no_ride = false;                       // XFH_NO_RIDE=1: no riders (tests)
     bool select_legacy = false;                 // XFH_SELECT_LEGACY=1: k_select takes its radix-select + bitonic form (tests)
     float* feat_nrm = nullptr;                  // [h8*w8] L2 norm of every feature pixel (k_feat_norm)
     u64* cand = nullptr; size_t cand_cap = 0;   // keys per frame (power of two >= Hmax*Wmax)

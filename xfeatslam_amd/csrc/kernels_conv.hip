@@ -1604,7 +1604,7 @@ static hipError_t ride_launch(xfh_ctx* c, const ConvArgs& a, int n_host, const C
     launch_k(c, XFH_K_CONV_MFMA, layer, kern, dim3(n_host + n_rider, 1, B), dim3(256), LDS, a, n_host, r, k);
     return hipGetLastError();
 }
-bool ride_mode(const xfh_ctx* c, int B) { return consumer_fold(B) && c->cfg.bn_mode == XFH_BN_BATCH_STATS; }      // (A/B on one box: +9.5 % at 2 frames, +5.5 % at 4, even at 8)
+bool ride_mode(const xfh_ctx* c, int B) { return consumer_fold(B) && c->cfg.bn_mode == XFH_BN_BATCH_STATS && !c->no_ride; }      // (A/B on one box: +9.5 % at 2 frames, +5.5 % at 4, even at 8)
 // host: BasicLayer li in 3 .. 6 (block1.3, block2.0, block2.1, block3.0); rider: step li - 3 of the keypoint branch
 hipError_t launch_layer_with_rider(xfh_ctx* c, int li, const float* in, size_t in_stride, int src, int pro, int Hin, int Win, int B,
                                    const float* K1h, size_t k1h_stride) {

@@ -780,7 +780,11 @@ void k_select(const u64* __restrict__ cand, size_t cand_cap, const int* __restri
             while ((span << (r + 1)) <= SEL_NB && r < sh) ++r;
         }
         __syncthreads();                                            // s_maxb complete; every thread has read s_T / s_segtot / s_bmin
-        if (r == 0 || s_maxb <= SEL_BUCKET_FINE) break;             // (s_maxb is 0 unless a selected bucket holds more than SEL_BUCKET_FINE keys)
+        const int maxb0 = s_maxb;
+        if (r == 0 || maxb0 <= SEL_BUCKET_FINE) break;              // (s_maxb is 0 unless a selected bucket holds more than SEL_BUCKET_FINE keys)
+        __syncthreads();                                            // ... and s_maxb, BEFORE thread 0 resets it below: without this barrier a wave that is a few
+                                                                    // instructions behind read the reset value, left the loop while the others went on to level 1,
+                                                                    // and the workgroup's barriers no longer matched (a rare, box-dependent corruption of one frame's selection)
         // refine: level 1 over the keys of buckets <= T
         T0 = T; sh = sh0 - r; msk = ((u64)SEL_NB << r) - 1ull; base = bmin << r;
         for (int e = t; e < SEL_NB; e += 1024) hist[e] = 0;
@@ -995,7 +999,7 @@ hipError_t run_extract(xfh_ctx* c, const uint8_t* d_gray, int B, int H0, int W0,
     CK(launch_fusion_chain(c, h8, w8, B, &head_done));
     if (head_done < 1) CK(launch_basic_layer(c, 18, c->feats, c->raw_stride[17], -1, PRO_PLAIN, h8, w8, B));
     if (head_done < 2) CK(launch_basic_layer(c, 19, c->raw[18], c->raw_stride[18], 18, PRO_BN, h8, w8, B));
-    if (consumer_fold(B)) return hipGetLastError();           // small batches: heatmap_head.2 + sigmoid are computed inside k_nms_score
+    if (consumer_fold(B) && !c->no_nms_heat) return hipGetLastError();           // small batches: heatmap_head.2 + sigmoid are computed inside k_nms_score
     hipLaunchKernelGGL(k_heads_heat, dim3((h8 * w8 + HF_PX - 1) / HF_PX, 1, B), dim3(HF_PX), 0, s,
                        (const float*)c->raw[19], stat_src(c, 19, B), c->raw_stride[19], (const float*)c->w.heat2_w, (const float*)c->w.heat2_b, h8 * w8, c->H1, xs / 64);
     return hipGetLastError();
@@ -1008,7 +1012,7 @@ hipError_t run_extract(xfh_ctx* c, const uint8_t* d_gray, int B, int H0, int W0,
     // NMS + score, top-k + placement, descriptors
     const int nms_blocks = ((W + NMS_TW - 1) / NMS_TW) * ((H + NMS_TH - 1) / NMS_TH);
     const int fn_blocks = consumer_fold(B) ? (h8 * w8 + 255) / 256 : 0;          // small batches: the feature norms ride on this launch
-    if (fn_blocks)
+    if (fn_blocks && !c->no_nms_heat)
         launch_k(c, XFH_K_NMS, -1, k_nms_score<true>, dim3(nms_blocks + fn_blocks, 1, B), dim3(256), 0, c->K1h, xs, c->H1, xs / 64,
                        H, W, c->cfg.nms_threshold, c->cand, c->cand_cap, c->cand_count,
                        nms_blocks, (const float*)c->feats, c->raw_stride[17], h8 * w8, c->feat_nrm, xs / 64,
