@@ -13,6 +13,12 @@ for (H, W, nf) in [(480, 640, 1000), (480, 640, 4096), (720, 1280, 2000)]:
     ts = []
     for _ in range(50):
         t = time.perf_counter(); ex(img); ts.append(time.perf_counter() - t)
+    if "--paced" in sys.argv:                     # one call every 33 ms, as a 30-Hz SLAM loop would: the GPU idles (and clocks down) between frames
+        tp = []
+        for _ in range(40):
+            time.sleep(0.033); t = time.perf_counter(); ex(img); tp.append(time.perf_counter() - t)
+        tp = np.array(tp) * 1e3
+        print(f"{H}x{W} nfeatures {nf}: one call every 33 ms: median {np.median(tp):.3f} ms  min {tp.min():.3f}  p90 {np.percentile(tp, 90):.3f}", flush=True)
     ts = np.array(ts) * 1e3
     print(f"{H}x{W} nfeatures {nf}: xfh_extract median {np.median(ts):.3f} ms  min {ts.min():.3f}  p90 {np.percentile(ts, 90):.3f}  (n_valid {ex.n_valid})", flush=True)
     d1 = np.zeros((nf, 64), np.float32)
