@@ -731,7 +731,8 @@ void k_conv_mfma(ConvArgs a) {
 }
 
 // k_conv_mfma_ride: a backbone layer (the HOST: its tiles are the workgroups below n_host) and, in the same launch, one step of the
-// keypoint branch (the RIDER: the workgroups from n_host on).  For batches <= 8 in the reference's batch-statistics mode the branch
+// keypoint branch (the RIDER: the workgroups from n_host on).  For batches <= 8 (every BatchNorm mode but the folded one, whose layers
+// have another epilogue) the branch
 // -- keypoint_head.0-2 (1x1 convolutions on unfold2d(x-hat)) and keypoint_head.3 + softmax + depth-to-space -- does not get a stream of
 // its own: its four dependent steps ride on block1.3, block2.0, block2.1 and block3.0, which follow each other on the one stream
 // anyway.  Forking a second stream costs the main queue 7-11 us (a hipEventRecord there is a barrier packet with a signal; attaching
@@ -1604,7 +1605,7 @@ static hipError_t ride_launch(xfh_ctx* c, const ConvArgs& a, int n_host, const C
     launch_k(c, XFH_K_CONV_MFMA, layer, kern, dim3(n_host + n_rider, 1, B), dim3(256), LDS, a, n_host, r, k);
     return hipGetLastError();
 }
-bool ride_mode(const xfh_ctx* c, int B) { return consumer_fold(B) && c->cfg.bn_mode == XFH_BN_BATCH_STATS && !c->no_ride; }      // (A/B on one box: +9.5 % at 2 frames, +5.5 % at 4, even at 8)
+bool ride_mode(const xfh_ctx* c, int B) { return consumer_fold(B) && c->cfg.bn_mode != XFH_BN_RUNNING_FOLDED && !c->no_ride; }      // (A/B on one box: +9.5 % at 2 frames, +5.5 % at 4, even at 8)
 // host: BasicLayer li in 3 .. 6 (block1.3, block2.0, block2.1, block3.0); rider: step li - 3 of the keypoint branch
 hipError_t launch_layer_with_rider(xfh_ctx* c, int li, const float* in, size_t in_stride, int src, int pro, int Hin, int Win, int B,
                                    const float* K1h, size_t k1h_stride) {
