@@ -76,7 +76,8 @@ def test_select_stage_on_crafted_candidates(name, nfeatures):
 
 
 def test_select_forms_agree_on_frames():
-    """whole extraction with k_select forced to its radix + bitonic form == the default (bucket ranking) records"""
+    """whole extraction with k_select forced to its radix + bitonic form, with the keypoint branch on a second stream instead of riding on
+    the backbone's launches, and with the heatmap head as a launch of its own == the default records"""
     import os
     from conftest import records_equal
     from xfeatslam_amd import capi, synth, weights as WT
@@ -85,19 +86,22 @@ def test_select_forms_agree_on_frames():
     frames = synth.frames(3, 480, 640, seed=11)
     blob = WT.pack_blob(WT.make_synthetic(1234, 3.0))
     raws = []
-    for legacy in ("0", "1"):
-        os.environ["XFH_SELECT_LEGACY"] = legacy
+    for knob in (None, "XFH_SELECT_LEGACY", "XFH_NO_RIDE", "XFH_NO_NMS_HEAT"):
+        if knob:
+            os.environ[knob] = "1"
         try:
             ctx = Context(nfeatures=4096, max_height=480, max_width=640, max_batch=3)
         finally:
-            del os.environ["XFH_SELECT_LEGACY"]
+            if knob:
+                del os.environ[knob]
         ctx.load_weights(blob)
         din = capi.DeviceBuffer(frames.nbytes).upload(frames); rec = capi.DeviceBuffer(3 * ctx.rec_bytes)
         capi.check(lib.xfh_extract_batch_device(ctx.h, din.ptr, 3, 480, 640, 150, 400, rec.ptr), ctx.h)
         ctx.synchronize()
         raws.append((ctx, rec.download(np.uint8, 3 * ctx.rec_bytes)))
     try:
-        assert records_equal(raws[0][0], raws[0][1], raws[1][1], 3)
+        for k in range(1, len(raws)):
+            assert records_equal(raws[0][0], raws[0][1], raws[k][1], 3), k
     finally:
         for c, _ in raws:
             c.close()
