@@ -195,6 +195,18 @@ int xfh_match_prepare_device(xfh_ctx* ctx, const float* d_desc, int n, void* d_i
 int xfh_match_mnn_prepared_device(xfh_ctx* ctx, const void* d_image1, int n1, const void* d_image2, int n2,
                                   float min_cossim, int* d_idx1, int* d_idx2, float* d_dist, int* d_n_matches);
 
+/* Many pairs in one call.  The reference's consumers meet one frame with several partners -- the previous frame, key frames, loop
+ * candidates: one ORBmatcher::match per frame pair (ORBmatcher.cc:358-372 per call; SURVEY.md 8e "for many frame pairs, shard pairs") --
+ * and one 4096 x 4096 pair is exactly one tile per CU, so a call per pair pays its launch ramp, staging wait and epilogue latency with
+ * nothing to overlap them.  This entry runs the similarity GEMM of ALL pairs as one persistent launch (equal shares of the tiles of all
+ * pairs per workgroup, the next tile's panel arriving while the current one is multiplied) and the mutual check / output of all
+ * pairs as a second one.  Pair p: prepared images d_image1[p] (n1[p] rows) and d_image2[p] (n2[p] rows) -- the same image may appear
+ * in any number of pairs, on either side -- match list to d_idx1[p] / d_idx2[p] / d_dist[p] (min(n1[p], n2[p]) slots each) and its
+ * length to d_n_matches[p]; results are those of xfh_match_mnn_prepared_device pair by pair, bit for bit.  The pointer and size arrays
+ * are HOST arrays (read before the call returns); everything they point to is device memory.  Asynchronous on the ctx stream. */
+int xfh_match_mnn_prepared_batch_device(xfh_ctx* ctx, int n_pairs, const void* const* d_image1, const int* n1, const void* const* d_image2, const int* n2,
+                                        float min_cossim, int* const* d_idx1, int* const* d_idx2, float* const* d_dist, int* d_n_matches);
+
 /* n_valid-aware match of two extraction records (option).  ORBmatcher::match treats the zero rows that pad a record
  * like descriptors (they have similarity 0 with everything and can end up in mutual pairs); here every pair that touches a padding
  * slot is dropped.  d_record1/2: records of this ctx' nfeatures (only their headers are read: valid slots are [0, mono_index) and

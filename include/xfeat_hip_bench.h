@@ -18,7 +18,7 @@ extern "C" {
 enum {
     XFH_K_NONE = 0, XFH_K_MNN_GEMM = 1, XFH_K_CONV_MFMA = 2, XFH_K_CONV_DIRECT = 3,
     XFH_K_NMS = 4, XFH_K_SELECT = 5, XFH_K_DESC = 6, XFH_K_HEADS = 7, XFH_K_DIST_I32 = 8,
-    XFH_K_PREPROC = 9, XFH_K_BEST2 = 10, XFH_K_DISTINCTIVE = 11, XFH_K_COUNT = 12
+    XFH_K_PREPROC = 9, XFH_K_BEST2 = 10, XFH_K_DISTINCTIVE = 11, XFH_K_MNN_GEMM_SEG = 12, XFH_K_COUNT = 13
 };
 /* layer_mask selects conv layers for XFH_K_CONV_*: 0 = every layer, else bit i = BasicLayer i
  * (0..22 in XFeatModel order) and bit 23 = block_fusion.2 */
@@ -34,6 +34,12 @@ int xfh_bench_match_prepared(xfh_ctx* ctx, const void* d_image1, int n1, const v
                              int* d_idx1, int* d_idx2, float* d_dist, int* d_n_matches, int iters, double* us_per_call);
 int xfh_bench_match_raw(xfh_ctx* ctx, const float* d_d1, int n1, const float* d_d2, int n2, float min_cossim,
                         int* d_idx1, int* d_idx2, float* d_dist, int* d_n_matches, int iters, double* us_per_call);   /* the same for xfh_match_mnn_device */
+/* the many-pairs call (xfh_match_mnn_prepared_batch_device): `iters` launches of its GEMM alone (k_mnn_gemm_seg) back to back -> wall time per
+ * launch; and `iters` whole calls (GEMM + k_mnn_post_batch) back to back from C -> wall time per call.  Arguments as the call itself. */
+int xfh_bench_mnn_gemm_batch(xfh_ctx* ctx, int n_pairs, const void* const* d_image1, const int* n1, const void* const* d_image2, const int* n2,
+                             int iters, double* us_per_launch);
+int xfh_bench_match_batch(xfh_ctx* ctx, int n_pairs, const void* const* d_image1, const int* n1, const void* const* d_image2, const int* n2, float min_cossim,
+                          int* const* d_idx1, int* const* d_idx2, float* const* d_dist, int* d_n_matches, int iters, double* us_per_call);
 const char* xfh_kernel_name(int kernel_id);
 
 /* intermediate tensors of frame `frame` of the last extract call, copied to host as float

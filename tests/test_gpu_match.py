@@ -268,3 +268,78 @@ def test_nan_and_inf_descriptors_return(mctx):
     have = {(int(a), int(b)) for a, b in zip(got[0], got[1])}
     assert len(clean - have) <= 8                           # pairs of finite rows survive unless a poisoned row displaced their partner
     assert mctx.match_mnn(d1, d2)[0].tolist() == want[0].tolist()       # and the ctx is still usable
+
+
+# ---- many pairs in one call (xfh_match_mnn_prepared_batch_device: k_mnn_gemm_seg + k_mnn_post_batch) ---------------------------------
+def test_mnn_batch_one_frame_against_partners(mctx, oracle_mod):
+    """the tracker's case (ORBmatcher.cc:358-372 called once per frame pair): one frame against several partners, one call.  Every pair list is the
+    oracle's; the batched call equals the pair-by-pair calls bit for bit."""
+    q, _ = synth.descriptor_sets(4096, 16, noise=0.3, seed=3)
+    partners = []
+    for k, (n, noise, zero) in enumerate([(4096, 0.3, 0), (4096, 0.5, 100), (2500, 0.3, 3), (4096, 0.2, 0), (1000, 0.4, 0)]):
+        _, d2 = synth.descriptor_sets(4096, n, zero_rows=zero, noise=noise, seed=3)        # noisy permuted copies of q's rows (same seed -> same d1)
+        partners.append(d2)
+    pq = mctx.match_prepare(q)
+    pp = [mctx.match_prepare(d) for d in partners]
+    res = mctx.match_mnn_prepared_batch([(pq, p) for p in pp])
+    for d2, p, r in zip(partners, pp, res):
+        a = oracle_mod.match_mnn(q, d2)
+        assert np.array_equal(a[0], r[0]) and np.array_equal(a[1], r[1]) and np.array_equal(a[2], r[2], equal_nan=True)
+        s = mctx.match_mnn_prepared(pq, p)
+        assert np.array_equal(s[0], r[0]) and np.array_equal(s[1], r[1]) and np.array_equal(s[2], r[2], equal_nan=True)
+    for thr in (0.5, 0.9):
+        res = mctx.match_mnn_prepared_batch([(pq, p) for p in pp], thr)
+        for d2, r in zip(partners, res):
+            a = oracle_mod.match_mnn(q, d2, thr)
+            assert np.array_equal(a[0], r[0]) and np.array_equal(a[1], r[1])
+    pq[0].free()
+    for p in pp:
+        p[0].free()
+
+
+@pytest.mark.parametrize("shapes", [
+    [(4096, 4096)] * 8,                                                          # BENCH's batched leg: every workgroup walks 8 tiles
+    [(300, 200), (1, 5), (5, 1), (129, 127), (257, 4097), (1000, 777)],          # ragged: tiles with masked rows and columns, tiny pairs
+    [(256, 256)],                                                                # one tile, one workgroup
+    [(4096, 4096), (1000, 777), (257, 4097), (1, 5), (129, 127), (300, 200), (2500, 4096), (4096, 2500), (512, 512),
+     (700, 300), (64, 4096), (4096, 64), (1024, 1024), (333, 334), (256, 257), (255, 256), (2048, 1024), (77, 99)],   # 18 pairs: two launches of <= 16
+])
+def test_mnn_batch_matches_oracle(mctx, oracle_mod, shapes):
+    """mixed shapes, duplicates (ties inside and across candidate groups, tiles and workgroups) and zero rows: every pair list equals the oracle's"""
+    data, prepared = [], []
+    for k, (n1, n2) in enumerate(shapes):
+        d1, d2 = synth.descriptor_sets(n1, n2, zero_rows=(5 if min(n1, n2) > 100 and k % 2 else 0), noise=0.3, seed=100 + k)
+        if n2 > 40:
+            d2[min(10, n2 - 1)] = d2[3]; d2[n2 - 1] = d2[3]
+        if n1 > 60:
+            d1[50] = d1[20]; d1[n1 - 1] = d1[0]
+        data.append((d1, d2)); prepared.append((mctx.match_prepare(d1), mctx.match_prepare(d2)))
+    for rep in range(2):                                                          # twice: the key planes and pairs of the first call are left behind
+        res = mctx.match_mnn_prepared_batch(prepared)
+        for (d1, d2), r in zip(data, res):
+            a = oracle_mod.match_mnn(d1, d2)
+            assert np.array_equal(a[0], r[0]) and np.array_equal(a[1], r[1]) and np.array_equal(a[2], r[2], equal_nan=True)
+            assert np.all(np.diff(r[0]) > 0)
+    for p1, p2 in prepared:
+        p1[0].free(); p2[0].free()
+
+
+def test_mnn_batch_empty_sides_and_arguments(mctx):
+    d1, d2 = synth.descriptor_sets(300, 200, noise=0.3)
+    p1, p2 = mctx.match_prepare(d1), mctx.match_prepare(d2)
+    assert mctx.match_mnn_prepared_batch([]) == []
+    L = capi.lib()
+    P = 3
+    out = capi.DeviceBuffer(3 * 4096 + 64); cnt = capi.DeviceBuffer(64).upload(np.full(16, -7, np.int32))
+    img1 = (C.c_void_p * P)(p1[0].ptr, None, p1[0].ptr); n1 = (C.c_int * P)(300, 0, 300)
+    img2 = (C.c_void_p * P)(p2[0].ptr, p2[0].ptr, None); n2 = (C.c_int * P)(200, 200, 0)
+    i1 = (C.c_void_p * P)(out.ptr, None, None); i2 = (C.c_void_p * P)(out.ptr + 1024, None, None); ds = (C.c_void_p * P)(out.ptr + 2048, None, None)
+    assert L.xfh_match_mnn_prepared_batch_device(mctx.h, P, img1, n1, img2, n2, -1.0, i1, i2, ds, cnt.ptr) == 0
+    mctx.synchronize()
+    k = cnt.download(np.int32, 3)
+    assert k[0] > 0 and k[1] == 0 and k[2] == 0                                   # an empty side: no matches (ORBmatcher.cc:358: nothing to compare)
+    n1b = (C.c_int * P)(300, -1, 300)
+    assert L.xfh_match_mnn_prepared_batch_device(mctx.h, P, img1, n1b, img2, n2, -1.0, i1, i2, ds, cnt.ptr) == 1
+    assert L.xfh_match_mnn_prepared_batch_device(mctx.h, P, None, n1, img2, n2, -1.0, i1, i2, ds, cnt.ptr) == 1
+    assert L.xfh_match_mnn_prepared_batch_device(mctx.h, 1, img1, n1, img2, n2, -1.0, i1, i2, ds, None) == 1
+    out.free(); cnt.free(); p1[0].free(); p2[0].free()

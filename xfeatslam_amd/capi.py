@@ -71,6 +71,7 @@ SYMBOLS = [
     ("xfh_match_image_bytes", _sz, [_i]),
     ("xfh_match_prepare_device", _i, [_vp, _vp, _i, _vp]),
     ("xfh_match_mnn_prepared_device", _i, [_vp, _vp, _i, _vp, _i, _f, _vp, _vp, _vp, _vp]),
+    ("xfh_match_mnn_prepared_batch_device", _i, [_vp, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
     ("xfh_match_records_device", _i, [_vp, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp, _vp]),
     ("xfh_descriptor_distance", _i, [_vp, _vp]),
     ("xfh_distance_i32", _i, [_vp, _vp, _i, _vp, _i, _vp]),
@@ -107,6 +108,8 @@ SYMBOLS = [
     ("xfh_timing_enable", _i, [_vp, _i, C.c_uint]),
     ("xfh_timing_read", _i, [_vp, _pi, C.POINTER(C.c_double)]),
     ("xfh_bench_mnn_gemm", _i, [_vp, _vp, _i, _vp, _i, _i, C.POINTER(C.c_double)]),
+    ("xfh_bench_mnn_gemm_batch", _i, [_vp, _i, _vp, _vp, _vp, _vp, _i, C.POINTER(C.c_double)]),
+    ("xfh_bench_match_batch", _i, [_vp, _i, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp, _vp, _i, C.POINTER(C.c_double)]),
     ("xfh_bench_match_prepared", _i, [_vp, _vp, _i, _vp, _i, C.c_float, _vp, _vp, _vp, _vp, _i, C.POINTER(C.c_double)]),
     ("xfh_bench_match_raw", _i, [_vp, _vp, _i, _vp, _i, C.c_float, _vp, _vp, _vp, _vp, _i, C.POINTER(C.c_double)]),
     ("xfh_bench_calib", _i, [_vp, _i, _sz, _i]),

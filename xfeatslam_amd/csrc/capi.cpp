@@ -65,7 +65,7 @@ const char* xfh_strerror(int s) {
 
 const char* xfh_kernel_name(int id) {
     static const char* n[XFH_K_COUNT] = {"none", "k_mnn_gemm", "k_conv_mfma", "k_conv_direct", "k_nms_score", "k_select",
-                                         "k_desc", "k_heads_kp", "k_dist_i32", "k_preproc", "k_best2_csr", "k_distinctive_csr"};
+                                         "k_desc", "k_heads_kp", "k_dist_i32", "k_preproc", "k_best2_csr", "k_distinctive_csr", "k_mnn_gemm_seg"};
     return (id >= 0 && id < XFH_K_COUNT) ? n[id] : "?";
 }
 
@@ -109,12 +109,15 @@ int xfh_create(const xfh_config* cfg, xfh_ctx** out) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return XFH_ERR_NO_DEVICE;
     if (cfg->device < 0 || cfg->device >= ndev) return XFH_ERR_NO_DEVICE;
+    int num_cu = 0;
     {   // the code objects in this library are gfx950 only
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess || strncmp(prop.gcnArchName, "gfx950", 6) != 0) return XFH_ERR_NO_DEVICE;
+        num_cu = prop.multiProcessorCount;
     }
     xfh_ctx* c = new xfh_ctx();
     c->cfg = *cfg;
+    if (num_cu > 0) c->num_cu = num_cu;
     if (c->cfg.nms_threshold <= 0.f) c->cfg.nms_threshold = 0.05f;
     c->Hmax = (cfg->max_height / 32) * 32; c->Wmax = (cfg->max_width / 32) * 32;
     if (const char* e = getenv("XFH_SELECT_LEGACY")) c->select_legacy = e[0] == '1';      // test knob: k_select's fallback form for every frame
@@ -243,7 +246,7 @@ int xfh_destroy(xfh_ctx* c) {
     for (int k = 1; k < xfh_ctx::SLOTS; ++k) { F(c->s_dgray[k]); if (c->s_hgray[k]) hipHostFree(c->s_hgray[k]); if (c->s_hrec[k]) hipHostFree(c->s_hrec[k]); }
     for (int k = 0; k < xfh_ctx::SLOTS; ++k) if (c->s_done[k]) hipEventDestroy(c->s_done[k]);
     MatchWs& w = c->mws;
-    F(w.img1); F(w.keys); F(w.b2_buf); F(w.h_d1); F(w.o_buf); F(w.o_tab);
+    F(w.img1); F(w.keys); F(w.b2_buf); F(w.h_d1); F(w.o_buf); F(w.o_tab); F(w.bkeys);
     if (w.h_out) hipHostFree(w.h_out);
     if (c->timer.ev) { for (int i = 0; i < 2 * KTimer::MAXEV; ++i) if (c->timer.ev[i]) hipEventDestroy(c->timer.ev[i]); free(c->timer.ev); }
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
@@ -599,6 +602,35 @@ int xfh_match_mnn_prepared_device(xfh_ctx* c, const void* image1, int n1, const 
     return XFH_OK;
 }
 
+// Many pairs in one call (ORBmatcher::match once per frame pair in the reference, ORBmatcher.cc:358-372; its consumers meet one frame with
+// several partners): one persistent GEMM launch over the tiles of all pairs + one post launch (kernels_match.hip: launch_mnn_batch).
+static int gather_pairs(xfh_ctx* c, int n_pairs, const void* const* image1, const int* n1, const void* const* image2, const int* n2,
+                        int* const* idx1, int* const* idx2, float* const* dist, int* n_matches, bool need_out, std::vector<XfhMatchPair>& v) {
+    if (!c || n_pairs < 0 || (n_pairs > 0 && (!image1 || !n1 || !image2 || !n2))) return XFH_ERR_INVALID_ARG;
+    if (need_out && n_pairs > 0 && (!idx1 || !idx2 || !dist || !n_matches)) return XFH_ERR_INVALID_ARG;
+    v.resize((size_t)n_pairs);
+    for (int p = 0; p < n_pairs; ++p) {
+        if (n1[p] < 0 || n2[p] < 0) return XFH_ERR_INVALID_ARG;
+        if ((n1[p] > 0 && !image1[p]) || (n2[p] > 0 && !image2[p])) return XFH_ERR_INVALID_ARG;
+        if ((((uintptr_t)image1[p]) | ((uintptr_t)image2[p])) & 15) return XFH_ERR_INVALID_ARG;
+        if (need_out && n1[p] > 0 && n2[p] > 0 && (!idx1[p] || !idx2[p] || !dist[p])) return XFH_ERR_INVALID_ARG;
+        v[p] = XfhMatchPair{(const float*)image1[p], n1[p], (const float*)image2[p], n2[p], need_out ? idx1[p] : nullptr, need_out ? idx2[p] : nullptr,
+                            need_out ? dist[p] : nullptr, need_out ? n_matches + p : nullptr};
+    }
+    return XFH_OK;
+}
+int xfh_match_mnn_prepared_batch_device(xfh_ctx* c, int n_pairs, const void* const* image1, const int* n1, const void* const* image2, const int* n2,
+                                        float min_cossim, int* const* idx1, int* const* idx2, float* const* dist, int* n_matches) {
+    std::vector<XfhMatchPair> v;
+    const int rc = gather_pairs(c, n_pairs, image1, n1, image2, n2, idx1, idx2, dist, n_matches, true, v);
+    if (rc != XFH_OK) return rc;
+    if (n_pairs == 0) return XFH_OK;
+    HIPCK(c, hipSetDevice(c->cfg.device));
+    XfhRange range("xfh:match_mnn_prepared_batch_device");
+    HIPCK(c, launch_mnn_batch(c, v.data(), n_pairs, min_cossim));
+    return XFH_OK;
+}
+
 // n_valid-aware form: the two sets are the nfeatures slots of two extraction records whose prepared images came
 // out of xfh_extract_batch_device_images; pairs that touch a padding slot are not reported (the reference's match() would report
 // them: zero rows have similarity 0 with everything, ORBmatcher.cc:358-372).  Otherwise xfh_match_mnn_prepared_device.
@@ -823,6 +855,38 @@ int xfh_bench_match_prepared(xfh_ctx* c, const void* image1, int n1, const void*
 int xfh_bench_match_raw(xfh_ctx* c, const float* d1, int n1, const float* d2, int n2, float min_cossim,
                         int* idx1, int* idx2, float* dist, int* n_matches, int iters, double* us_per_call) {
     return bench_match(c, false, d1, n1, d2, n2, min_cossim, idx1, idx2, dist, n_matches, iters, us_per_call);
+}
+int xfh_bench_mnn_gemm_batch(xfh_ctx* c, int n_pairs, const void* const* image1, const int* n1, const void* const* image2, const int* n2, int iters, double* us_per_launch) {
+    std::vector<XfhMatchPair> v;
+    const int rc = gather_pairs(c, n_pairs, image1, n1, image2, n2, nullptr, nullptr, nullptr, nullptr, false, v);
+    if (rc != XFH_OK) return rc;
+    if (n_pairs < 1 || iters < 1 || !us_per_launch) return XFH_ERR_INVALID_ARG;
+    HIPCK(c, hipSetDevice(c->cfg.device));
+    HIPCK(c, bench_mnn_gemm_batch(c, v.data(), n_pairs, iters, us_per_launch));
+    return XFH_OK;
+}
+int xfh_bench_match_batch(xfh_ctx* c, int n_pairs, const void* const* image1, const int* n1, const void* const* image2, const int* n2, float min_cossim,
+                          int* const* idx1, int* const* idx2, float* const* dist, int* n_matches, int iters, double* us_per_call) {
+    std::vector<XfhMatchPair> v;
+    const int rc = gather_pairs(c, n_pairs, image1, n1, image2, n2, idx1, idx2, dist, n_matches, true, v);
+    if (rc != XFH_OK) return rc;
+    if (n_pairs < 1 || iters < 1 || !us_per_call) return XFH_ERR_INVALID_ARG;
+    HIPCK(c, hipSetDevice(c->cfg.device));
+    hipEvent_t e0, e1;
+    HIPCK(c, hipEventCreate(&e0));
+    if (hipEventCreate(&e1) != hipSuccess) { hipEventDestroy(e0); return XFH_ERR_HIP; }
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < 50 && e == hipSuccess; ++i) e = launch_mnn_batch(c, v.data(), n_pairs, min_cossim);
+    if (e == hipSuccess) e = hipEventRecord(e0, c->stream);
+    for (int i = 0; i < iters && e == hipSuccess; ++i) e = launch_mnn_batch(c, v.data(), n_pairs, min_cossim);
+    if (e == hipSuccess) e = hipEventRecord(e1, c->stream);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    *us_per_call = (double)ms * 1e3 / iters;
+    HIPCK(c, e);
+    return XFH_OK;
 }
 int xfh_timing_enable(xfh_ctx* c, int kernel_id, unsigned layer_mask) {
     if (!c || kernel_id < 0 || kernel_id >= XFH_K_COUNT) return XFH_ERR_INVALID_ARG;

@@ -145,6 +145,7 @@ struct MatchWs {
     int* h_out = nullptr; size_t cap_hout = 0;                         // pinned mirror of o_buf
     int32_t* o_tab = nullptr; size_t cap_tab = 0;
     void* b2_buf = nullptr; size_t cap_b2 = 0;                             // staging for the host-pointer best2 call
+    u64* bkeys = nullptr; size_t cap_bkeys = 0;                            // key planes + pairs of the many-pairs call (xfh_match_mnn_prepared_batch_device), grown on demand
 };
 
 // ---- launchers implemented in the .hip files ------------------------------------------
@@ -156,6 +157,14 @@ hipError_t launch_match_prepare(xfh_ctx* c, const float* d, int n, float* img);
 hipError_t bench_mnn_gemm(xfh_ctx* c, const float* img1, int n1, const float* img2, int n2, int iters, double* us_per_launch);
 hipError_t launch_mnn_prepared(xfh_ctx* c, const float* img1, int n1, const float* img2, int n2, float min_cossim,
                                int* idx1, int* idx2, float* dist, int* n_matches, const int* hdr1 = nullptr, const int* hdr2 = nullptr);
+struct MnnBatch;
+hipError_t launch_mnn_gemm_seg(xfh_ctx* c, const MnnBatch& jb);           // kernels_mnn_gemm.hip: the persistent many-pairs GEMM (mnn_gemm_seg.hip.h)
+struct XfhMatchPair {                                                     // one pair of a many-pairs call: prepared images in, match list out (device pointers)
+    const float* img1; int n1; const float* img2; int n2;
+    int* idx1; int* idx2; float* dist; int* n_matches;
+};
+hipError_t launch_mnn_batch(xfh_ctx* c, const XfhMatchPair* pairs, int n_pairs, float min_cossim);
+hipError_t bench_mnn_gemm_batch(xfh_ctx* c, const XfhMatchPair* pairs, int n_pairs, int iters, double* us_per_launch);
 hipError_t launch_mnn_gemm(xfh_ctx* c, const float* img1, int n1, const float* img2, int n2, u64* partR, size_t ldr, u64* partC, size_t ldc, u64* pairs);   // kernels_mnn_gemm.hip
 hipError_t launch_dist_i32(xfh_ctx* c, const float* d1, int n1, const float* d2, int n2, int32_t* out);
 hipError_t launch_distinctive(xfh_ctx* c, const float* table, const int* offsets, const int* indices, int n_groups, int max_group,

@@ -49,6 +49,7 @@ struct xfh_ctx {
     xfh_config cfg;
     XfhComm* comm = nullptr;        // RCCL communicator + communication stream (comm.cpp), created by xfh_comm_create
     int Hmax = 0, Wmax = 0;         // resized maxima (multiples of 32)
+    int num_cu = 256;               // compute units of the device (workgroups of the persistent match GEMM)
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;   // own_stream or an external one
     hipStream_t aux_stream = nullptr;                  // keypoint branch of run_extract (forked / joined with the two events)

@@ -346,6 +346,73 @@ hipError_t launch_mnn_prepared(xfh_ctx* c, const float* img1, int n1, const floa
     return launch_gemm_post(c, img1, n1, img2, n2, min_cossim, idx1, idx2, dist, n_matches, hdr1, hdr2);
 }
 
+// ---- many pairs in one call: k_mnn_gemm_seg over the tiles of all pairs + k_mnn_post_batch (at most MNN_MAX_JOBS pairs per launch pair; longer lists
+// go out in chunks).  Key planes and pairs live in one buffer of the ctx, laid out per chunk by mnn_seg_plan and grown when a call needs more.
+static hipError_t batch_chunk(xfh_ctx* c, const XfhMatchPair* pr, int n, float min_cossim, bool gemm_only) {
+    MatchWs& w = c->mws;
+    MnnPairIn in[MNN_MAX_JOBS];
+    int m = 0; int src[MNN_MAX_JOBS];
+    hipError_t e;
+    for (int p = 0; p < n; ++p) {
+        if (pr[p].n1 <= 0 || pr[p].n2 <= 0) {             // an empty side: no matches, nothing to multiply
+            if (!gemm_only && (e = hipMemsetAsync(pr[p].n_matches, 0, sizeof(int), c->stream)) != hipSuccess) return e;
+            continue;
+        }
+        in[m] = MnnPairIn{pr[p].img1, pr[p].n1, pr[p].img2, pr[p].n2}; src[m++] = p;
+    }
+    if (m == 0) return hipSuccess;
+    MnnBatch jb;
+    const size_t need = mnn_seg_plan(in, m, c->num_cu, nullptr, &jb);
+    if (w.cap_bkeys < need) {
+        if (w.bkeys) { if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return e; hipFree(w.bkeys); w.bkeys = nullptr; w.cap_bkeys = 0; }
+        if ((e = hipMalloc((void**)&w.bkeys, need * sizeof(u64))) != hipSuccess) return e;
+        w.cap_bkeys = need;
+    }
+    mnn_seg_plan(in, m, c->num_cu, w.bkeys, &jb);
+    if ((e = launch_mnn_gemm_seg(c, jb)) != hipSuccess) return e;
+    if (gemm_only) return hipSuccess;
+    MnnPostBatch pb;
+    int gx = 0;
+    for (int q = 0; q < m; ++q) {
+        const MnnJob& J = jb.job[q]; const XfhMatchPair& P = pr[src[q]]; MnnPostArgs& a = pb.job[q];
+        a.img1 = J.img1; a.img2 = J.img2; a.partR = J.partR; a.partC = J.partC; a.pairs = J.pairs;
+        a.idx1 = P.idx1; a.idx2 = P.idx2; a.dist = P.dist; a.n_matches = P.n_matches;
+        a.stamps = nullptr; a.hdr1 = nullptr; a.hdr2 = nullptr;
+        a.ldr = J.ldr; a.ldc = J.ldc; a.n1 = J.n1; a.n2 = J.n2; a.npr = 0; a.npc = J.P1; a.nb = (J.n1 + 15) / 16; a.ncoll = mnn_ncoll(J.n1);
+        a.segT = jb.T; a.segG = jb.G; a.tile0 = J.tile0; a.P2 = J.P2; a.min_cossim = min_cossim; a.pad = 0;
+        if (a.nb + a.ncoll > gx) gx = a.nb + a.ncoll;
+    }
+    for (int q = m; q < MNN_MAX_JOBS; ++q) pb.job[q] = pb.job[0];
+    XFH_SET_LDS_ATTR_ONCE(c, k_mnn_post_batch, MNN_POST_LDS);
+    hipLaunchKernelGGL(k_mnn_post_batch, dim3(gx, m), dim3(256), MNN_POST_LDS, c->stream, pb);
+    return hipGetLastError();
+}
+hipError_t launch_mnn_batch(xfh_ctx* c, const XfhMatchPair* pairs, int n_pairs, float min_cossim) {
+    hipError_t e;
+    // chunks share the key buffer: the stream orders a chunk's post before the next chunk's GEMM
+    for (int p0 = 0; p0 < n_pairs; p0 += MNN_MAX_JOBS)
+        if ((e = batch_chunk(c, pairs + p0, n_pairs - p0 < MNN_MAX_JOBS ? n_pairs - p0 : MNN_MAX_JOBS, min_cossim, false)) != hipSuccess) return e;
+    return hipSuccess;
+}
+// measurement hook (xfh_bench_mnn_gemm_batch): `iters` launches of k_mnn_gemm_seg alone on the first <= MNN_MAX_JOBS pairs, wall time per launch
+hipError_t bench_mnn_gemm_batch(xfh_ctx* c, const XfhMatchPair* pairs, int n_pairs, int iters, double* us_per_launch) {
+    const int n = n_pairs < MNN_MAX_JOBS ? n_pairs : MNN_MAX_JOBS;
+    hipError_t e = hipSuccess;
+    hipEvent_t e0, e1;
+    if ((e = hipEventCreate(&e0)) != hipSuccess) return e;
+    if ((e = hipEventCreate(&e1)) != hipSuccess) { hipEventDestroy(e0); return e; }
+    for (int i = 0; i < 10 && e == hipSuccess; ++i) e = batch_chunk(c, pairs, n, -1.0f, true);
+    if (e == hipSuccess) e = hipEventRecord(e0, c->stream);
+    for (int i = 0; i < iters && e == hipSuccess; ++i) e = batch_chunk(c, pairs, n, -1.0f, true);
+    if (e == hipSuccess) e = hipEventRecord(e1, c->stream);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    *us_per_launch = (double)ms * 1e3 / (iters > 0 ? iters : 1);
+    return e;
+}
+
 hipError_t launch_dist_i32(xfh_ctx* c, const float* d1, int n1, const float* d2, int n2, int32_t* out) {
     if (n1 <= 0 || n2 <= 0) return hipSuccess;
     launch_k(c, XFH_K_DIST_I32, -1, k_dist_mfma, dim3((n2 + DT - 1) / DT, (n1 + DT - 1) / DT), dim3(256), 0, d1, n1, d2, n2, out);

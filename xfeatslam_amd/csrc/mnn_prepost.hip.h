@@ -2,6 +2,7 @@
 // (second arg-max level, mutual check, ordered output).  Included by kernels_match.hip and tools/probes/mnn_probe.hip.
 #pragma once
 #include "mnn_layout.h"
+#include "mnn_seg_plan.h"
 
 // k_rownorm_img: F::normalize of both descriptor sets (ORBmatcher.cc:358-359: fp64 sum of squares, fp32
 // sqrt / max(.,1e-12) / divide) written as panel images; rows past the end of a set are written as zeros
@@ -52,22 +53,39 @@ __device__ __forceinline__ const float* mnn_row(const float* img, int row, int& 
 __host__ __device__ inline int mnn_ncoll(int n1) { const int nq = (n1 + 255) >> 8; return nq < 16 ? (nq < 1 ? 1 : nq) : 16; }
 #define MNN_POST_LD 68                 // LDS row pitch in floats (272 B: per-lane rows are read conflict free)
 #define MNN_POST_LDS ((16 + 256) * MNN_POST_LD * 4)
+// everything one match needs from k_mnn_post.  segG > 0: the key planes come from k_mnn_gemm_seg (mnn_gemm_seg.hip.h) -- the number of
+// row planes of a d1 panel follows from (segT, segG, tile0, P2) with the GEMM's own arithmetic and `npr` is ignored.
+struct MnnPostArgs {
+    const float* img1; const float* img2;
+    const u64* partR; const u64* partC; u64* pairs;
+    int* idx1; int* idx2; float* dist; int* n_matches;
+    long long* stamps; const int* hdr1; const int* hdr2;
+    size_t ldr, ldc;
+    int n1, n2, npr, npc, nb, ncoll;
+    int segT, segG, tile0, P2;
+    float min_cossim; int pad;
+};
 template <int TS>            // TS (probes only): wall-clock stamps of block 0 / the collector into `stamps`
-__global__ __launch_bounds__(256)
-void k_mnn_post(const float* __restrict__ img1, int n1, const float* __restrict__ img2, int n2,
-                const u64* __restrict__ partR, size_t ldr, int npr, const u64* __restrict__ partC, size_t ldc, int npc, float min_cossim,
-                u64* __restrict__ pairs, int nb, int ncoll, int* __restrict__ idx1, int* __restrict__ idx2, float* __restrict__ dist, int* __restrict__ n_matches,
-                long long* __restrict__ stamps, const int* __restrict__ hdr1, const int* __restrict__ hdr2) {
+__device__ __forceinline__ void mnn_post_body(const MnnPostArgs& a, const int bid, const int nblk) {
+    const float* __restrict__ img1 = a.img1; const float* __restrict__ img2 = a.img2;
+    const u64* __restrict__ partR = a.partR; const u64* __restrict__ partC = a.partC; u64* __restrict__ pairs = a.pairs;
+    int* __restrict__ idx1 = a.idx1; int* __restrict__ idx2 = a.idx2; float* __restrict__ dist = a.dist; int* __restrict__ n_matches = a.n_matches;
+    long long* __restrict__ stamps = a.stamps; const int* __restrict__ hdr1 = a.hdr1; const int* __restrict__ hdr2 = a.hdr2;
+    const size_t ldr = a.ldr, ldc = a.ldc;
+    const int n1 = a.n1, n2 = a.n2, npc = a.npc, nb = a.nb, ncoll = a.ncoll;
+    const float min_cossim = a.min_cossim;
     extern __shared__ __attribute__((aligned(16))) float spost[];
     const int t = threadIdx.x;
-#define MNN_STAMP(k) do { if (TS && t == 0 && (blockIdx.x == 0 || blockIdx.x + 1 == gridDim.x)) stamps[(blockIdx.x ? 16 : 0) + (k)] = wall_clock64(); } while (0)
+#define MNN_STAMP(k) do { if (TS && t == 0 && (bid == 0 || bid + 1 == nblk)) stamps[(bid ? 16 : 0) + (k)] = wall_clock64(); } while (0)
     MNN_STAMP(0);
-    if ((int)blockIdx.x < nb) {
+    if (bid < nb) {
         float* sA = spost;                               // [16 rows][68]: row in natural piece order (piece p = 2g + half at 4p)
         float* sB = spost + 16 * MNN_POST_LD;            // [16 row groups][16 candidates][68]
         const int c = t & 15, grp = t >> 4;
-        const int row = blockIdx.x * 16 + grp;           // the image holds whole panels: rows up to the panel end are readable (zeros)
+        const int row = bid * 16 + grp;                  // the image holds whole panels: rows up to the panel end are readable (zeros)
         // bestR[row] = maximum over the npr planes the GEMM blocks of this d1 panel wrote: lane c takes planes c, c+16, ...
+        int npr = a.npr;
+        if (a.segG > 0) npr = mnn_seg_planes(a.tile0 + (row >> 8) * a.P2, a.P2, a.segT, a.segG);      // uniform over the workgroup (16 rows of one panel)
         u64 kr = 0ull;
         if (row < n1) for (int pl = c; pl < npr; pl += 16) kr = mnn_umax64(kr, partR[(size_t)pl * ldr + row]);
         kr = mnn_umax64(kr, __shfl_xor(kr, 1)); kr = mnn_umax64(kr, __shfl_xor(kr, 2)); kr = mnn_umax64(kr, __shfl_xor(kr, 4)); kr = mnn_umax64(kr, __shfl_xor(kr, 8));
@@ -168,7 +186,7 @@ void k_mnn_post(const float* __restrict__ img1, int n1, const float* __restrict_
     // The pairs are re-armed by the NEXT call's k_mnn_gemm_img (a collector must not: the others still read them).
     int* wcnt = (int*)spost;                             // [qb own][4 waves], then [4] for the count of the rows before
     const int lane = t & 63, wave = t >> 6;
-    const int k = blockIdx.x - nb;                       // collector index
+    const int k = bid - nb;                              // collector index
     const int nq = (n1 + 255) >> 8;                      // blocks of 256 rows
     const int qspan = (nq + ncoll - 1) / ncoll;
     const int q_lo = (k * qspan < nq) ? k * qspan : nq, q_hi = (q_lo + qspan < nq) ? q_lo + qspan : nq;
@@ -248,4 +266,29 @@ void k_mnn_post(const float* __restrict__ img1, int n1, const float* __restrict_
     }
     MNN_STAMP(10);
 #undef MNN_STAMP
+}
+
+template <int TS>
+__global__ __launch_bounds__(256)
+void k_mnn_post(const float* __restrict__ img1, int n1, const float* __restrict__ img2, int n2,
+                const u64* __restrict__ partR, size_t ldr, int npr, const u64* __restrict__ partC, size_t ldc, int npc, float min_cossim,
+                u64* __restrict__ pairs, int nb, int ncoll, int* __restrict__ idx1, int* __restrict__ idx2, float* __restrict__ dist, int* __restrict__ n_matches,
+                long long* __restrict__ stamps, const int* __restrict__ hdr1, const int* __restrict__ hdr2) {
+    MnnPostArgs a;
+    a.img1 = img1; a.img2 = img2; a.partR = partR; a.partC = partC; a.pairs = pairs; a.idx1 = idx1; a.idx2 = idx2; a.dist = dist; a.n_matches = n_matches;
+    a.stamps = stamps; a.hdr1 = hdr1; a.hdr2 = hdr2; a.ldr = ldr; a.ldc = ldc; a.n1 = n1; a.n2 = n2; a.npr = npr; a.npc = npc; a.nb = nb; a.ncoll = ncoll;
+    a.segT = 0; a.segG = 0; a.tile0 = 0; a.P2 = 0; a.min_cossim = min_cossim; a.pad = 0;
+    mnn_post_body<TS>(a, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// the matches of up to MNN_MAX_JOBS pairs in one launch: blockIdx.y = pair (the table sits in the kernel arguments), blockIdx.x = block of that
+// pair's own grid (writers 0 .. nb-1, then its collectors); blocks past a pair's count leave at once.  Workgroups are dispatched in
+// ascending (y, x) order, so a pair's collectors only ever wait for writers that were dispatched before them.
+struct MnnPostBatch { MnnPostArgs job[MNN_MAX_JOBS]; };
+__global__ __launch_bounds__(256)
+void k_mnn_post_batch(const MnnPostBatch pb) {
+    const MnnPostArgs& a = pb.job[blockIdx.y];
+    const int nblk = a.nb + a.ncoll;
+    if ((int)blockIdx.x >= nblk) return;
+    mnn_post_body<0>(a, (int)blockIdx.x, nblk);
 }

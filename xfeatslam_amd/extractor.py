@@ -119,6 +119,41 @@ class Context:
         out.free()
         return i1, i2, dist
 
+    @staticmethod
+    def pair_tables(pairs):
+        """host-side pointer / size arrays of a many-pairs call: pairs = [((img1, n1), (img2, n2)), ...] -> (p1, n1, p2, n2) ctypes arrays"""
+        P = len(pairs)
+        p1 = (C.c_void_p * P)(*[a[0].ptr for a, _ in pairs]); p2 = (C.c_void_p * P)(*[b[0].ptr for _, b in pairs])
+        n1 = (C.c_int * P)(*[a[1] for a, _ in pairs]); n2 = (C.c_int * P)(*[b[1] for _, b in pairs])
+        return p1, n1, p2, n2
+
+    def match_mnn_prepared_batch(self, pairs, min_cossim: float = -1.0):
+        """xfh_match_mnn_prepared_batch_device: ORBmatcher::match of every (prepared set, prepared set) pair in one persistent GEMM launch +
+        one post launch -> [(idx1, idx2, dist), ...], pair by pair what match_mnn_prepared returns"""
+        P = len(pairs)
+        if P == 0:
+            return []
+        nm = [max(1, min(a[1], b[1])) for a, b in pairs]
+        off = np.concatenate([[0], np.cumsum([(12 * k + 63) // 64 * 64 for k in nm])]).astype(np.int64)
+        out = capi.DeviceBuffer(int(off[-1]) + 64); cnt = capi.DeviceBuffer(4 * P + 64)
+        p1, n1, p2, n2 = self.pair_tables(pairs)
+        i1 = (C.c_void_p * P)(*[out.ptr + int(off[p]) for p in range(P)])
+        i2 = (C.c_void_p * P)(*[out.ptr + int(off[p]) + 4 * nm[p] for p in range(P)])
+        ds = (C.c_void_p * P)(*[out.ptr + int(off[p]) + 8 * nm[p] for p in range(P)])
+        check(lib().xfh_match_mnn_prepared_batch_device(self.h, P, p1, n1, p2, n2, float(min_cossim), i1, i2, ds, cnt.ptr), self.h)
+        self.synchronize()
+        ks = cnt.download(np.int32, P)
+        res = []
+        for p in range(P):
+            k = int(ks[p])
+            if k < 0 or k > nm[p]:
+                out.free(); cnt.free()
+                raise capi.XfhError(6, "k_mnn_post_batch: collector timed out (n_matches < 0)")
+            res.append((out.download(np.int32, nm[p], int(off[p]))[:k], out.download(np.int32, nm[p], int(off[p]) + 4 * nm[p])[:k],
+                        out.download(np.float32, nm[p], int(off[p]) + 8 * nm[p])[:k]))
+        out.free(); cnt.free()
+        return res
+
     def distance_i32(self, d1: np.ndarray, d2: np.ndarray) -> np.ndarray:
         d1 = np.ascontiguousarray(d1, np.float32); d2 = np.ascontiguousarray(d2, np.float32)
         out = np.zeros((len(d1), len(d2)), np.int32)
