@@ -109,6 +109,7 @@ def main():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--streams", type=int, default=4, help="sub-batches in flight per GPU (one ctx with its own HIP streams each)")
     ap.add_argument("--match-iters", type=int, default=300)
+    ap.add_argument("--match-pairs", type=int, default=8, help="pairs of the batched match leg (frame 0 against this many partner frames in one call)")
     ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the bounded all-core CPU-baseline sample (0 = skip)")
     ap.add_argument("--gather", choices=["allgather", "root", "compact"], default="allgather",
                     help="how the records reach the SLAM rank with N > 1: allgather = ncclAllGather (default: the collective BASELINE.json / SURVEY.md 8e name), "
@@ -696,6 +697,73 @@ def legs(out, args, lib, capi, synth, Context, ctx, blob, frames, d_in, d_recb, 
                                                       "note": "the same events inside the three-launch loop (k_rownorm_img in front)"},
                                  "steady_state": {"wall_us_per_launch": gemm_b2b.value, "frac": 2.0 * nf * nf * 64 / (gemm_b2b.value * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS,
                                                   "measured": "xfh_bench_mnn_gemm: 300 launches of the kernel alone back to back, wall time between two stream events / 300"}}}
+
+    # ---- many pairs in one call: frame 0 against P partners (the tracker's frame against previous frame / key frames / loop candidates; the
+    # reference calls ORBmatcher::match once per pair).  One persistent GEMM launch (k_mnn_gemm_seg) + one post launch for all pairs.
+    P = args.match_pairs
+    nfr_img = min(B, P + 1)
+    bimgs = capi.DeviceBuffer(nfr_img * ib); brec = capi.DeviceBuffer(nfr_img * rec_bytes)
+    capi.check(lib.xfh_extract_batch_device_images(ctx.h, in_ptr, nfr_img, H, W, 0, 0, brec.ptr, bimgs.ptr), ctx.h)
+    ctx.synchronize()
+    partners = [1 + (k % max(nfr_img - 1, 1)) if nfr_img > 1 else 0 for k in range(P)]
+    t_img1 = (C.c_void_p * P)(*[bimgs.ptr] * P); t_img2 = (C.c_void_p * P)(*[bimgs.ptr + j * ib for j in partners])
+    t_n = (C.c_int * P)(*[nf] * P)
+    bout = capi.DeviceBuffer(P * 12 * nf + 64); bcnt = capi.DeviceBuffer(4 * P + 64)
+    t_i1 = (C.c_void_p * P)(*[bout.ptr + k * 12 * nf for k in range(P)]); t_i2 = (C.c_void_p * P)(*[bout.ptr + k * 12 * nf + 4 * nf for k in range(P)])
+    t_ds = (C.c_void_p * P)(*[bout.ptr + k * 12 * nf + 8 * nf for k in range(P)])
+
+    def match_batch():
+        capi.check(lib.xfh_match_mnn_prepared_batch_device(ctx.h, P, t_img1, t_n, t_img2, t_n, -1.0, t_i1, t_i2, t_ds, bcnt.ptr), ctx.h)
+    for _ in range(30):
+        match_batch()
+    ctx.synchronize()
+    ctx.timing_enable(capi.K["MNN_GEMM_SEG"])
+    for _ in range(max(20, args.match_iters // P)):
+        match_batch()
+    ctx.synchronize()
+    n_seg, ms_seg = ctx.timing_read()
+    ctx.timing_enable(0)
+    bk = bcnt.download(np.int32, P)
+    batch_lists = [(bout.download(np.int32, int(bk[k]), k * 12 * nf), bout.download(np.int32, int(bk[k]), k * 12 * nf + 4 * nf),
+                    bout.download(np.float32, int(bk[k]), k * 12 * nf + 8 * nf)) for k in range(P)]
+    same = True                                             # the batched call against the pair-by-pair call, every pair
+    for k in range(P):
+        capi.check(lib.xfh_match_mnn_prepared_device(ctx.h, bimgs.ptr, nf, bimgs.ptr + partners[k] * ib, nf, -1.0, *mo), ctx.h)
+        ctx.synchronize()
+        nk = int(mout.download(np.int32, 1, 12 * nf)[0])
+        same = same and nk == int(bk[k]) and np.array_equal(mout.download(np.int32, nk), batch_lists[k][0]) and \
+            np.array_equal(mout.download(np.int32, nk, 4 * nf), batch_lists[k][1]) and np.array_equal(mout.download(np.float32, nk, 8 * nf), batch_lists[k][2])
+    c_bat, c_seg = C.c_double(0.0), C.c_double(0.0)
+    capi.check(lib.xfh_bench_match_batch(ctx.h, P, t_img1, t_n, t_img2, t_n, -1.0, t_i1, t_i2, t_ds, bcnt.ptr, max(20, args.match_iters // P), C.byref(c_bat)), ctx.h)
+    sclk_in = C.c_double(0.0)
+    capi.check(lib.xfh_bench_mnn_gemm_batch(ctx.h, P, t_img1, t_n, t_img2, t_n, 100, C.byref(c_seg), C.byref(sclk_in)), ctx.h)
+    sclk, cpm = C.c_double(0.0), C.c_double(0.0)
+    capi.check(lib.xfh_bench_sclk(ctx.h, 4096, C.byref(sclk), C.byref(cpm)), ctx.h)
+    seg_us = ms_seg / max(n_seg, 1) * 1e3
+    seg_flop = 2.0 * nf * nf * 64 * P
+    peak_at_sclk = PEAK_F32_MFMA_TFLOPS * sclk_in.value / 2400.0         # 157.3 TFLOP/s = 256 CUs x 256 flop/clk x 2.4 GHz
+    out["match"]["batched"] = {
+        "pairs": P, "n1": nf, "n2": nf, "us_per_call": c_bat.value, "us_per_pair": c_bat.value / P, "pairs_per_s": P * nf * nf / (c_bat.value * 1e-6),
+        "n_matches": [int(x) for x in bk],
+        "call": f"xfh_match_mnn_prepared_batch_device: frame 0's prepared image against the images of {P} partner frames (as written by xfh_extract_batch_device_images), "
+                "k_mnn_gemm_seg + k_mnn_post_batch, calls back to back from a C loop (xfh_bench_match_batch: wall time between two stream events / calls)",
+        "pair_lists_equal_pair_by_pair_calls": bool(same),
+        "roofline": {"kernel": "k_mnn_gemm_seg", "bound": "mfma", "achieved": seg_flop / (seg_us * 1e-6) / 1e12 if n_seg else 0.0, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                     "frac": seg_flop / (seg_us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS if n_seg else 0.0, "avg_launch_us": seg_us, "launches": n_seg, "flops_per_launch": seg_flop,
+                     "measured": "HIP events attached to every dispatch of the kernel inside the loop of batched calls (the rocprofv3 --kernel-trace view)",
+                     "steady_state": {"wall_us_per_launch": c_seg.value, "frac": seg_flop / (c_seg.value * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                                      "measured": "xfh_bench_mnn_gemm_batch: 100 launches of the kernel alone back to back, wall time between two stream events / 100"}}}
+    # the clock the f32 MFMA peak is priced at (2.4 GHz -> 157.3 TFLOP/s) is not the clock the GPU holds under this load
+    out["match"]["sclk_under_f32_mfma_load"] = {
+        "sclk_mhz": sclk_in.value, "sclk_mhz_mfma_loop_on_constant_operands": sclk.value, "cycles_per_mfma_oldest_wave": cpm.value, "peak_at_sclk_TFLOPs": peak_at_sclk,
+        "frac_of_peak_at_sclk": {"k_mnn_gemm_img": gemm_tf / peak_at_sclk if peak_at_sclk else None,
+                                 "k_mnn_gemm_seg": seg_flop / (seg_us * 1e-6) / 1e12 / peak_at_sclk if (peak_at_sclk and n_seg) else None},
+        "measured": "sclk_mhz: shader clocks (s_memtime) per 100 MHz reference tick (s_memrealtime) that workgroup 0 of k_mnn_gemm_seg saw across one launch of the batched "
+                    "GEMM (xfh_bench_mnn_gemm_batch); the second figure: xfh_bench_sclk, every SIMD issuing v_mfma_f32_32x32x2_f32 back to back on constant operands. "
+                    "f32 MFMAs and VALU instructions share the SIMD's vector pipe on gfx950 (profiles/r04_pipe_probe.log), so the ceiling of the GEMM with its arg-max "
+                    "epilogue is below this peak as well: DESIGN.md 5"}
+    for b in (bimgs, brec, bout, bcnt):
+        b.free()
 
     # ---- the other matcher kernels (no timing anywhere in round 1) ----------------------------------------------------
     aux = {}

@@ -35,9 +35,11 @@ int xfh_bench_match_prepared(xfh_ctx* ctx, const void* d_image1, int n1, const v
 int xfh_bench_match_raw(xfh_ctx* ctx, const float* d_d1, int n1, const float* d_d2, int n2, float min_cossim,
                         int* d_idx1, int* d_idx2, float* d_dist, int* d_n_matches, int iters, double* us_per_call);   /* the same for xfh_match_mnn_device */
 /* the many-pairs call (xfh_match_mnn_prepared_batch_device): `iters` launches of its GEMM alone (k_mnn_gemm_seg) back to back -> wall time per
- * launch; and `iters` whole calls (GEMM + k_mnn_post_batch) back to back from C -> wall time per call.  Arguments as the call itself. */
+ * launch, and (sclk_mhz, may be NULL) the shader clock workgroup 0 saw INSIDE the last launch (shader clocks per 100 MHz reference tick: the clock
+ * the GPU holds on these operands, which prices the f32 MFMA peak this kernel can reach); and `iters` whole calls (GEMM + k_mnn_post_batch) back
+ * to back from C -> wall time per call.  Arguments as the call itself. */
 int xfh_bench_mnn_gemm_batch(xfh_ctx* ctx, int n_pairs, const void* const* d_image1, const int* n1, const void* const* d_image2, const int* n2,
-                             int iters, double* us_per_launch);
+                             int iters, double* us_per_launch, double* sclk_mhz);
 int xfh_bench_match_batch(xfh_ctx* ctx, int n_pairs, const void* const* d_image1, const int* n1, const void* const* d_image2, const int* n2, float min_cossim,
                           int* const* d_idx1, int* const* d_idx2, float* const* d_dist, int* d_n_matches, int iters, double* us_per_call);
 const char* xfh_kernel_name(int kernel_id);
@@ -67,6 +69,10 @@ int xfh_debug_select(xfh_ctx* ctx, const unsigned long long* keys, int n, int wi
  * them under rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE; tools/summarize_profiles.py turns counter / nbytes into the
  * correction factors of profiles/pmc_traffic.json. */
 int xfh_bench_calib(xfh_ctx* ctx, int mode, size_t nbytes, int iters);
+/* The shader clock under f32 MFMA load: every SIMD of the device issues `mfmas` v_mfma_f32_32x32x2_f32 per wave back to back (two waves per SIMD);
+ * *sclk_mhz = shader clocks per 100 MHz reference tick, *cycles_per_mfma = the issue period seen by one wave (128 = the matrix pipe never idles).
+ * The f32 MFMA peak at THIS clock is 256 CUs x 256 flop x sclk; the nominal 157.3 TFLOP/s assumes 2.4 GHz. */
+int xfh_bench_sclk(xfh_ctx* ctx, int mfmas, double* sclk_mhz, double* cycles_per_mfma);
 
 #ifdef __cplusplus
 }

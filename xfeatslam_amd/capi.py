@@ -25,7 +25,7 @@ STATUS = {0: "OK", 1: "INVALID_ARG", 2: "EMPTY_IMAGE", 3: "BAD_SIZE", 4: "NO_WEI
 ERR_EMPTY_IMAGE = 2
 ERR_NO_DEVICE = 7
 
-K = dict(NONE=0, MNN_GEMM=1, CONV_MFMA=2, CONV_DIRECT=3, NMS=4, SELECT=5, DESC=6, HEADS=7, DIST_I32=8, PREPROC=9, BEST2=10, DISTINCTIVE=11)
+K = dict(NONE=0, MNN_GEMM=1, CONV_MFMA=2, CONV_DIRECT=3, NMS=4, SELECT=5, DESC=6, HEADS=7, DIST_I32=8, PREPROC=9, BEST2=10, DISTINCTIVE=11, MNN_GEMM_SEG=12)
 T = dict(X=0, XSTAT=1, SKIP_POOL=2, FEATS=6, H1=8, K1H=9, RAW0=16, STAT0=48, SEL=80)
 
 
@@ -108,7 +108,8 @@ SYMBOLS = [
     ("xfh_timing_enable", _i, [_vp, _i, C.c_uint]),
     ("xfh_timing_read", _i, [_vp, _pi, C.POINTER(C.c_double)]),
     ("xfh_bench_mnn_gemm", _i, [_vp, _vp, _i, _vp, _i, _i, C.POINTER(C.c_double)]),
-    ("xfh_bench_mnn_gemm_batch", _i, [_vp, _i, _vp, _vp, _vp, _vp, _i, C.POINTER(C.c_double)]),
+    ("xfh_bench_sclk", _i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    ("xfh_bench_mnn_gemm_batch", _i, [_vp, _i, _vp, _vp, _vp, _vp, _i, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     ("xfh_bench_match_batch", _i, [_vp, _i, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp, _vp, _i, C.POINTER(C.c_double)]),
     ("xfh_bench_match_prepared", _i, [_vp, _vp, _i, _vp, _i, C.c_float, _vp, _vp, _vp, _vp, _i, C.POINTER(C.c_double)]),
     ("xfh_bench_match_raw", _i, [_vp, _vp, _i, _vp, _i, C.c_float, _vp, _vp, _vp, _vp, _i, C.POINTER(C.c_double)]),

@@ -53,3 +53,46 @@ extern "C" int xfh_bench_calib(xfh_ctx* c, int mode, size_t nbytes, int iters) {
     if (e != hipSuccess) { c->hip_err = std::string("xfh_bench_calib: ") + hipGetErrorString(e); return XFH_ERR_HIP; }
     return XFH_OK;
 }
+
+// xfh_bench_sclk: the shader clock the GPU holds while every SIMD issues v_mfma_f32_32x32x2_f32 back to back.  One workgroup of 8 waves per
+// CU runs `mfmas` MFMAs per wave over 8 independent accumulators; wave 0 of every workgroup reports its span in shader clocks (clock64 =
+// s_memtime) and in the constant 100 MHz counter (wall_clock64 = s_memrealtime): sclk = 100 MHz * clocks / ticks, and clocks / MFMAs = the
+// issue period (64 cycles alone, 128 with two waves per SIMD).  The peak the match GEMM is priced against (157.3 TFLOP/s) assumes 2.4 GHz; boxes
+// of this pool hold 2.0 - 2.2 GHz under this load (profiles/r04_pipe_probe.log), which caps ANY f32 MFMA kernel at sclk / 2.4 of that peak.
+__global__ __launch_bounds__(512, 2)
+void k_sclk(int mfmas, long long* __restrict__ out, float* __restrict__ sink) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    f32x16 acc[8];
+    for (int q = 0; q < 8; ++q) for (int e = 0; e < 16; ++e) acc[q][e] = 0.f;
+    const float a = (float)lane * 1e-3f, b = 1.0f;
+    __syncthreads();
+    const long long c0 = clock64(), w0 = wall_clock64();
+    for (int it = 0; it < mfmas; it += 8) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[q], 0, 0, 0);
+    }
+    float r = 0.f;
+    for (int q = 0; q < 8; ++q) r += acc[q][0] + acc[q][15];
+    const long long c1 = clock64(), w1 = wall_clock64();
+    if (wave == 0 && lane == 0) { out[blockIdx.x * 2] = c1 - c0; out[blockIdx.x * 2 + 1] = w1 - w0; }
+    if (r == 123.456f) *sink = r;
+}
+extern "C" int xfh_bench_sclk(xfh_ctx* c, int mfmas, double* sclk_mhz, double* cycles_per_mfma) {
+    if (!c || mfmas < 8 || !sclk_mhz || !cycles_per_mfma) return XFH_ERR_INVALID_ARG;
+    if (hipSetDevice(c->cfg.device) != hipSuccess) return XFH_ERR_HIP;
+    const int G = c->num_cu;
+    long long* out = nullptr; float* sink = nullptr;
+    if (hipMalloc((void**)&out, (size_t)G * 16) != hipSuccess) return XFH_ERR_OUT_OF_MEMORY;
+    if (hipMalloc((void**)&sink, 256) != hipSuccess) { hipFree(out); return XFH_ERR_OUT_OF_MEMORY; }
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k_sclk, dim3(G), dim3(512), 0, c->stream, mfmas, out, sink);     // the last launch counts: clocks settled
+    hipError_t e = hipStreamSynchronize(c->stream);
+    long long* h = (long long*)malloc((size_t)G * 16);
+    if (e == hipSuccess) e = hipMemcpy(h, out, (size_t)G * 16, hipMemcpyDeviceToHost);
+    double clk = 0, tick = 0;
+    for (int b = 0; b < G; ++b) { clk += (double)h[2 * b]; tick += (double)h[2 * b + 1]; }
+    free(h); hipFree(out); hipFree(sink);
+    if (e != hipSuccess) { c->hip_err = std::string("xfh_bench_sclk: ") + hipGetErrorString(e); return XFH_ERR_HIP; }
+    *sclk_mhz = tick > 0 ? 100.0 * clk / tick : 0.0;
+    *cycles_per_mfma = clk / G / mfmas;
+    return XFH_OK;
+}

@@ -856,13 +856,14 @@ int xfh_bench_match_raw(xfh_ctx* c, const float* d1, int n1, const float* d2, in
                         int* idx1, int* idx2, float* dist, int* n_matches, int iters, double* us_per_call) {
     return bench_match(c, false, d1, n1, d2, n2, min_cossim, idx1, idx2, dist, n_matches, iters, us_per_call);
 }
-int xfh_bench_mnn_gemm_batch(xfh_ctx* c, int n_pairs, const void* const* image1, const int* n1, const void* const* image2, const int* n2, int iters, double* us_per_launch) {
+int xfh_bench_mnn_gemm_batch(xfh_ctx* c, int n_pairs, const void* const* image1, const int* n1, const void* const* image2, const int* n2, int iters, double* us_per_launch,
+                             double* sclk_mhz) {
     std::vector<XfhMatchPair> v;
     const int rc = gather_pairs(c, n_pairs, image1, n1, image2, n2, nullptr, nullptr, nullptr, nullptr, false, v);
     if (rc != XFH_OK) return rc;
     if (n_pairs < 1 || iters < 1 || !us_per_launch) return XFH_ERR_INVALID_ARG;
     HIPCK(c, hipSetDevice(c->cfg.device));
-    HIPCK(c, bench_mnn_gemm_batch(c, v.data(), n_pairs, iters, us_per_launch));
+    HIPCK(c, bench_mnn_gemm_batch(c, v.data(), n_pairs, iters, us_per_launch, sclk_mhz));
     return XFH_OK;
 }
 int xfh_bench_match_batch(xfh_ctx* c, int n_pairs, const void* const* image1, const int* n1, const void* const* image2, const int* n2, float min_cossim,

@@ -164,7 +164,7 @@ struct XfhMatchPair {                                                     // one
     int* idx1; int* idx2; float* dist; int* n_matches;
 };
 hipError_t launch_mnn_batch(xfh_ctx* c, const XfhMatchPair* pairs, int n_pairs, float min_cossim);
-hipError_t bench_mnn_gemm_batch(xfh_ctx* c, const XfhMatchPair* pairs, int n_pairs, int iters, double* us_per_launch);
+hipError_t bench_mnn_gemm_batch(xfh_ctx* c, const XfhMatchPair* pairs, int n_pairs, int iters, double* us_per_launch, double* sclk_mhz);
 hipError_t launch_mnn_gemm(xfh_ctx* c, const float* img1, int n1, const float* img2, int n2, u64* partR, size_t ldr, u64* partC, size_t ldc, u64* pairs);   // kernels_mnn_gemm.hip
 hipError_t launch_dist_i32(xfh_ctx* c, const float* d1, int n1, const float* d2, int n2, int32_t* out);
 hipError_t launch_distinctive(xfh_ctx* c, const float* table, const int* offsets, const int* indices, int n_groups, int max_group,

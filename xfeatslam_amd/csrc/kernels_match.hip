@@ -348,7 +348,7 @@ hipError_t launch_mnn_prepared(xfh_ctx* c, const float* img1, int n1, const floa
 
 // ---- many pairs in one call: k_mnn_gemm_seg over the tiles of all pairs + k_mnn_post_batch (at most MNN_MAX_JOBS pairs per launch pair; longer lists
 // go out in chunks).  Key planes and pairs live in one buffer of the ctx, laid out per chunk by mnn_seg_plan and grown when a call needs more.
-static hipError_t batch_chunk(xfh_ctx* c, const XfhMatchPair* pr, int n, float min_cossim, bool gemm_only) {
+static hipError_t batch_chunk(xfh_ctx* c, const XfhMatchPair* pr, int n, float min_cossim, bool gemm_only, u64* dbg = nullptr) {
     MatchWs& w = c->mws;
     MnnPairIn in[MNN_MAX_JOBS];
     int m = 0; int src[MNN_MAX_JOBS];
@@ -369,6 +369,7 @@ static hipError_t batch_chunk(xfh_ctx* c, const XfhMatchPair* pr, int n, float m
         w.cap_bkeys = need;
     }
     mnn_seg_plan(in, m, c->num_cu, w.bkeys, &jb);
+    jb.dbg = dbg;
     if ((e = launch_mnn_gemm_seg(c, jb)) != hipSuccess) return e;
     if (gemm_only) return hipSuccess;
     MnnPostBatch pb;
@@ -395,21 +396,26 @@ hipError_t launch_mnn_batch(xfh_ctx* c, const XfhMatchPair* pairs, int n_pairs, 
     return hipSuccess;
 }
 // measurement hook (xfh_bench_mnn_gemm_batch): `iters` launches of k_mnn_gemm_seg alone on the first <= MNN_MAX_JOBS pairs, wall time per launch
-hipError_t bench_mnn_gemm_batch(xfh_ctx* c, const XfhMatchPair* pairs, int n_pairs, int iters, double* us_per_launch) {
+hipError_t bench_mnn_gemm_batch(xfh_ctx* c, const XfhMatchPair* pairs, int n_pairs, int iters, double* us_per_launch, double* sclk_mhz) {
     const int n = n_pairs < MNN_MAX_JOBS ? n_pairs : MNN_MAX_JOBS;
     hipError_t e = hipSuccess;
     hipEvent_t e0, e1;
-    if ((e = hipEventCreate(&e0)) != hipSuccess) return e;
-    if ((e = hipEventCreate(&e1)) != hipSuccess) { hipEventDestroy(e0); return e; }
+    u64* dbg = nullptr;
+    if ((e = hipMalloc((void**)&dbg, 2 * sizeof(u64))) != hipSuccess) return e;
+    if ((e = hipEventCreate(&e0)) != hipSuccess) { hipFree(dbg); return e; }
+    if ((e = hipEventCreate(&e1)) != hipSuccess) { hipEventDestroy(e0); hipFree(dbg); return e; }
     for (int i = 0; i < 10 && e == hipSuccess; ++i) e = batch_chunk(c, pairs, n, -1.0f, true);
     if (e == hipSuccess) e = hipEventRecord(e0, c->stream);
-    for (int i = 0; i < iters && e == hipSuccess; ++i) e = batch_chunk(c, pairs, n, -1.0f, true);
+    for (int i = 0; i < iters && e == hipSuccess; ++i) e = batch_chunk(c, pairs, n, -1.0f, true, dbg);       // the last launch's clocks are read below
     if (e == hipSuccess) e = hipEventRecord(e1, c->stream);
     if (e == hipSuccess) e = hipEventSynchronize(e1);
     float ms = 0.f;
     if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
-    hipEventDestroy(e0); hipEventDestroy(e1);
+    u64 h[2] = {0, 0};
+    if (e == hipSuccess) e = hipMemcpy(h, dbg, sizeof h, hipMemcpyDeviceToHost);
+    hipEventDestroy(e0); hipEventDestroy(e1); hipFree(dbg);
     *us_per_launch = (double)ms * 1e3 / (iters > 0 ? iters : 1);
+    if (sclk_mhz) *sclk_mhz = h[1] ? 100.0 * (double)h[0] / (double)h[1] : 0.0;
     return e;
 }
 

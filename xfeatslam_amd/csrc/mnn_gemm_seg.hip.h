@@ -43,6 +43,10 @@ void k_mnn_gemm_seg(const MnnBatch jb) {
     const int NS = tau_hi - tau_lo;
     if (NS <= 0) return;
     const float NEG = -__builtin_huge_valf();
+    // measurement (xfh_bench_mnn_gemm_batch): workgroup 0 reports its span in shader clocks and in 100 MHz reference ticks -> the clock the
+    // GPU holds INSIDE this kernel, on these operands (an MFMA loop on constant operands clocks higher)
+    long long sclk0 = 0, wall0 = 0;
+    if (DBG == 0 && jb.dbg && w == 0) { sclk0 = clock64(); wall0 = wall_clock64(); }
     // The per-lane addresses of the epilogue are recomputed from the lane id inside the phase that uses them (LAUNDER keeps hipcc from
     // hoisting them out of the tile loop): hoisted, they sit in registers across the K loop -- accumulators 128 + strip 64 + operands 32
     // are live there -- and get spilled; a reload at the start of a K phase waits vmcnt(0), i.e. for the key stores before it.
@@ -310,6 +314,7 @@ void k_mnn_gemm_seg(const MnnBatch jb) {
     flush_rows(prev);
     MNN_SEG_STAMP();
     if (SKEW && wc == 0) __builtin_amdgcn_s_barrier();                       // X's closing phase pairs with Y's last E phase
+    if (DBG == 0 && jb.dbg && w == 0 && t == 0) { jb.dbg[0] = (u64)(clock64() - sclk0); jb.dbg[1] = (u64)(wall_clock64() - wall0); }
     if (DBG == 3 && lane == 0) jb.job[0].partR[(size_t)w * 8 + wave] = (u64)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));   // hwreg(HW_REG_HW_ID, 0, 32)
 #undef MNN_LAUNDER
 #undef MNN_SEG_STAMP
