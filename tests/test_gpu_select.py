@@ -75,36 +75,43 @@ def test_select_stage_on_crafted_candidates(name, nfeatures):
         ctx.close()
 
 
-def test_select_forms_agree_on_frames():
+def test_select_forms_agree_on_frames(tmp_path):
     """whole extraction with k_select forced to its radix + bitonic form, with the keypoint branch on a second stream instead of riding on
-    the backbone's launches, and with the heatmap head as a launch of its own == the default records"""
+    the backbone's launches, and with the heatmap head as a launch of its own == the records of the shipped library.  The knobs that force
+    those forms exist in the debug build only (libxfeat_hip_knobs.so, -DXFH_TEST_KNOBS): each variant runs in a worker process that
+    loads that build; the shipped library ignores the variables (checked first)."""
     import os
+    import subprocess
+    import sys
     from conftest import records_equal
     from xfeatslam_amd import capi, synth, weights as WT
     from xfeatslam_amd.extractor import Context
     lib = capi.lib()
+    assert os.path.exists(capi.KNOBS_LIB_PATH), "run `make -C xfeatslam_amd/csrc knobs` (or __graft_entry__.build())"
     frames = synth.frames(3, 480, 640, seed=11)
     blob = WT.pack_blob(WT.make_synthetic(1234, 3.0))
-    raws = []
-    for knob in (None, "XFH_SELECT_LEGACY", "XFH_NO_RIDE", "XFH_NO_NMS_HEAT"):
-        if knob:
-            os.environ[knob] = "1"
-        try:
-            ctx = Context(nfeatures=4096, max_height=480, max_width=640, max_batch=3)
-        finally:
-            if knob:
-                del os.environ[knob]
+    os.environ["XFH_SELECT_LEGACY"] = "1"; os.environ["XFH_NO_RIDE"] = "1"        # the shipped build must not even look at these
+    try:
+        ctx = Context(nfeatures=4096, max_height=480, max_width=640, max_batch=3)
+    finally:
+        del os.environ["XFH_SELECT_LEGACY"]; del os.environ["XFH_NO_RIDE"]
+    try:
         ctx.load_weights(blob)
         din = capi.DeviceBuffer(frames.nbytes).upload(frames); rec = capi.DeviceBuffer(3 * ctx.rec_bytes)
         capi.check(lib.xfh_extract_batch_device(ctx.h, din.ptr, 3, 480, 640, 150, 400, rec.ptr), ctx.h)
         ctx.synchronize()
-        raws.append((ctx, rec.download(np.uint8, 3 * ctx.rec_bytes)))
-    try:
-        for k in range(1, len(raws)):
-            assert records_equal(raws[0][0], raws[0][1], raws[k][1], 3), k
+        base = rec.download(np.uint8, 3 * ctx.rec_bytes)
+        worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "workers", "knob_worker.py")
+        for knob in (None, "XFH_SELECT_LEGACY", "XFH_NO_RIDE", "XFH_NO_NMS_HEAT"):
+            env = dict(os.environ, XFEAT_HIP_LIB=capi.KNOBS_LIB_PATH)
+            if knob:
+                env[knob] = "1"
+            out = str(tmp_path / f"rec_{knob}.npy")
+            r = subprocess.run([sys.executable, worker, out], env=env, capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, (knob, r.stderr[-2000:])
+            assert records_equal(ctx, base, np.load(out), 3), knob
     finally:
-        for c, _ in raws:
-            c.close()
+        ctx.close()
 
 
 def test_select_stage_is_stable_over_many_launches():

@@ -13,7 +13,10 @@ import os
 import numpy as np
 
 _DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_DIR, "libxfeat_hip.so")
+# XFEAT_HIP_LIB: another build of the same ABI (the harness only: tests/workers/knob_worker.py and tools/ load the debug build with the test knobs,
+# libxfeat_hip_knobs.so, this way -- the library itself reads no such variable)
+LIB_PATH = os.environ.get("XFEAT_HIP_LIB") or os.path.join(_DIR, "libxfeat_hip.so")
+KNOBS_LIB_PATH = os.path.join(_DIR, "libxfeat_hip_knobs.so")
 
 KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
                      ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])

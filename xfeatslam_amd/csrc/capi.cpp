@@ -120,20 +120,25 @@ int xfh_create(const xfh_config* cfg, xfh_ctx** out) {
     if (num_cu > 0) c->num_cu = num_cu;
     if (c->cfg.nms_threshold <= 0.f) c->cfg.nms_threshold = 0.05f;
     c->Hmax = (cfg->max_height / 32) * 32; c->Wmax = (cfg->max_width / 32) * 32;
-    if (const char* e = getenv("XFH_SELECT_LEGACY")) c->select_legacy = e[0] == '1';      // test knob: k_select's fallback form for every frame
-    if (const char* e = getenv("XFH_NO_NMS_HEAT")) c->no_nms_heat = e[0] == '1';          // test knob: k_heads_heat as a launch of its own for every batch size
-    if (const char* e = getenv("XFH_NO_RIDE")) c->no_ride = e[0] == '1';                  // test knob: the keypoint branch on the second stream for every batch size
+#ifdef XFH_TEST_KNOBS
+    // DEBUG BUILD ONLY (make knobs -> libxfeat_hip_knobs.so, loaded by tests/workers/knob_worker.py and tools/flake_hunt.sh): kernel forms that the
+    // shipped library selects by batch size alone can be forced here, to bisect a box-dependent failure.  The default build has one path.
+    if (const char* e = getenv("XFH_SELECT_LEGACY")) c->select_legacy = e[0] == '1';      // k_select's fallback form for every frame
+    if (const char* e = getenv("XFH_NO_NMS_HEAT")) c->no_nms_heat = e[0] == '1';          // k_heads_heat as a launch of its own for every batch size
+    if (const char* e = getenv("XFH_NO_RIDE")) c->no_ride = e[0] == '1';                  // the keypoint branch on the second stream for every batch size
+#endif
     const int B = cfg->max_batch;
     int rc = XFH_OK;
     auto fail = [&](int code) { xfh_destroy(c); return code; };
 #define A(ptr, bytes) do { if (hipMalloc((void**)&(ptr), (bytes)) != hipSuccess) return fail(XFH_ERR_OUT_OF_MEMORY); } while (0)
     if (hipSetDevice(cfg->device) != hipSuccess) return fail(XFH_ERR_HIP);
     {
-        // XFH_CU_MASKS="lo-hi,lo-hi,..." (measurement knob, tools/cu_mask_ab.sh): the k-th ctx created in this process runs its streams on
-        // the CUs [lo, hi] of entry k mod n only (hipExtStreamCreateWithCUMask).  Unset (the default): all CUs.
-        static std::atomic<int> created{0};
         uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         bool masked = false;
+#ifdef XFH_TEST_KNOBS
+        // XFH_CU_MASKS="lo-hi,lo-hi,..." (measurement knob of the debug build, tools/cu_mask_ab.sh): the k-th ctx created in this process runs its
+        // streams on the CUs [lo, hi] of entry k mod n only (hipExtStreamCreateWithCUMask).  Unset: all CUs.
+        static std::atomic<int> created{0};
         if (const char* e = getenv("XFH_CU_MASKS")) {
             std::vector<std::pair<int, int>> rg;
             for (const char* p = e; *p;) {
@@ -148,6 +153,7 @@ int xfh_create(const xfh_config* cfg, xfh_ctx** out) {
                 masked = true;
             }
         }
+#endif
         if (masked) {
             if (hipExtStreamCreateWithCUMask(&c->own_stream, 8, mask) != hipSuccess) return fail(XFH_ERR_HIP);
             if (hipExtStreamCreateWithCUMask(&c->aux_stream, 8, mask) != hipSuccess) return fail(XFH_ERR_HIP);
