@@ -133,11 +133,16 @@ public:
         if (_image.empty()) return -1;                       // :253-254
         const cv::Mat image = _image.getMat();
         if (image.type() != CV_8UC1) throw std::invalid_argument("Unsupported number of channels in the input image.");  // :179, :257
+        if ((size_t)image.step < (size_t)image.cols) throw std::invalid_argument("image rows overlap (step < cols)");
         _descriptors.create(nfeatures, 64, CV_32F);          // :347
         cv::Mat desc = _descriptors.getMat();
+        // create() keeps a pre-sized array of the right shape as it is -- also a non-continuous one (an ROI, a padded row step): the C ABI
+        // writes nfeatures * 64 CONTIGUOUS floats, so such a destination gets them through a temporary
+        cv::Mat dense = desc.isContinuous() ? desc : cv::Mat(nfeatures, 64, CV_32F);
         int n_valid = 0;
-        const int mono = run(image.data, image.rows, image.cols, (int)image.step, desc.ptr<float>(0), _keypoints, vLappingArea, &n_valid);
-        if (mono >= 0 && n_valid == 0) _descriptors.release();   // :350-353
+        const int mono = run(image.data, image.rows, image.cols, (int)image.step, dense.ptr<float>(0), _keypoints, vLappingArea, &n_valid);
+        if (mono >= 0 && n_valid == 0) { _descriptors.release(); return mono; }   // :350-353
+        if (dense.data != desc.data) dense.copyTo(desc);
         return mono;
     }
 #else

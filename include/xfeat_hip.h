@@ -128,10 +128,11 @@ size_t xfh_record_desc_offset(int nfeatures);
 /* B dense frames [B][H][W] u8 in HOST memory -> B records in HOST memory: the batched form of operator()'s contract (host image
  * in, host keypoints / descriptors out, XFextractor.cc:250-356; SURVEY.md 8d "host-visible").  B is NOT limited by cfg.max_batch:
  * the call is cut into sub-batches of cfg.max_batch frames that rotate over up to xfh_pipeline_lanes (default 4) internal lanes
- * (own activations and HIP streams, shared weights, built at the first call that needs them), with the H2D copy of a sub-batch,
- * the kernels of others and the D2H copy of finished records overlapping on separate streams.  gray / records_out should be
- * pinned (xfh_host_alloc, or the caller's own buffers through xfh_host_register): pageable memory works, but the runtime then
- * stages every copy and the stages serialise.
+ * (own activations and ONE HIP stream each, shared weights, built at the first call that needs them).  Inside a lane the H2D copy of a
+ * sub-batch, its kernels and the D2H copy of its records follow each other in order on that one stream; the overlap comes from the lanes running
+ * side by side (one lane's copies on the DMA engines while other lanes' kernels own the CUs) -- a cross-stream event per sub-batch measured
+ * slower.  gray / records_out should be pinned (xfh_host_alloc, or the caller's own buffers through xfh_host_register): pageable
+ * memory works, but the runtime then stages every copy and the stages serialise.
  *   xfh_extract_batch_submit  returns when everything is queued; both buffers must stay untouched until the batch is complete.
  *                             Up to XFH_MAX_BATCHES_INFLIGHT submits may be outstanding (one more: XFH_ERR_INVALID_ARG); their
  *                             sub-batches simply queue up on the lanes, so a consumer that double-buffers records_out keeps
@@ -139,9 +140,12 @@ size_t xfh_record_desc_offset(int nfeatures);
  *   xfh_extract_batch_wait    the OLDEST outstanding submit is complete in its records_out (XFH_ERR_INVALID_ARG if none is)
  *   xfh_extract_batch_drain   every submit so far is complete
  *   xfh_extract_batch         = submit + drain.
- * These calls and the single-frame ring (xfh_extract_submit) share the ctx' first frame buffer: a batch call while a
- * single-frame submission is outstanding returns XFH_ERR_INVALID_ARG, and so does xfh_extract (it would collect the OLDER
- * submission's result). */
+ *                             A submit that FAILS has waited for whatever part of it was already queued: nothing of it is in flight when
+ *                             the error comes back, and the buffers are the caller's again.
+ * These calls and the single-frame ring (xfh_extract_submit) share the ctx' first frame buffer (lane 0 is the ctx itself): a batch call while a
+ * single-frame submission is outstanding returns XFH_ERR_INVALID_ARG, and so does xfh_extract (it would collect the OLDER submission's
+ * result).  The other direction needs no guard: xfh_extract_submit while batches are outstanding queues on the ctx' own stream BEHIND lane 0's
+ * sub-batches (same stream, in order), so the shared frame buffer is overwritten only after the kernels that read it. */
 #define XFH_MAX_BATCHES_INFLIGHT 8
 int xfh_extract_batch(xfh_ctx* ctx, const uint8_t* gray, int B, int H, int W, int lap_x0, int lap_x1,
                       void* records_out);

@@ -106,6 +106,26 @@ __global__ __launch_bounds__(512, 2) void k_yield(int nm, int nv, long long* out
     if (r == 123.456f) *sink = r;
 }
 
+// dependent accumulation chains: NCH independent accumulators per wave, WPS waves per SIMD (1 or 2): cycles per MFMA
+template <int NCH, int WPS>
+__global__ __launch_bounds__(512, 2) void k_chain(int nm, long long* out, float* sink) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (WPS == 1 && wave >= 4) return;
+    f32x16 acc[NCH];
+    for (int q = 0; q < NCH; ++q) for (int e = 0; e < 16; ++e) acc[q][e] = 0.f;
+    const float a = (float)lane * 1e-3f, b = 1.0f;
+    const long long t0 = clock64();
+    for (int it = 0; it < nm; it += NCH) {
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[q], 0, 0, 0);
+    }
+    float r = 0.f;
+    for (int q = 0; q < NCH; ++q) r += acc[q][0] + acc[q][15];
+    const long long t1 = clock64();
+    if (lane == 0) out[blockIdx.x * 8 + wave] = t1 - t0;
+    if (r == 123.456f) *sink = r;
+}
+
 int main() {
     long long* out; float* sink; CK(hipMalloc(&out, 256 * 8 * 8)); CK(hipMalloc(&sink, 4));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -154,6 +174,18 @@ int main() {
     shadow("two waves per SIMD: MFMA + 4 VALU", k_shadow<4, 1>, 1);
     shadow("two waves per SIMD: MFMA + 8 VALU", k_shadow<8, 1>, 1);
     shadow("two waves per SIMD: MFMA + 16 VALU", k_shadow<16, 1>, 1);
+    auto chain = [&](const char* name, auto kern, int wps) {
+        hipLaunchKernelGGL(kern, dim3(256), dim3(512), 0, 0, NM, out, sink); CK(hipDeviceSynchronize());
+        std::vector<long long> h(256 * 8); CK(hipMemcpy(h.data(), out, h.size() * 8, hipMemcpyDeviceToHost));
+        double m = 0; int n = 0, mx = 0;
+        for (int b = 0; b < 256; ++b) for (int w = 0; w < 4 * wps; ++w) { m += (double)h[b * 8 + w]; ++n; }
+        printf("%-58s %.2f ticks per MFMA of a wave\n", name, m / n / NM);
+    };
+    chain("1 wave per SIMD, 1 accumulator chain", k_chain<1, 1>, 1);
+    chain("1 wave per SIMD, 2 accumulator chains", k_chain<2, 1>, 1);
+    chain("1 wave per SIMD, 4 accumulator chains", k_chain<4, 1>, 1);
+    chain("2 waves per SIMD, 1 accumulator chain each", k_chain<1, 2>, 2);
+    chain("2 waves per SIMD, 2 accumulator chains each", k_chain<2, 2>, 2);
     auto yield = [&](const char* name, auto kern, int nv) {
         hipLaunchKernelGGL(kern, dim3(256), dim3(512), 0, 0, NM, nv, out, sink); CK(hipDeviceSynchronize());
         std::vector<long long> h(256 * 8); CK(hipMemcpy(h.data(), out, h.size() * 8, hipMemcpyDeviceToHost));

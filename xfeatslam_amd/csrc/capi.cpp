@@ -316,9 +316,7 @@ static std::vector<float> pack_mfma(const float* w, int cout, int cin, int ks, i
 }
 
 
-int xfh_load_weights(xfh_ctx* c, const void* blob, size_t nbytes) {
-    if (!c || !blob) return XFH_ERR_INVALID_ARG;
-    HIPCK(c, hipSetDevice(c->cfg.device));
+static int load_weights_impl(xfh_ctx* c, const void* blob, size_t nbytes) {
     BlobEntry e; char nm[80];
     for (int i = 0; i < XFH_NUM_LAYERS; ++i) {
         const LayerSpec& L = XFH_LAYERS[i];
@@ -403,8 +401,21 @@ int xfh_load_weights(xfh_ctx* c, const void* blob, size_t nbytes) {
     if ((rc = upload(c, &c->w.kp3_b, std::vector<float>(e.p, e.p + 65))) != XFH_OK) return rc;
     c->w.loaded = true;
     if (xfh_verbose()) fprintf(stderr, "[xfh] ctx %p: weights loaded (%zu bytes, bn_mode %d)\n", (void*)c, nbytes, c->cfg.bn_mode);
-    if (c->twin) { HIPCK(c, hipStreamSynchronize(c->twin->stream)); if ((rc = ctx_share_weights(c, c->twin)) != XFH_OK) return rc; }
-    return pipe_reshare_weights(c);
+    return XFH_OK;
+}
+int xfh_load_weights(xfh_ctx* c, const void* blob, size_t nbytes) {
+    if (!c || !blob) return XFH_ERR_INVALID_ARG;
+    HIPCK(c, hipSetDevice(c->cfg.device));
+    // A reload replaces the packed buffers one by one (upload() frees and reallocates), and the twin / the pipeline lanes hold COPIES of the
+    // pointers: until the reload has succeeded nobody has weights, and whatever happens the children get the parent's current state -- after a
+    // failed reload that is "not loaded" (xfh_extract* then return XFH_ERR_NO_WEIGHTS) instead of pointers into freed memory.
+    c->w.loaded = false;
+    if (c->twin) HIPCK(c, hipStreamSynchronize(c->twin->stream));
+    const int rc = load_weights_impl(c, blob, nbytes);
+    int rs = XFH_OK;
+    if (c->twin) rs = ctx_share_weights(c, c->twin);
+    const int rp = pipe_reshare_weights(c);
+    return rc != XFH_OK ? rc : (rs != XFH_OK ? rs : rp);
 }
 
 int xfh_load_weights_file(xfh_ctx* c, const char* path) {

@@ -488,6 +488,7 @@ __device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[NT], float* __
 #ifndef XFH_PD
 #define XFH_PD 3
 #endif
+
 // The body is a device function of (tile, frame) so that it can also run as a RIDER in another layer's launch (k_conv_mfma_ride below).
 // `a` is taken BY VALUE: through a `const ConvArgs&` the compiler no longer reads the kernel arguments with scalar loads -- the PRO_FUSE
 // instance went from 127 to 166 VGPRs (two workgroups per CU to one: 950 -> 1230 us at 256 frames).
@@ -949,6 +950,226 @@ void k_conv_mfma_p(ConvArgs a, int ntile, int total) {
 }
 
 // ------------------------------------------------------------------------------------
+// k_conv_mfma_t: persistent form of k_conv_mfma for the 3x3 layers whose weight matrix does NOT fit in LDS (the stride-2 layers and the >= 64-channel
+// 3x3 layers at large batches).  k_conv_mfma runs these with one or two workgroups per CU, and a workgroup is a strictly serial chain -- raw tile
+// from global memory (a round trip), statistics (another), activation + LDS, the first weight chunk (a third), K loop, epilogue: phase stamps
+// of the 64 -> 64 stride-2 layer show 7 of 23 us before the first MFMA, with nothing else resident on the CU to cover them.  Here a workgroup
+//   - walks over tiles  blockIdx.x, blockIdx.x + gridDim.x, ...  (frames x tiles) like k_conv_mfma_p,
+//   - issues the raw global loads of the NEXT tile (and its frame's statistics) before the K loop of the current one: registers hold them,
+//     BatchNorm + ReLU are applied when they move to LDS after the epilogue,
+//   - streams the weights as an ENDLESS cycle of chunks through the same two LDS buffers and PD register sets: every tile uses the same
+//     weights, so the last chunk iterations of a tile already bring in the first chunks of the next one and no tile starts with a weight wait.
+// Same tiles, same MFMAs in the same order, same statistics partials as k_conv_mfma: interchangeable bit for bit (test_batch_is_per_frame).
+template <int CIN, int COUT, int KS, int ST, int WM, int WN, int NT, int WW, int PRO, int EPI, int CBMAX = 64>
+__global__ __launch_bounds__(64 * WM * WN)
+void k_conv_mfma_t(ConvArgs a, int ntile, int total) {
+    static_assert(PRO == PRO_BN, "layers behind a finalised BatchNorm (large batches)");
+    constexpr int NTHR = 64 * WM * WN;
+    constexpr int WH = 32 / WW, TH = WM * WH, TW = WW;
+    constexpr int COUTP = WN * NT * 32;
+    constexpr int PAD = KS / 2;
+    constexpr int TIH = (TH - 1) * ST + KS, TIW = (TW - 1) * ST + KS;
+    constexpr int CP = CIN + 4;
+    constexpr int CB = CIN > CBMAX ? CBMAX : CIN;
+    constexpr int NCB = CIN / CB;
+    constexpr int NCHUNK = KS * KS * NCB;
+    static_assert(NCHUNK >= 3 && NCHUNK % 3 == 0, "the chunk ring (three LDS buffers, three register sets) closes on itself");
+    constexpr int WS = CB + 4;
+    constexpr int WCH = COUTP * CB;
+    constexpr int NWLD = (WCH / 4 + NTHR - 1) / NTHR;
+    constexpr int G = CIN / 8;
+    constexpr int NITEM = TIH * TIW * G;
+    constexpr int NE = NTHR / G * G;
+    constexpr int NIT = (NITEM + NE - 1) / NE;
+    constexpr int IN_FLOATS = TIH * TIW * CP;
+    constexpr int W_FLOATS = COUTP * WS;
+    static_assert(NIT <= 32, "inside mask");
+    constexpr int SPC = CB / 8;                                  // k steps of 8 per chunk
+    constexpr int GS = (NT == 1 && SPC % 2 == 0) ? 2 : 1;        // steps per operand group: at least 8 MFMAs
+    constexpr int GPC = SPC / GS, NGT = NCHUNK * GPC;            // groups per chunk / per tile
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_in = smem;
+    float* s_w = smem + IN_FLOATS;               // three buffers of W_FLOATS
+    double* s_red = (double*)(s_w + 3 * W_FLOATS);   // [WM][COUTP][2]
+
+    const int t = threadIdx.x;
+    const int g = t % G;                         // this thread's channel group in every item it stages
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63, i = lane & 31, h = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    const int pr = i / WW, pc = i % WW;
+    const int ly = (wm * WH + pr) * ST, lx = pc * ST;
+
+    int tile = blockIdx.x;
+    if (tile >= total) return;
+    // ---- the weight ring.  Chunk c of the endless sequence c = 0, 1, 2, ... is chunk c % NCHUNK of the layer; it lives in LDS buffer c % 3 while it is
+    // multiplied, and before that in register set c % 3.  While chunk c is multiplied, chunk c + 1 is already in LDS (written one chunk earlier, made
+    // visible by the barrier in between), chunk c + 2 moves from its registers to the buffer chunk c - 1 has just left, and that register set is refilled
+    // with chunk c + 5.  ONE barrier per chunk, at its start, and no wait behind it: the operands of a chunk's first group are read BEFORE the barrier.
+    f32x4 wreg[3][NWLD];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int q = 0; q < NWLD; ++q) {
+            const int f = t + q * NTHR;
+            if (f < WCH / 4) wreg[c][q] = *(const f32x4*)(a.w + (size_t)c * WCH + (size_t)f * 4);
+        }
+
+    f32x4 v0[NIT], v1[NIT], m0, m1, r0, r1;
+    unsigned inside = 0u;
+    auto load_tile = [&](int tl_) {               // global -> registers (raw values + the frame's statistics), clamped addresses, no branches
+        const int b = tl_ / ntile, tl = tl_ - b * ntile;
+        const int tx0 = (tl % a.tiles_x) * TW, ty0 = (tl / a.tiles_x) * TH;
+        const float* in = a.in + (size_t)b * a.in_stride + g * 8;
+        inside = 0u;
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int item = t + k * NE;
+            const int pix = (NITEM % NE != 0 && k == NIT - 1) ? min(item, NITEM - 1) / G : item / G;
+            const int gy = ty0 * ST - PAD + pix / TIW, gx = tx0 * ST - PAD + pix % TIW;
+            const int cy = min(max(gy, 0), a.Hin - 1), cx = min(max(gx, 0), a.Win - 1);
+            const float* p = in + ((size_t)cy * a.Win + cx) * CIN;
+            v0[k] = *(const f32x4*)p; v1[k] = *(const f32x4*)(p + 4);
+            inside |= (gy == cy && gx == cx) ? (1u << k) : 0u;
+        }
+        const float* st = a.st.stat + (size_t)b * 2 * CIN + g * 8;          // large batches: always finalised statistics
+        m0 = *(const f32x4*)st; m1 = *(const f32x4*)(st + 4); r0 = *(const f32x4*)(st + CIN); r1 = *(const f32x4*)(st + CIN + 4);
+    };
+    auto store_tile = [&]() {                     // registers -> activated, k-permuted LDS tile (zero padding outside the image)
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            const int item = t + k * NE;
+            if (t < NE && item < NITEM) {
+                f32x4 x0 = v0[k], x1 = v1[k];
+                const bool in_img = inside & (1u << k);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    x0[q] = fmaxf((x0[q] - m0[q]) * r0[q], 0.f);
+                    x1[q] = fmaxf((x1[q] - m1[q]) * r1[q], 0.f);
+                    x0[q] = in_img ? x0[q] : 0.f; x1[q] = in_img ? x1[q] : 0.f;
+                }
+                float* d = s_in + (item / G) * CP + g * 8;
+                *(f32x4*)d = f32x4{x0.x, x0.z, x1.x, x1.z};
+                *(f32x4*)(d + 4) = f32x4{x0.y, x0.w, x1.y, x1.w};
+            }
+        }
+    };
+    // ring position rc (compile time, any value with the right residues): its register set -> its LDS buffer; the set is refilled with position rc + 3
+    auto push_chunk = [&](int rc) {
+        float* wd = s_w + (rc % 3) * W_FLOATS;
+        const float* wsrc = a.w + (size_t)((rc + 3) % NCHUNK) * WCH;
+#pragma unroll
+        for (int q = 0; q < NWLD; ++q) {
+            const int f = t + q * NTHR;
+            if (f < WCH / 4) {
+                const int n = f / (CB / 4), c4 = f % (CB / 4);
+                *(f32x4*)(wd + n * WS + c4 * 4) = wreg[rc % 3][q];
+                wreg[rc % 3][q] = *(const f32x4*)(wsrc + (size_t)f * 4);
+            }
+        }
+    };
+
+    float biasv[NT];
+    conv_bias<COUT, NT, EPI>(a.bias, wn * NT * 32 + i, biasv);
+    load_tile(tile);
+    store_tile();
+    push_chunk(0);
+    push_chunk(1);
+    __syncthreads();                              // the first tile and the first two weight chunks are in LDS
+
+    f32x4 av[2][GS], bv[2][GS][NT];
+    auto load_group = [&](int q, int buf) {       // operands of group q of the tile (chunk q / GPC): A from the input tile, B from the chunk's buffer
+#pragma unroll
+        for (int u = 0; u < GS; ++u) {
+            const int ch = q / GPC, kk = (q % GPC) * GS + u;
+            const int tap = ch / NCB, cb = ch % NCB;
+            const int ky = tap / KS, kx = tap % KS;
+            av[buf][u] = *(const f32x4*)(s_in + ((ly + ky) * TIW + lx + kx) * CP + cb * CB + 4 * h + kk * 8);
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+                bv[buf][u][n] = *(const f32x4*)(s_w + (ch % 3) * W_FLOATS + (wn * NT * 32 + i + n * 32) * WS + 4 * h + kk * 8);
+        }
+    };
+    while (true) {
+        const int next = tile + gridDim.x;
+        const bool has_next = next < total;
+        f32x16 acc[NT];
+        auto mfma_part = [&](int buf, int part, bool first) {      // half of a group's MFMAs, k ascending per accumulator
+            if constexpr (GS == 2) {
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[buf][part][j], bv[buf][part][n][j], acc[n], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int j = 2 * part; j < 2 * part + 2; ++j)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[buf][0][j], bv[buf][0][n][j], acc[n], 0, 0, 0);
+            }
+        };
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[n][r] = 0.f;
+        load_group(0, 0);                         // (the barrier in front of this tile made the tile and chunks 0, 1 visible)
+        push_chunk(2);                            // into the buffer the previous tile's last chunk has left
+        if (has_next) load_tile(next);            // in flight during the K loop below
+#pragma unroll
+        for (int q = 0; q < NGT; ++q) {
+            const int cur = q & 1;
+            if (q > 0 && q % GPC == 0) {          // a chunk begins: every wave has left the previous chunk -> its buffer takes the chunk after next
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_s_barrier();
+                push_chunk(q / GPC + 2);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_part(cur, 0, q == 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (q + 1 < NGT) load_group(q + 1, cur ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_part(cur, 1, false);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+
+        // ---- epilogue of `tile` (C/D layout: channel (lane&31) of tile n, pixels (r&3) + 8*(r>>2) + 4*h)
+        const int b = tile / ntile, tl = tile - b * ntile;
+        const int tx0 = (tl % a.tiles_x) * TW, ty0 = (tl / a.tiles_x) * TH;
+        double sum[NT], sq[NT];
+        {
+            const int oy0 = ty0 + wm * WH;
+            float* wave_out = a.out + (size_t)b * a.out_stride + ((size_t)oy0 * a.Wout + tx0) * COUT;
+            conv_epilogue<COUT, NT, WW, WH, EPI>(acc, wave_out, a.Wout, a.Hout - oy0, a.Wout - tx0, wn * NT * 32 + i, h, biasv, sum, sq);
+        }
+        if constexpr (EPI == EPI_STATS) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                sum[n] += __shfl_xor(sum[n], 32);
+                sq[n] += __shfl_xor(sq[n], 32);
+                if (h == 0) {
+                    const int co = (wn * NT + n) * 32 + i;
+                    s_red[(wm * COUTP + co) * 2 + 0] = sum[n];
+                    s_red[(wm * COUTP + co) * 2 + 1] = sq[n];
+                }
+            }
+        }
+        __syncthreads();                          // every wave is done with s_in and with the tile's last chunk; s_red is complete
+        if constexpr (EPI == EPI_STATS) {
+            for (int co = t; co < COUT; co += NTHR) {
+                double S = 0.0, SS = 0.0;
+#pragma unroll
+                for (int m = 0; m < WM; ++m) { S += s_red[(m * COUTP + co) * 2 + 0]; SS += s_red[(m * COUTP + co) * 2 + 1]; }
+                double* p = a.part + (size_t)b * a.part_stride + ((size_t)tl * COUT + co) * 2;
+                p[0] = S; p[1] = SS;
+            }
+        }
+        if (!has_next) break;
+        store_tile();
+        __syncthreads();                          // the next tile is in LDS (and s_red has been read)
+        tile = next;
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // k_conv_mfma16: the SINGLE-FRAME form of the 3x3 stride-1 layers with >= 64 channels, on v_mfma_f32_16x16x4_f32.
 // One frame gives a layer 40-150 workgroups; with 32x32x2 tiles a wave then walks an accumulation chain of 288-576 dependent
 // MFMAs of 64 cycles each (7.7-15 us of pure chain per layer) on a mostly idle GPU.  The 16x16x4 instruction is the same exact
@@ -1348,6 +1569,35 @@ static hipError_t conv_mfma_launch(xfh_ctx* c, const ConvArgs& a, int B, int* np
     return hipGetLastError();
 }
 
+#ifndef XFH_CONV_T
+#define XFH_CONV_T 1       // bit mask (A/B builds): which layers take the persistent streamed-weights form k_conv_mfma_t at batches > 32 -- 1: block4.0 (64 -> 64 s2),
+                           // 2: block3.0 / block5.0 (24 -> 64 s2, 64 -> 128 s2), 4: block4.1/2, 8: block5.1/2, 16: block3.1 / block_fusion.1; 0: k_conv_mfma everywhere.
+                           // Measured per 256-frame launch on one box (tools/ab_serial.sh): block4.0 317 -> 274 us (113 KB of LDS: ONE 4-wave workgroup per CU, nothing
+                           // else covers its serial phases); every other layer runs 2 workgroups per CU, which already overlap each other's phases, and gets SLOWER
+                           // (24 -> 64 s2 443 -> 469, 64 -> 128 s2 149 -> 158, 64 -> 64 at 1/16 205 -> 209, 128 -> 128 232 -> 266, dominant 64 -> 64 790 -> 810)
+#endif
+template <int CIN, int COUT, int KS, int ST, int WM, int WN, int NT, int WW, int PRO, int EPI, int CBMAX = 64>
+static hipError_t conv_mfma_t_launch(xfh_ctx* c, const ConvArgs& a, int B, int* npart_out, int layer) {
+    constexpr int WH = 32 / WW, TH = WM * WH, TW = WW;
+    constexpr int COUTP = WN * NT * 32;
+    constexpr int TIH = (TH - 1) * ST + KS, TIW = (TW - 1) * ST + KS;
+    constexpr int CB = CIN > CBMAX ? CBMAX : CIN;
+    constexpr size_t LDS = sizeof(float) * ((size_t)TIH * TIW * (CIN + 4) + 3 * (size_t)COUTP * (CB + 4)) + sizeof(double) * WM * COUTP * 2;
+    static_assert(LDS <= 160 * 1024, "LDS budget");
+    ConvArgs aa = a;
+    aa.dbg = layer;
+    aa.tiles_x = (a.Wout + TW - 1) / TW;
+    const int ntile = aa.tiles_x * ((a.Hout + TH - 1) / TH);
+    if (npart_out) *npart_out = ntile;
+    auto kern = k_conv_mfma_t<CIN, COUT, KS, ST, WM, WN, NT, WW, PRO, EPI, CBMAX>;
+    XFH_SET_LDS_ATTR_ONCE(c, kern, LDS);
+    const int total = ntile * B;
+    const int per_cu = (int)((160 * 1024) / LDS) > 2 ? 2 : (int)((160 * 1024) / LDS);
+    const int grid = total < c->num_cu * per_cu ? total : c->num_cu * per_cu;
+    launch_k(c, XFH_K_CONV_MFMA, layer, kern, dim3(grid), dim3(64 * WM * WN), LDS, aa, ntile, total);
+    return hipGetLastError();
+}
+
 template <int CIN, int COUT, int ST, int GW, int PGY, int PRO, int EPI, int CGS = 1, int PD = 3>
 static hipError_t conv_mfma16_launch(xfh_ctx* c, const ConvArgs& a, int B, int* npart_out, int layer) {
     constexpr int GH = 16 / GW, TH = GH * PGY, TW = GW, NW = PGY * (COUT / 16 / CGS);
@@ -1495,6 +1745,7 @@ static hipError_t launch_basic_layer_t(xfh_ctx* c, int li, const float* in, size
             break;
         case 6:
             if (consumer_fold(B)) { a.w = c->w.alt[li]; e = conv_mfma_launch<24, 64, 3, 2, 4, 1, 2, 16, PRO_BN, EPI, 64, 3>(c, a, B, &np, li); }   // three taps per chunk: 3 weight round trips instead of 9
+            else if constexpr ((XFH_CONV_T & 2) != 0) { if (!small_batch(B)) e = conv_mfma_t_launch<24, 64, 3, 2, 4, 1, 2, 16, PRO_BN, EPI>(c, a, B, &np, li); else e = conv_mfma_launch<24, 64, 3, 2, 4, 1, 2, 16, PRO_BN, EPI>(c, a, B, &np, li); }
             else e = conv_mfma_launch<24, 64, 3, 2, 4, 1, 2, 16, PRO_BN, EPI>(c, a, B, &np, li);
             break;      // 8x16 pixels; 8x8 pixels (46 KB, three workgroups per CU) measured 526 -> 757 us at B = 256
         case 7: case 17: case 16:
@@ -1514,6 +1765,7 @@ static hipError_t launch_basic_layer_t(xfh_ctx* c, int li, const float* in, size
             } else {
                 a.w = c->w.alt[li];
                 if (li == 16) e = conv_mfma_launch<64, 64, 3, 1, 4, 2, 1, 16, PRO_FUSE, EPI, 32>(c, a, B, &np, li);
+                else if constexpr ((XFH_CONV_T & 16) != 0) e = conv_mfma_t_launch<64, 64, 3, 1, 4, 2, 1, 16, PRO_BN, EPI, 32>(c, a, B, &np, li);
                 else e = conv_mfma_launch<64, 64, 3, 1, 4, 2, 1, 16, PRO_BN, EPI, 32>(c, a, B, &np, li);
             }
             break;
@@ -1526,16 +1778,22 @@ static hipError_t launch_basic_layer_t(xfh_ctx* c, int li, const float* in, size
             // 32-channel chunks (60 KB, two workgroups per CU) 403 -> 558 us at B = 256 -- a workgroup streams the whole 147 KB weight
             // matrix from L2 for its tile, so halving the tile doubles that traffic; the small maps are bound by it
             if (small_batch(B)) { a.w = c->w.m16[li]; e = split_channels(Hout, Wout, 4, 8, B) ? conv_mfma16_launch<64, 64, 2, 8, 2, PRO_BN, EPI, 2>(c, a, B, &np, li) : conv_mfma16_launch<64, 64, 2, 8, 2, PRO_BN, EPI>(c, a, B, &np, li); }     // single frame: 4x8 pixels, 8 waves of 16 x 16
+            else if constexpr ((XFH_CONV_T & 1) != 0) e = conv_mfma_t_launch<64, 64, 3, 2, 2, 2, 1, 8, PRO_BN, EPI>(c, a, B, &np, li);   // persistent, next tile prefetched
             else e = conv_mfma_launch<64, 64, 3, 2, 2, 2, 1, 8, PRO_BN, EPI>(c, a, B, &np, li);
             break;
         case 10: case 11:
             if (small_batch(B)) { a.w = c->w.m16[li]; e = split_channels(Hout, Wout, 4, 8, B) ? conv_mfma16_launch<64, 64, 1, 8, 2, PRO_BN, EPI, 2>(c, a, B, &np, li) : conv_mfma16_launch<64, 64, 1, 8, 2, PRO_BN, EPI>(c, a, B, &np, li); }                    // 4x8 pixels, 8 waves of 16 x 16
+            else if constexpr ((XFH_CONV_T & 4) != 0) { a.w = c->w.alt[li]; e = conv_mfma_t_launch<64, 64, 3, 1, 4, 2, 1, 8, PRO_BN, EPI, 32>(c, a, B, &np, li); }
             else { a.w = c->w.alt[li]; e = conv_mfma_launch<64, 64, 3, 1, 4, 2, 1, 8, PRO_BN, EPI, 32>(c, a, B, &np, li); }   // 16x8 pixels, 8 waves, 32-channel chunks (67 KB): half the weight streaming per pixel of the 8x8 form
             break;
         case 12:
             if (small_batch(B)) { a.w = c->w.m16[li]; e = split_channels(Hout, Wout, 4, 4, B) ? conv_mfma16_launch<64, 128, 2, 4, 1, PRO_BN, EPI, 2>(c, a, B, &np, li) : conv_mfma16_launch<64, 128, 2, 4, 1, PRO_BN, EPI>(c, a, B, &np, li); break; }     // single frame: 4x4 pixels, 8 waves of 16 x 16
-            a.w = c->w.alt[li]; e = conv_mfma_launch<64, 128, 3, 2, 1, 4, 1, 8, PRO_BN, EPI, 32>(c, a, B, &np, li); break;      // 32-channel chunks: 111 -> 78 KB of LDS, two workgroups per CU (212 -> 168 us at B = 256)
+            a.w = c->w.alt[li];
+            if constexpr ((XFH_CONV_T & 2) != 0) e = conv_mfma_t_launch<64, 128, 3, 2, 1, 4, 1, 8, PRO_BN, EPI, 32>(c, a, B, &np, li);
+            else e = conv_mfma_launch<64, 128, 3, 2, 1, 4, 1, 8, PRO_BN, EPI, 32>(c, a, B, &np, li);
+            break;      // 32-channel chunks: 111 -> 78 KB of LDS, two workgroups per CU (212 -> 168 us at B = 256)
         case 13: case 14:       // 32-channel weight chunks: 69 KB LDS -> 2 workgroups per CU, 58 -> 50 us at B = 32
+            if constexpr ((XFH_CONV_T & 8) != 0) { if (!small_batch(B)) { a.w = c->w.alt[li]; e = conv_mfma_t_launch<128, 128, 3, 1, 4, 4, 1, 8, PRO_BN, EPI, 32>(c, a, B, &np, li); break; } }
             if (!small_batch(B)) { a.w = c->w.alt[li]; e = conv_mfma_launch<128, 128, 3, 1, 4, 4, 1, 8, PRO_BN, EPI, 32>(c, a, B, &np, li); }   // 16x8 pixels x 128 channels, 16 waves (132 KB): the 590 KB weight matrix is streamed once per 128 pixels
             else { a.w = c->w.m16[li]; e = split_channels(Hout, Wout, 4, 4, B) ? conv_mfma16_launch<128, 128, 1, 4, 1, PRO_BN, EPI, 2>(c, a, B, &np, li) : conv_mfma16_launch<128, 128, 1, 4, 1, PRO_BN, EPI>(c, a, B, &np, li); }                                   // 4x4 pixels, 8 waves of 16 x 16
             break;

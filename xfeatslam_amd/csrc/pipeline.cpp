@@ -115,6 +115,12 @@ int xfh_extract_batch_submit(xfh_ctx* c, const uint8_t* gray, int B, int H, int 
     const size_t rec = xfh_record_bytes(c->cfg.nfeatures), fb = (size_t)H * W;
     const int slot = (P.b_head + P.b_count) % XFH_PIPE_MAX_BATCHES;
     unsigned used = 0;
+    // a failure in the middle leaves earlier sub-batches queued (they will still copy into records_out): the lanes touched so far are waited for
+    // before the error is returned, so that a failed submit never leaves anything of this call in flight (xfh_extract_batch_wait could not cover it)
+    auto fail = [&](int code) {
+        for (int l = 0; l < nl; ++l) if (used >> l & 1) hipStreamSynchronize(P.lane[l].ctx->stream);
+        return code;
+    };
     for (int j = 0; j < nsub; ++j) {
         const int n = B - j * S < S ? B - j * S : S;
         const int li = nl == 1 ? 0 : (int)(P.next % (unsigned)nl);             // a call of one sub-batch always runs on the ctx itself
@@ -122,16 +128,18 @@ int xfh_extract_batch_submit(xfh_ctx* c, const uint8_t* gray, int B, int H, int 
         PipeLane& L = P.lane[li];
         xfh_ctx* lc = L.ctx;
         L.busy = true;
-        HIPCK(c, hipMemcpyAsync(lc->d_gray, gray + (size_t)j * S * fb, (size_t)n * fb, hipMemcpyHostToDevice, lc->stream));
+        used |= 1u << li;
+        hipError_t e = hipMemcpyAsync(lc->d_gray, gray + (size_t)j * S * fb, (size_t)n * fb, hipMemcpyHostToDevice, lc->stream);
+        if (e != hipSuccess) { c->hip_err = std::string("hipMemcpyAsync (frames): ") + hipGetErrorString(e); return fail(XFH_ERR_HIP); }
         {
             const int flags = lc->cfg.flags;
             if (nl > 1) lc->cfg.flags |= XFH_FLAG_SERIAL_BRANCH;            // lane 0 is the caller's ctx: same rule while it works as a lane
-            const hipError_t e = run_extract(lc, lc->d_gray, n, H, W, lap0, lap1, lc->d_records);
+            e = run_extract(lc, lc->d_gray, n, H, W, lap0, lap1, lc->d_records);
             lc->cfg.flags = flags;
-            if (e != hipSuccess) { c->hip_err = std::string("run_extract: ") + hipGetErrorString(e); return XFH_ERR_HIP; }
+            if (e != hipSuccess) { c->hip_err = std::string("run_extract: ") + hipGetErrorString(e); return fail(XFH_ERR_HIP); }
         }
-        HIPCK(c, hipMemcpyAsync((uint8_t*)records_out + (size_t)j * S * rec, lc->d_records, (size_t)n * rec, hipMemcpyDeviceToHost, lc->stream));
-        used |= 1u << li;
+        e = hipMemcpyAsync((uint8_t*)records_out + (size_t)j * S * rec, lc->d_records, (size_t)n * rec, hipMemcpyDeviceToHost, lc->stream);
+        if (e != hipSuccess) { c->hip_err = std::string("hipMemcpyAsync (records): ") + hipGetErrorString(e); return fail(XFH_ERR_HIP); }
     }
     // the batch is complete when the last download of every lane it touched is: one event per lane, waited for by the HOST
     for (int l = 0; l < nl; ++l) if (used >> l & 1) HIPCK(c, hipEventRecord(P.lane[l].done[slot], P.lane[l].ctx->stream));
