@@ -22,6 +22,7 @@ JSON line:
   configs3      BASELINE.json configs[3]: one 1280x720 frame per rank per step + the gather, all three gather forms (N > 1);
                 with one GPU the batch of 8 on that GPU
   gather_forms  (N > 1) the headline workload under the two gather forms that are not the default
+  extract_only  (N > 1) the headline workload without any exchange: extraction scaling apart from the gather
   single_frame  one frame per call, device resident (latency path)
   host_api      what the drop-in operator() really does: xfh_extract from host memory (H2D + kernels + record to host
                 inside the clock), synchronous latency and pipelined (2 frames in flight) throughput, nfeatures 4096 / 1000
@@ -199,13 +200,14 @@ def main():
         # S sub-batches of B frames, each on its own ctx / stream; the exchange of generation g runs on the ctx's
         # communication stream while the next step extracts into the other generation
         g = step_no[0] & 1 if use_comm else 0
-        if use_comm:
+        exchange = use_comm and form != "none"             # "none": the extraction alone on every rank (multi-rank leg `extract_only`)
+        if exchange:
             comm.fence(g)                                  # the collective that last read generation g has finished
             for c_ in ctxs[1:]:
                 comm.fence_ctx(c_, g)
         for k, c_ in enumerate(ctxs):
             capi.check(lib.xfh_extract_batch_device(c_.h, in_ptr + k * B * H * W, B, H, W, 0, 0, d_rec[g].ptr + k * B * rec_bytes), c_.h)
-        if use_comm:
+        if exchange:
             for c_ in ctxs[1:]:
                 comm.wait_ctx(c_)                          # the collective waits for every sub-batch, not only ctx 0's
             gather(form, d_rec[g].ptr, S * B, g)
@@ -366,6 +368,13 @@ def multi_rank_legs(args, lib, capi, synth, Context, xd, comm, ctx, blob, rank, 
         gf[form] = {"frames_per_s": N * frames_per_rank / dt, "ms_per_step": dt * 1e3, "steps": k2}
     gf["note"] = f"the timed region's workload ({frames_per_rank} VGA frames per GPU per step) with the other gather forms; `value` uses --gather {args.gather}"
     res["gather_forms"] = gf
+    # the same workload with NO exchange at all (every rank extracts, nobody gathers; barriers around the clock as everywhere): separates how the
+    # extraction scales with N (one process per GPU: it should not change) from what the gather of N x frames_per_rank records costs
+    comm.synchronize()
+    dt = timed(lambda: step("none"), k2)
+    comm.fence(0); comm.fence(1)
+    res["extract_only"] = {"frames_per_s": N * frames_per_rank / dt, "ms_per_step": dt * 1e3, "steps": k2,
+                           "note": "no gather: extraction on every rank, MAX over ranks of the step time; value / this = what the exchange costs at this N"}
     # ---- configs[3] ---------------------------------------------------------------------------------------------------
     ctx3 = Context(nfeatures=nf, max_height=C3_H, max_width=C3_W, max_batch=1, device=dev)
     ctx3.load_weights(blob)

@@ -100,10 +100,12 @@ def test_sharded_extract_and_gathers_world_n(gpu_lib, oracle_mod, tmp_path, worl
     ref.close()
 
 
-def test_bench_runs_with_two_ranks(gpu_lib, tmp_path):
-    """bench.py --gpus 2 exactly as the driver launches it (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment), both
-    ranks on GPU 0 over the librccl stand-in, small sizes: the multi-rank line carries the headline, the other two gather forms and
-    the configs[3] leg (one 1280x720 frame per rank + gather, all three forms)."""
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_runs_with_n_ranks(gpu_lib, tmp_path, world):
+    """bench.py --gpus N exactly as the driver launches it (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment), all ranks on
+    GPU 0 over the librccl stand-in, small sizes, N = 2 and N = 8 (the node the scaling run uses: its first real launch should be boring):
+    the multi-rank line carries the headline, the other two gather forms, the extraction alone (no exchange) and the configs[3] leg (one
+    1280x720 frame per rank + gather, all three forms)."""
     import json
     stub_dir = os.path.join(ROOT, "tests", "stubs")
     if not os.path.exists(os.path.join(stub_dir, "librccl.so.1")):
@@ -111,16 +113,16 @@ def test_bench_runs_with_two_ranks(gpu_lib, tmp_path):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
     procs = []
-    for r in range(2):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env["LD_LIBRARY_PATH"] = stub_dir + (":" + env["LD_LIBRARY_PATH"] if env.get("LD_LIBRARY_PATH") else "")
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "3", "--streams", "2",
-                                       "--height", "96", "--width", "128", "--cpu-frames", "0", "--match-iters", "5", "--host-steps", "3"],
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1", "--batch", "3", "--streams", "2",
+                                       "--height", "96", "--width", "128", "--cpu-frames", "0", "--match-iters", "5", "--match-pairs", "2", "--host-steps", "3"],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = []
     try:
         for p in procs:
-            outs.append(p.communicate(timeout=600))
+            outs.append(p.communicate(timeout=900))
     finally:
         for p in procs:
             if p.poll() is None:
@@ -128,10 +130,12 @@ def test_bench_runs_with_two_ranks(gpu_lib, tmp_path):
     for r, p in enumerate(procs):
         assert p.returncode == 0, f"rank {r}:\n{outs[r][1][-3000:] if r < len(outs) else ''}"
     line = json.loads(outs[0][0].strip().splitlines()[-1])
-    assert outs[1][0].strip() == ""                                                   # only rank 0 prints
-    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0 and line["config"]["frames_per_gpu_per_step"] == 6
+    assert all(outs[r][0].strip() == "" for r in range(1, world))                     # only rank 0 prints
+    assert line["n_gpus"] == world and line["scaling"] == "weak" and line["value"] > 0 and line["config"]["frames_per_gpu_per_step"] == 6
     assert set(line["gather_forms"]) >= {"root", "compact"} and all(line["gather_forms"][f]["frames_per_s"] > 0 for f in ("root", "compact"))
+    assert line["extract_only"]["frames_per_s"] > 0
     c3 = line["configs3"]
-    assert c3["n_ranks"] == 2 and set(c3["per_gather_form"]) == {"allgather", "root", "compact"}
+    assert c3["n_ranks"] == world and set(c3["per_gather_form"]) == {"allgather", "root", "compact"}
     assert all(v["frames_per_s"] > 0 and v["one_step_latency_ms"] > 0 for v in c3["per_gather_form"].values())
     assert line["roofline"]["frac"] > 0 and "in_timed_region" in line["roofline"] and line["host_visible"]["value"] > 0
+    assert line["match"]["batched"]["pair_lists_equal_pair_by_pair_calls"] is True
