@@ -297,6 +297,19 @@ def main():
                    "frames_per_gpu_per_step": B * S, "sub_batches_in_flight": S, "height": H, "width": W, "nfeatures": nf,
                    "weights": f"synthetic seed 1234, keypoint-logit gain {KP_GAIN}", "parallelism": f"frames x{N}"},
     }
+    # MFMA-busy of the dominant kernels from the builder's SQ-counter pass over a serial 64-frame step (tools/pmc_kernels.sh -> profiles/r04_pmc_kernels_B64.json)
+    PMC_BUSY_SRC = ("profiles/r04_pmc_kernels_B64.json: SQ_VALU_MFMA_BUSY_CYCLES (busy SIMD-cycles, calibrated on a pure MFMA loop) / (launch duration x 1024 SIMDs x 2.4 GHz) from the "
+                    "builder's rocprofv3 --pmc pass over a serial 64-frame step; a constant in this run, not an observation of it")
+    try:
+        _pmck = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_kernels_B64.json")))["kernels"]
+    except Exception:
+        _pmck = {}
+
+    def pmc_busy(prefix):
+        for k_, v_ in _pmck.items():
+            if k_.startswith(prefix) and v_.get("mfma_busy_pct") is not None:
+                return v_["mfma_busy_pct"] / 100.0
+        return None
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")     # written by tools/summarize_profiles.py from --pmc passes
     if os.path.exists(tpath):
@@ -325,9 +338,11 @@ def main():
     kname = ("k_conv_mfma<64,64,3,...>" if B > 32 else "k_conv_mfma16<64,64,1,16,2,...> (16x16x4 tiles, the form for batches <= 32)") + " (block3.1, block_fusion.1: 3x3 64->64 at 1/8 res)" + ("" if args.bn != "folded" else ", bias+ReLU epilogue")
     out["roofline"] = {"kernel": kname,
                        "measured": f"HIP events attached to every dispatch of the kernel (hipExtLaunchKernelGGL): the same launches ({B} frames each) with ONE ctx alone on the GPU "
-                                   "right after the timed region -- the kernel's own duration, the view rocprofv3 --kernel-trace gives of a serial run (profiles/r03_roofline_table.md)",
+                                   "right after the timed region -- the kernel's own duration, the view rocprofv3 --kernel-trace gives of a serial run (profiles/r04_roofline_table_B64.md: "
+                                   "`bench.py --streams 1 --batch 64 --serial-branch --only-match-leg` under rocprofv3, 191 us per launch on the box whose events read 192)",
                        "bound": "mfma", "achieved": iso_tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": iso_tf / PEAK_F32_MFMA_TFLOPS,
                        "traffic": conv_traffic, "traffic_source": pmc_src if conv_traffic else None,
+                       "mfma_busy": pmc_busy("k_conv_mfma<64, 64, 3, 1, 4, 2, 1, 16, 1, 0") if B > 32 else None, "mfma_busy_source": PMC_BUSY_SRC,
                        "avg_launch_us": iso_us, "launches": n_iso, "flops_per_launch": conv_flops(H, W) * B,
                        "in_timed_region": {"note": "the same events inside the timed region, all ctx" + (f": {S} sub-batches are in flight, a launch shares the CUs with the other ctx' kernels, so this "
                                                    "span is longer than the kernel's own speed (it measures neither the kernel nor the step)" if S > 1 else ""),
@@ -697,7 +712,7 @@ def legs(out, args, lib, capi, synth, Context, ctx, blob, frames, d_in, d_recb, 
                     "host_api_us_per_call": host_match_dt * 1e6,
                     "roofline": {"kernel": "k_mnn_gemm_img", "bound": "mfma", "achieved": gemm_tf, "peak": PEAK_F32_MFMA_TFLOPS,
                                  "unit": "TFLOP/s", "frac": gemm_tf / PEAK_F32_MFMA_TFLOPS,
-                                 "traffic": (traffic or {}).get("gemm_bytes_per_launch"), "avg_launch_us": gemm_us,
+                                 "traffic": (traffic or {}).get("gemm_bytes_per_launch"), "mfma_busy": pmc_busy("k_mnn_gemm_img"), "mfma_busy_source": PMC_BUSY_SRC, "avg_launch_us": gemm_us,
                                  "launches": n_gemm, "flops_per_launch": 2.0 * nf * nf * 64,
                                  "measured": "HIP events attached to every dispatch of the kernel inside the loop of two-launch calls on prepared images (the hand-off "
                                              "call; the view rocprofv3 --kernel-trace gives.  In a busy stream these timestamps overlap the neighbouring kernels: "
@@ -758,7 +773,8 @@ def legs(out, args, lib, capi, synth, Context, ctx, blob, frames, d_in, d_recb, 
                 "k_mnn_gemm_seg + k_mnn_post_batch, calls back to back from a C loop (xfh_bench_match_batch: wall time between two stream events / calls)",
         "pair_lists_equal_pair_by_pair_calls": bool(same),
         "roofline": {"kernel": "k_mnn_gemm_seg", "bound": "mfma", "achieved": seg_flop / (seg_us * 1e-6) / 1e12 if n_seg else 0.0, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                     "frac": seg_flop / (seg_us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS if n_seg else 0.0, "avg_launch_us": seg_us, "launches": n_seg, "flops_per_launch": seg_flop,
+                     "frac": seg_flop / (seg_us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS if n_seg else 0.0, "mfma_busy": pmc_busy("k_mnn_gemm_seg"), "mfma_busy_source": PMC_BUSY_SRC,
+                     "avg_launch_us": seg_us, "launches": n_seg, "flops_per_launch": seg_flop,
                      "measured": "HIP events attached to every dispatch of the kernel inside the loop of batched calls (the rocprofv3 --kernel-trace view)",
                      "steady_state": {"wall_us_per_launch": c_seg.value, "frac": seg_flop / (c_seg.value * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS,
                                       "measured": "xfh_bench_mnn_gemm_batch: 100 launches of the kernel alone back to back, wall time between two stream events / 100"}}}

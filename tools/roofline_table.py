@@ -12,8 +12,18 @@ Peaks: f32 MFMA 157.3 TFLOP/s, HBM 8 TB/s (/opt/skills/guides/MI355X_MICROARCH.m
 import collections, csv, glob, json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-f = glob.glob(os.path.join(ROOT, "gpurun_out", "prof_serial", "*kernel_trace.csv"))[0]
-cfg = json.loads(open(os.path.join(ROOT, "gpurun_out", "bench_prof_serial.json")).read().strip().splitlines()[-1])["config"]
+src = sys.argv[2] if len(sys.argv) > 2 else "prof_serial"          # gpurun_out/<src>/*kernel_trace.csv + gpurun_out/bench_<src>.json
+suffix = sys.argv[3] if len(sys.argv) > 3 else ""                  # e.g. "_B64": profiles/<tag>_roofline_table<suffix>.md
+f = glob.glob(os.path.join(ROOT, "gpurun_out", src, "*kernel_trace.csv"))[0]
+_line = json.loads(open(os.path.join(ROOT, "gpurun_out", "bench_" + src + ".json")).read().strip().splitlines()[-1])
+cfg = _line["config"]
+MATCH_PAIRS = (_line.get("match", {}).get("batched") or {}).get("pairs", 8)
+# per-kernel SQ counters of a serial step (tools/pmc_kernels.py writes profiles/<tag>_pmc_kernels.json): VALU instructions and MFMA-busy per launch
+PMC = {}
+try:
+    PMC = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_pmc_kernels{suffix}.json")))["kernels"]
+except Exception:
+    pass
 B, H, W = cfg["frames_per_gpu_per_step"] // cfg["sub_batches_in_flight"], cfg["height"] // 32 * 32, cfg["width"] // 32 * 32
 PEAK_TF, PEAK_TB = 157.3, 8.0
 # (cin, cout, k, stride) -> list of output sizes (h, w) of the layers that run on that instance
@@ -38,7 +48,7 @@ for n, d in agg.items():
     per_step = len(d) / steps if not any(k in n for k in MATCH) else 1
     flops = bytes_ = None; bound = "latency"
     m4 = re.match(r"void k_conv4_p<(\d+), (\d+), (\d+)", n)
-    m = re.match(r"void k_conv_(mfma_p|mfma|direct)<(\d+), (\d+), (\d+), (\d+)(?:, (\d+), (\d+), (\d+), (\d+))?", n)
+    m = re.match(r"void k_conv_(mfma_p|mfma_t|mfma|direct)<(\d+), (\d+), (\d+), (\d+)(?:, (\d+), (\d+), (\d+), (\d+))?", n)
     if m4:                                            # 4x4x1 MFMA form of the 3x3 layers with few output channels
         cin, cout, st = int(m4.group(1)), int(m4.group(2)), int(m4.group(3))
         ho, wo = L[(cin, cout, 3, st)]
@@ -64,45 +74,64 @@ for n, d in agg.items():
         if m.group(1) == "direct" and m.group(5) == "5":        # PRO_L0: block1.1 reads the 1-channel image and recomputes block1.0 (its 36 flops / pixel are counted here too)
             bytes_ = 4.0 * B * (H * W + ho * wo * cout)
             flops += 2.0 * H * W * 4 * 9 * B
-        bound = "mfma" if m.group(1) != "direct" and flops / bytes_ > PEAK_TF / PEAK_TB else "hbm"
+        # the direct convolutions (block1) move 1.05 - 1.25 x their algorithmic bytes (profiles/pmc_traffic.json) at 30 - 45 % of the HBM peak: they are
+        # bound by their per-pixel VALU work, not by traffic
+        bound = "mfma" if m.group(1) != "direct" and flops / bytes_ > PEAK_TF / PEAK_TB else ("valu" if m.group(1) == "direct" else "hbm")
+    elif "k_mnn_gemm_seg" in n:
+        flops, bytes_, bound = 2.0 * 4096 * 4096 * 64 * MATCH_PAIRS, (1 + MATCH_PAIRS) * 4096 * 256.0, "mfma"
     elif "k_mnn_gemm" in n:
         flops, bytes_, bound = 2.0 * 4096 * 4096 * 64, 2 * 4096 * 256.0, "mfma"
     elif "k_dist_mfma" in n:                         # 4096 x 4096 int32 distance table (DescriptorDistance of every pair): the 64 MB write bounds it
         flops, bytes_, bound = 2.0 * 4096 * 4096 * 64, 4096.0 * 4096 * 4 + 2 * 4096 * 256.0, "hbm"
     elif "k_best2_csr" in n: bytes_, bound = 4096.0 * 64 * (256 + 4) + 4096 * 256, "hbm"      # 64 gathered 256-byte rows per query (L2 resident table)
     elif "k_distinctive_csr" in n: bytes_, bound = 4096.0 * 16 * (256 + 4), "hbm"
-    elif "k_block1_stats" in n: bytes_, bound = 4.0 * B * H * W, "hbm"
+    elif "k_block1_stats" in n: bytes_, bound, flops = 4.0 * B * H * W, "valu", 2.0 * H * W * 4 * 9 * B
     elif "k_feat_norm" in n: bytes_, bound = 4.0 * B * (H // 8) * (W // 8) * 65, "hbm"
     elif "k_heads_kp" in n:
         bytes_, bound = 4.0 * B * (H // 8 * (W // 8) * 64 + H * W), "valu"
         flops = 2.0 * B * (H // 8) * (W // 8) * 65 * 64
-    elif "k_preproc" in n: bytes_, bound = B * H * W * 5.0, "hbm"
+    elif "k_preproc" in n: bytes_, bound = B * H * W * 5.0, "valu"
     elif "k_norm_aux" in n: bytes_, bound = B * H * W * (4 + 4 + 0.25), "hbm"
     elif "k_b2in" in n: bytes_, bound = 4.0 * B * (H // 4) * (W // 4) * 24 * 2, "hbm"
     elif "k_fuse_in" in n: bytes_, bound = 4.0 * B * 64 * ((H // 8) * (W // 8) * 2 + (H // 16) * (W // 16) + (H // 32) * (W // 32)), "hbm"
     elif "k_feats_norm" in n: bytes_, bound = 4.0 * B * (H // 8) * (W // 8) * 64 * 2, "hbm"
     elif "k_heads_heat" in n: bytes_, bound = 4.0 * B * (H // 8) * (W // 8) * 65, "hbm"
-    elif "k_nms_score" in n: bytes_, bound = 4.0 * B * H * W, "hbm"
+    elif "k_nms_score" in n: bytes_, bound = 4.0 * B * H * W, "valu"
     elif "k_desc" in n: bytes_, bound = B * 4096.0 * (4 * 256 + 284), "hbm"
     elif "k_rownorm" in n: bytes_, bound = 2 * 4096 * 256.0 * 2, "hbm"
     rows.append((us * per_step, n, len(d), per_step, us, flops, bytes_, bound))
 rows.sort(key=lambda r: -r[0])
 MATCH = ("k_mnn", "k_rownorm", "k_dist_mfma", "k_best2_csr", "k_distinctive_csr")
 tot = sum(r[0] for r in rows if not any(k in r[1] for k in MATCH))
-out = os.path.join(ROOT, "profiles", f"{tag}_roofline_table.md")
+out = os.path.join(ROOT, "profiles", f"{tag}_roofline_table{suffix}.md")
+SCLK = 2.4e9
+def pmc_of(n):
+    for k, v in PMC.items():
+        if n.startswith(k) or k.startswith(n[:len(k)]):
+            return v
+    return None
 with open(out, "w") as o:
     o.write(f"# Every kernel of one bench step against its bound (B = {B} frames of {H}x{W}, one ctx, one stream, 1 x MI355X)\n\n"
             f"Source: rocprofv3 --kernel-trace of `python bench.py --streams 1 --batch {B} --serial-branch` (all kernels serial on one stream; tools/gpu_round.sh), launches with the batched grid only; {steps} steps.  The matcher kernels (k_mnn_*, k_rownorm_img, k_dist_mfma, k_best2_csr, k_distinctive_csr) are the 4096 x 4096 legs of the same run.\n"
             f"`alg` = algorithmic flops / HBM bytes per launch (raw input map read once + raw output map written once; no halo, no weights);\n"
             f"achieved = alg / average duration; % of the bound's peak (f32 MFMA {PEAK_TF} TFLOP/s, HBM {PEAK_TB} TB/s).  `latency` = per-frame single\n"
-            f"workgroup or dependent-launch bound kernels (no meaningful roofline).  Extraction kernels sum to {tot:.0f} us per step = {tot / B:.1f} us per frame.\n\n"
-            "| kernel | launches/step | avg us | us/step | bound | alg GFLOP | alg MB | achieved | % of peak |\n|---|---|---|---|---|---|---|---|---|\n")
+            f"workgroup or dependent-launch bound kernels (no meaningful roofline).  Extraction kernels sum to {tot:.0f} us per step = {tot / B:.1f} us per frame.\n"
+            f"`valu` = kernels whose traffic is within 1.05 - 1.25 x of algorithmic while they sit far below the HBM peak: bound by their vector work; for them (and as a second\n"
+            f"figure for the MFMA kernels) `pipe` = share of the 1024 SIMDs' cycles the launch's plain VALU instructions (4 cycles each; SQ_INSTS_VALU minus the MFMAs it includes) and MFMAs (64 / 32 cycles) account for,\n"
+            f"from the SQ counters of a serial step (tools/pmc_kernels.sh; VALU and f32 MFMA share one pipe on gfx950, profiles/{tag}_pipe_probe.log) at 2.4 GHz; `mfma busy` = SQ_VALU_MFMA_BUSY_CYCLES (busy SIMD-cycles, calibrated on a pure MFMA loop) / (launch duration in the counter run x 1024 SIMDs x 2.4 GHz).\n\n"
+            "| kernel | launches/step | avg us | us/step | bound | alg GFLOP | alg MB | achieved | % of peak | pipe | mfma busy |\n|---|---|---|---|---|---|---|---|---|---|---|\n")
     for tot_us, n, cnt, per, us, fl, by, bound in rows:
         nm = re.sub(r"\(.*", "", n.replace("void ", ""))
         if bound == "mfma": ach, pct = f"{fl / us / 1e6:.1f} TFLOP/s", f"{fl / us / 1e6 / PEAK_TF * 100:.0f} %"
         elif bound == "hbm": ach, pct = f"{by / us / 1e6:.2f} TB/s", f"{by / us / 1e6 / PEAK_TB * 100:.0f} %"
-        elif bound == "valu": ach, pct = f"{fl / us / 1e6:.1f} TFLOP/s (VALU)", "-"
+        elif bound == "valu": ach, pct = (f"{by / us / 1e6:.2f} TB/s" if by else "-"), (f"{by / us / 1e6 / PEAK_TB * 100:.0f} % of HBM" if by else "-")
         else: ach, pct = "-", "-"
-        o.write(f"| `{nm}` | {per:.0f} | {us:.1f} | {tot_us:.1f} | {bound} | {fl / 1e9:.2f} | {by / 1e6:.1f} | {ach} | {pct} |\n" if fl and by else
-                f"| `{nm}` | {per:.0f} | {us:.1f} | {tot_us:.1f} | {bound} | {'-' if not fl else f'{fl / 1e9:.2f}'} | {'-' if not by else f'{by / 1e6:.1f}'} | {ach} | {pct} |\n")
+        pm = pmc_of(nm)
+        pipe = mb = "-"
+        if pm:
+            cyc = us * 1e-6 * SCLK * 1024.0
+            pipe = f"{100.0 * ((pm['valu_per_launch'] - pm['mfma_per_launch']) * 4.0 + pm['mfma_per_launch'] * pm.get('mfma_cycles', 64.0)) / cyc:.0f} %"      # SQ_INSTS_VALU counts the MFMAs too
+            mb = f"{pm['mfma_busy_pct']:.0f} %" if pm.get('mfma_busy_pct') is not None and pm['mfma_per_launch'] > 0 else "-"
+        o.write(f"| `{nm}` | {per:.0f} | {us:.1f} | {tot_us:.1f} | {bound} | {fl / 1e9:.2f} | {by / 1e6:.1f} | {ach} | {pct} | {pipe} | {mb} |\n" if fl and by else
+                f"| `{nm}` | {per:.0f} | {us:.1f} | {tot_us:.1f} | {bound} | {'-' if not fl else f'{fl / 1e9:.2f}'} | {'-' if not by else f'{by / 1e6:.1f}'} | {ach} | {pct} | {pipe} | {mb} |\n")
 print(open(out).read())
