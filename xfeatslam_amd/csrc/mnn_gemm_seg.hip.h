@@ -85,6 +85,7 @@ void k_mnn_gemm_seg(const MnnBatch jb) {
     const f32x16 Z16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
     f32x4 fa[4][2][2];                                // the wave's d1 strip: [quarter][group of 8][rt]
+    f32x4 fb[2][4];                                   // d2 operands of the current / next group of 8 k (loop carried: a tile's first group is read one phase early)
     f32x16 acc[2][4];
     float rkv = -__builtin_huge_valf(); unsigned rkg = 0u;   // running (value, d2 row group) of d1 row row_base + wr*64 + lane over this group's d2 rows
     int row_wfirst = 0;                               // first workgroup of the current d1 panel
@@ -181,7 +182,6 @@ void k_mnn_gemm_seg(const MnnBatch jb) {
         if (s > 0 && (cur.p != prev.p || cur.by != prev.by)) { flush_rows(prev); enter_row(cur); __builtin_amdgcn_s_waitcnt(0x0f70); }
         {
             const float* bq = smem + buf * MNN_PANEL_FLOATS;
-            f32x4 fb[2][4];
             auto load_group = [&](int g, int b) {                            // 4 ds_read_b128: group of 8 k (quarter g>>1, half g&1)
 #pragma unroll
                 for (int ct = 0; ct < 4; ++ct) fb[b][ct] = *(const f32x4*)(bq + offB[ct][g & 1] + (g >> 1) * 4096);
@@ -198,8 +198,8 @@ void k_mnn_gemm_seg(const MnnBatch jb) {
             // the operand reads of group g+1 sit in the MIDDLE of the MFMAs of group g: hipcc waits lgkmcnt(0), never a counted wait,
             // before the first MFMA that needs an operand, so reads issued right in front of that wait are exposed in full (and with
             // SKEW one wave per SIMD is alone in its K phase), while reads sunk behind the group's MFMAs are exposed as well
-            load_group(0, 0);
-            if (merge) { merge_load(); merge_store(prev_dst, prev_kb); }    // the accumulators are dead here: registers to spare; one LDS wait serves both
+            if (s == 0) load_group(0, 0);                                    // (later tiles: read at the end of the previous E phase, in front of the barrier)
+            if (merge) { merge_load(); merge_store(prev_dst, prev_kb); }    // the accumulators are dead here: registers to spare
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int g = 0; g < 8; ++g) {
@@ -213,9 +213,9 @@ void k_mnn_gemm_seg(const MnnBatch jb) {
             }
         }
         XFH_MFMA_SETTLE();                                                   // common.h: the epilogue branches
-        __builtin_amdgcn_s_waitcnt(0xc07f);                                  // lgkmcnt(0): this wave's operand reads are done
-        MNN_SEG_STAMP();
-        __builtin_amdgcn_s_barrier();                                        // ---- end of the K phase: buffer `buf` is dead
+        __builtin_amdgcn_s_waitcnt(0x0070);                                  // lgkmcnt(0): this wave's operand reads are done; vmcnt(0): its pieces of the next panel
+        MNN_SEG_STAMP();                                                     // (issued a whole K phase ago) have landed, so that behind this barrier the next panel is
+        __builtin_amdgcn_s_barrier();                                        // readable by every wave.  ---- end of the K phase: buffer `buf` is dead
         MNN_SEG_STAMP();
         // ================= E phase of tile s.  acc[rt][ct][r] = < d1 row R0 + rt*16 + r , d2 row C0 + ct >
         // scalar work for the phases ahead: where this tile's d2-row keys go (M, next K phase), the tile after next and its panel
@@ -304,7 +304,12 @@ void k_mnn_gemm_seg(const MnnBatch jb) {
                 rkv = better ? M : rkv;
             }
         }
-        __builtin_amdgcn_s_waitcnt(0x0070);                                  // vmcnt(0): this wave's pieces of the next panel have landed; lgkmcnt(0)
+        __builtin_amdgcn_s_waitcnt(0x0070);                                  // this wave's LDS writes (column values) are done
+        if (s + 1 < NS) {                                                    // the next K phase's first operands, read in front of the barrier this phase ends with (the wait
+            const float* bq = smem + (buf ^ 1) * MNN_PANEL_FLOATS;           // for them then overlaps the wait for the other waves): the next panel is complete since the K-end barrier
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) fb[0][ct] = *(const f32x4*)(bq + offB[ct][0]);
+        }
         MNN_SEG_STAMP();
         __builtin_amdgcn_s_barrier();                                        // ---- end of the E phase
         prev = cur; cur = nxt; nxt = nn; nxt_src = nn_src;
