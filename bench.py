@@ -49,6 +49,21 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, dense f32 MFMA
+
+# MFMA-busy of the dominant kernels from the builder's SQ-counter pass over a serial 64-frame step (tools/pmc_kernels.sh -> profiles/r04_pmc_kernels_B64.json)
+PMC_BUSY_SRC = ("profiles/r04_pmc_kernels_B64.json: SQ_VALU_MFMA_BUSY_CYCLES (busy SIMD-cycles, calibrated on a pure MFMA loop) / (launch duration x 1024 SIMDs x 2.4 GHz) from the "
+                "builder's rocprofv3 --pmc pass over a serial 64-frame step; a constant in this run, not an observation of it")
+try:
+    _pmck = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_kernels_B64.json")))["kernels"]
+except Exception:
+    _pmck = {}
+
+def pmc_busy(prefix):
+    for k_, v_ in _pmck.items():
+        if k_.startswith(prefix) and v_.get("mfma_busy_pct") is not None:
+            return v_["mfma_busy_pct"] / 100.0
+    return None
+
 NFEATURES = 4096
 KP_GAIN = 6.0                     # "dense" synthetic weights: > 4096 NMS candidates at VGA
 DOMINANT_LAYERS = (7, 17)         # k_conv_mfma<64,64,3,1,4,2,1,16,PRO_BN,EPI_STATS,32>: block3.1, block_fusion.1
@@ -118,7 +133,7 @@ def main():
                          "compact = header + valid rows to rank 0")
     ap.add_argument("--force-comm", action="store_true", help="run the RCCL exchange also with one rank")
     ap.add_argument("--no-legs", action="store_true", help="timed region only (no host_visible / configs3 / host_api / match / aux / cpu legs)")
-    ap.add_argument("--host-steps", type=int, default=12, help="steps of the host-visible leg (each: the same frames per GPU as a timed step)")
+    ap.add_argument("--host-steps", type=int, default=24, help="steps of the host-visible leg (each: the same frames per GPU as a timed step)")
     ap.add_argument("--libtorch-leg", type=str, default="", help=argparse.SUPPRESS)        # child process of the cpu_baseline leg: "threads,threads,..."
     ap.add_argument("--only-match-leg", action="store_true", help="of the extra legs run the matcher ones only (short traces for the PMC passes)")
     ap.add_argument("--no-bn-leg", action="store_true", help="skip the eval()-BatchNorm legs (their kernels share names with the headline's in a kernel trace)")
@@ -297,19 +312,6 @@ def main():
                    "frames_per_gpu_per_step": B * S, "sub_batches_in_flight": S, "height": H, "width": W, "nfeatures": nf,
                    "weights": f"synthetic seed 1234, keypoint-logit gain {KP_GAIN}", "parallelism": f"frames x{N}"},
     }
-    # MFMA-busy of the dominant kernels from the builder's SQ-counter pass over a serial 64-frame step (tools/pmc_kernels.sh -> profiles/r04_pmc_kernels_B64.json)
-    PMC_BUSY_SRC = ("profiles/r04_pmc_kernels_B64.json: SQ_VALU_MFMA_BUSY_CYCLES (busy SIMD-cycles, calibrated on a pure MFMA loop) / (launch duration x 1024 SIMDs x 2.4 GHz) from the "
-                    "builder's rocprofv3 --pmc pass over a serial 64-frame step; a constant in this run, not an observation of it")
-    try:
-        _pmck = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_kernels_B64.json")))["kernels"]
-    except Exception:
-        _pmck = {}
-
-    def pmc_busy(prefix):
-        for k_, v_ in _pmck.items():
-            if k_.startswith(prefix) and v_.get("mfma_busy_pct") is not None:
-                return v_["mfma_busy_pct"] / 100.0
-        return None
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")     # written by tools/summarize_profiles.py from --pmc passes
     if os.path.exists(tpath):
@@ -480,12 +482,12 @@ def legs(out, args, lib, capi, synth, Context, ctx, blob, frames, d_in, d_recb, 
     ctx.synchronize()
 
     # ---- SURVEY.md 8d read literally: host-visible.  The step's frames from pinned host memory to records in pinned host memory
-    # through the batch pipeline (csrc/pipeline.cpp: sub-batches of B frames over 4 in-order lanes), PCIe inside the clock
+    # through the batch pipeline (csrc/pipeline.cpp: sub-batches of B frames drained by host-driven lanes), PCIe inside the clock
     if not args.only_match_leg:
         S = max(1, args.streams)
         nfr = S * B
         hin = capi.HostBuffer(nfr * H * W); hin.array[:] = frames.reshape(-1)[:nfr * H * W]
-        houts = [capi.HostBuffer(nfr * rec_bytes) for _ in range(2)]
+        houts = [capi.HostBuffer(nfr * rec_bytes) for _ in range(3)]
         hk = max(3, args.host_steps)
         for _ in range(3):
             capi.check(lib.xfh_extract_batch(ctx.h, hin.ptr, nfr, H, W, 0, 0, houts[0].ptr), ctx.h)
@@ -494,21 +496,26 @@ def legs(out, args, lib, capi, synth, Context, ctx, blob, frames, d_in, d_recb, 
             capi.check(lib.xfh_extract_batch(ctx.h, hin.ptr, nfr, H, W, 0, 0, houts[0].ptr), ctx.h)
         blocking_dt = (time.perf_counter() - t1) / hk
         t1 = time.perf_counter()
+        # a streaming consumer: three record buffers in rotation, two steps submitted ahead of the one it waits for (submit(t + 2); wait() -> step t is
+        # complete in houts[t % 3]), so that every lane always has its next sub-batch queued behind the one whose records are on their way out
         capi.check(lib.xfh_extract_batch_submit(ctx.h, hin.ptr, nfr, H, W, 0, 0, houts[0].ptr), ctx.h)
-        for t in range(1, hk):
-            capi.check(lib.xfh_extract_batch_submit(ctx.h, hin.ptr, nfr, H, W, 0, 0, houts[t & 1].ptr), ctx.h)
-            capi.check(lib.xfh_extract_batch_wait(ctx.h), ctx.h)           # step t - 1 is complete in houts[(t - 1) & 1]: the consumer's turn
-        capi.check(lib.xfh_extract_batch_wait(ctx.h), ctx.h)
+        if hk > 1:
+            capi.check(lib.xfh_extract_batch_submit(ctx.h, hin.ptr, nfr, H, W, 0, 0, houts[1].ptr), ctx.h)
+        for t in range(2, hk):
+            capi.check(lib.xfh_extract_batch_submit(ctx.h, hin.ptr, nfr, H, W, 0, 0, houts[t % 3].ptr), ctx.h)
+            capi.check(lib.xfh_extract_batch_wait(ctx.h), ctx.h)           # step t - 2 is complete in houts[(t - 2) % 3]: the consumer's turn
+        for _ in range(min(hk, 2)):
+            capi.check(lib.xfh_extract_batch_wait(ctx.h), ctx.h)
         piped_dt = (time.perf_counter() - t1) / hk
-        got = ctx.parse_records(np.array(houts[(hk - 1) & 1].array[:2 * rec_bytes]), 2)
+        got = ctx.parse_records(np.array(houts[(hk - 1) % 3].array[:2 * rec_bytes]), 2)
         dev_recs = ctx.parse_records(d_recb.download(np.uint8, rec_bytes * 2), 2) if B > 1 else None
         same = None if dev_recs is None else bool(all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2:4] == b[2:4] for a, b in zip(got, dev_recs)))
         out_b, in_b = nfr * rec_bytes, nfr * H * W
         out["host_visible"] = {
             "value": nfr / piped_dt, "unit": "frames/s",
             "workload": f"SURVEY.md 8d metric read literally (host-visible): {nfr} distinct {H}x{W} u8 frames per step from pinned HOST memory -> {nfr} padded {nf}-row records "
-                        f"(keypoints + descriptors, {rec_bytes} B each) in pinned HOST memory through xfh_extract_batch_submit / _wait: sub-batches of {B} frames over 4 in-order "
-                        "lanes (H2D, kernels, D2H per lane), the consumer double-buffers the records (submit(t + 1); wait() -> step t); PCIe both ways inside the clock",
+                        f"(keypoints + descriptors, {rec_bytes} B each) in pinned HOST memory through xfh_extract_batch_submit / _wait: sub-batches of {B} frames drained by 6 host-driven "
+                        "lanes (a worker thread per lane: copy in, kernels, copy out), the consumer rotates three record buffers (submit(t + 2); wait() -> step t); PCIe both ways inside the clock, pipeline fill and drain included",
             "ms_per_step": piped_dt * 1e3, "steps": hk, "frames_per_step": nfr,
             "blocking": {"value": nfr / blocking_dt, "ms_per_step": blocking_dt * 1e3, "note": "xfh_extract_batch per step (submit + drain): the last sub-batches' downloads are exposed"},
             "pcie": {"bytes_out_per_frame": rec_bytes, "bytes_in_per_frame": H * W, "out_GBps": out_b / piped_dt / 1e9, "in_GBps": in_b / piped_dt / 1e9,
@@ -580,6 +587,19 @@ def legs(out, args, lib, capi, synth, Context, ctx, blob, frames, d_in, d_recb, 
                         "roofline_isolated": {"kernel": "same 3x3 64->64 launches as the headline" + (", bias+ReLU epilogue, no statistics" if name == "folded" else ""),
                                               "bound": "mfma", "achieved": tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_F32_MFMA_TFLOPS,
                                               "avg_launch_us": us, "launches": n_c}}
+            # the latency path in this mode: one frame per call on a single-frame ctx, back to back, device resident (as `single_frame` of the default mode)
+            f1 = Context(nfeatures=nf, max_height=H, max_width=W, max_batch=1, device=ctx.device, bn_mode=BN_MODES[name])
+            f1.load_weights(blob)
+            for _ in range(20):
+                capi.check(lib.xfh_extract_batch_device(f1.h, in_ptr, 1, H, W, 0, 0, d_r.ptr), f1.h)
+            f1.synchronize()
+            n1 = 200
+            t1 = time.perf_counter()
+            for _ in range(n1):
+                capi.check(lib.xfh_extract_batch_device(f1.h, in_ptr, 1, H, W, 0, 0, d_r.ptr), f1.h)
+            f1.synchronize()
+            bn[name]["single_frame"] = {"ms_per_frame": (time.perf_counter() - t1) / n1 * 1e3, "frames_per_s": n1 / (time.perf_counter() - t1)}
+            f1.close()
             for fc in fcs:
                 fc.close()
             d_r.free()

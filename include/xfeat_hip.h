@@ -127,11 +127,12 @@ size_t xfh_record_desc_offset(int nfeatures);
 
 /* B dense frames [B][H][W] u8 in HOST memory -> B records in HOST memory: the batched form of operator()'s contract (host image
  * in, host keypoints / descriptors out, XFextractor.cc:250-356; SURVEY.md 8d "host-visible").  B is NOT limited by cfg.max_batch:
- * the call is cut into sub-batches of cfg.max_batch frames that rotate over up to xfh_pipeline_lanes (default 4) internal lanes
- * (own activations and ONE HIP stream each, shared weights, built at the first call that needs them).  Inside a lane the H2D copy of a
- * sub-batch, its kernels and the D2H copy of its records follow each other in order on that one stream; the overlap comes from the lanes running
- * side by side (one lane's copies on the DMA engines while other lanes' kernels own the CUs) -- a cross-stream event per sub-batch measured
- * slower.  gray / records_out should be pinned (xfh_host_alloc, or the caller's own buffers through xfh_host_register): pageable
+ * the call is cut into sub-batches of cfg.max_batch frames.  One sub-batch (B <= cfg.max_batch) runs on the ctx itself, in order on its stream.
+ * More go into one queue that up to xfh_pipeline_lanes (default 6) internal lanes drain: a lane = a child ctx (own activations and HIP streams,
+ * the ctx' weights, built at the first call that needs it) + a copy stream + a host THREAD of the library that drives one sub-batch at a time --
+ * copy in, kernels, copy out, each waited for on the host -- so that no copy command ever sits in a stream in front of a kernel and no stream
+ * waits for another on the GPU; the lanes overlap each other (0.93-0.95 of the device-resident rate, 0.74-0.85 with in-order streams).
+ * gray / records_out should be pinned (xfh_host_alloc, or the caller's own buffers through xfh_host_register): pageable
  * memory works, but the runtime then stages every copy and the stages serialise.
  *   xfh_extract_batch_submit  returns when everything is queued; both buffers must stay untouched until the batch is complete.
  *                             Up to XFH_MAX_BATCHES_INFLIGHT submits may be outstanding (one more: XFH_ERR_INVALID_ARG); their
@@ -142,10 +143,11 @@ size_t xfh_record_desc_offset(int nfeatures);
  *   xfh_extract_batch         = submit + drain.
  *                             A submit that FAILS has waited for whatever part of it was already queued: nothing of it is in flight when
  *                             the error comes back, and the buffers are the caller's again.
- * These calls and the single-frame ring (xfh_extract_submit) share the ctx' first frame buffer (lane 0 is the ctx itself): a batch call while a
- * single-frame submission is outstanding returns XFH_ERR_INVALID_ARG, and so does xfh_extract (it would collect the OLDER submission's
- * result).  The other direction needs no guard: xfh_extract_submit while batches are outstanding queues on the ctx' own stream BEHIND lane 0's
- * sub-batches (same stream, in order), so the shared frame buffer is overwritten only after the kernels that read it. */
+ * These calls and the single-frame ring (xfh_extract_submit) share the ctx' first frame buffer (a one-sub-batch submit runs on the ctx itself): a
+ * batch call while a single-frame submission is outstanding returns XFH_ERR_INVALID_ARG, and so does xfh_extract (it would collect the OLDER
+ * submission's result).  The other direction needs no guard: xfh_extract_submit while batches are outstanding queues on the ctx' own stream BEHIND a
+ * one-sub-batch submit (same stream, in order), and the lanes of larger submits have buffers of their own.  The ctx stays single-caller: the worker
+ * threads touch the lanes only, never the ctx' own buffers or streams. */
 #define XFH_MAX_BATCHES_INFLIGHT 8
 int xfh_extract_batch(xfh_ctx* ctx, const uint8_t* gray, int B, int H, int W, int lap_x0, int lap_x1,
                       void* records_out);
@@ -153,7 +155,7 @@ int xfh_extract_batch_submit(xfh_ctx* ctx, const uint8_t* gray, int B, int H, in
                              void* records_out);
 int xfh_extract_batch_wait(xfh_ctx* ctx);
 int xfh_extract_batch_drain(xfh_ctx* ctx);
-int xfh_pipeline_lanes(xfh_ctx* ctx, int lanes);      /* 1 .. 8; sub-batches in flight side by side */
+int xfh_pipeline_lanes(xfh_ctx* ctx, int lanes);      /* 1 .. 8 (default 6); sub-batches in flight side by side, one worker thread each */
 /* pinned host memory for the calls above (hipHostMalloc / hipHostRegister behind the ABI, for host languages without a HIP binding) */
 int xfh_host_alloc(void** p, size_t nbytes);
 int xfh_host_free(void* p);

@@ -819,7 +819,7 @@ int xfh_synchronize(xfh_ctx* c) {
     if (!c) return XFH_ERR_INVALID_ARG;
     HIPCK(c, hipStreamSynchronize(c->stream));
     if (c->twin) HIPCK(c, hipStreamSynchronize(c->twin->stream));
-    for (int l = 1; l < c->pipe.nlanes; ++l) HIPCK(c, hipStreamSynchronize(c->pipe.lane[l].ctx->stream));
+    // (the batch pipeline's lanes are driven by their worker threads: xfh_extract_batch_wait / _drain are the calls that wait for them)
     return XFH_OK;
 }
 int xfh_set_stream(xfh_ctx* c, void* s) {

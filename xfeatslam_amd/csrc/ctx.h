@@ -25,23 +25,25 @@ struct XfhComm;
 struct xfh_ctx;
 
 // xfh_extract_batch / _submit / _wait (host-visible frames in, host-visible records out; pipeline.cpp).  A call of
-// B frames is cut into sub-batches of cfg.max_batch frames that rotate over up to XFH_PIPE_MAX_LANES lanes.  A lane = one ctx
-// (lane 0: the ctx itself, the others: children with their own activations and streams that borrow its weights) whose ONE
-// stream carries, in order, the H2D copy of a sub-batch, its kernels and the D2H copy of its records; the lanes overlap
-// each other (one lane's copies run on the SDMA engines while other lanes' kernels own the CUs).  No cross-stream event
-// anywhere: pipeline.cpp explains why.
+// B frames is cut into sub-batches of cfg.max_batch frames.  One sub-batch: on the ctx itself, in order on its stream (H2D, kernels, D2H, an event).
+// More: the sub-batches go into ONE queue that up to XFH_PIPE_MAX_LANES worker lanes drain.  A lane = a child ctx (own activations and streams,
+// the parent's weights) + a copy stream + a host thread that drives, per sub-batch, copy in -> wait -> kernels -> wait -> copy out -> wait: no copy
+// command ever sits in a stream in front of a kernel and there is no GPU-side event wait anywhere; the lanes overlap each other.  pipeline.cpp says why.
 #define XFH_PIPE_MAX_LANES 8
 #define XFH_PIPE_MAX_BATCHES 8                   // xfh_extract_batch_submit calls outstanding (include/xfeat_hip.h: XFH_MAX_BATCHES_INFLIGHT)
+struct PipeShared;                               // queue, mutex, condition variables, per-slot counters (pipeline.cpp)
 struct PipeLane {
-    xfh_ctx* ctx = nullptr;
-    hipEvent_t done[XFH_PIPE_MAX_BATCHES] = {};  // done[k]: this lane's last download of outstanding batch slot k has finished
-    bool busy = false;                           // something was queued since the last drain
+    xfh_ctx* ctx = nullptr;                      // child ctx of the lane
+    hipStream_t copy = nullptr;                  // its copy stream (both directions)
+    void* thread = nullptr;                      // std::thread*
 };
 struct Pipe {
-    int nlanes = 0, max_lanes = 4;
+    int nlanes = 0, max_lanes = 6;               // 512 VGA frames per step on one box: 26.6 k frames/s with 4 lanes, 29.3 k with 6, 29.2 k with 8 (profiles/r04_host_batch_probe.log)
     PipeLane lane[XFH_PIPE_MAX_LANES];
-    unsigned long long next = 0;                 // sub-batches submitted so far
-    unsigned lanes_of[XFH_PIPE_MAX_BATCHES] = {};   // bit l: lane l carries a part of outstanding batch slot k
+    PipeShared* sh = nullptr;
+    hipEvent_t inline_done[XFH_PIPE_MAX_BATCHES] = {};   // one-sub-batch submits run on the ctx itself: their last download
+    bool slot_inline[XFH_PIPE_MAX_BATCHES] = {};
+    bool inline_busy = false;
     int b_head = 0, b_count = 0;                 // ring of outstanding submits, oldest first
 };
 

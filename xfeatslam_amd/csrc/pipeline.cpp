@@ -7,44 +7,120 @@
 //   xfh_extract_batch_drain    everything submitted so far has
 //   xfh_extract_batch          submit + drain
 //
-// A call is cut into sub-batches of cfg.max_batch frames which rotate over the lanes of the ctx (ctx.h: PipeLane).  Per
-// sub-batch, IN ORDER ON THE LANE'S ONE STREAM: the H2D copy of its frames (SDMA), the kernels, the D2H copy of the padded
-// records (SDMA).  Overlap comes from the lanes: while one lane's stream sits in a copy, the kernels of the others own the
-// CUs; PCIe carries 0.31 MB in + 1.16 MB out per VGA frame at nfeatures 4096.  The host never waits before
-// xfh_extract_batch_wait, and there is NO cross-stream event:
+// A call is cut into sub-batches of cfg.max_batch frames.  PCIe carries 0.31 MB in + 1.16 MB out per VGA frame at nfeatures 4096 against 33 us of
+// kernels: everything depends on the copies of one sub-batch running beside the kernels of others, and on nothing else getting in the way.
 //
-// the classic three-stream form (upload stream | kernel stream | download stream, two buffer generations, events between them)
-// was built first and traced (rocprofv3 --kernel-trace --memory-copy-trace, profiles/r03_host_pipeline.md): the kernels of
-// sub-batch t+1 did not start before the DOWNLOAD of sub-batch t had finished although nothing orders them.  The runtime
-// multiplexes all HIP streams of a process onto four hardware queues; an event wait is a barrier packet in the waiting stream's
-// queue, and a barrier packet that waits for a millisecond-long SDMA copy stalls every other stream that happens to share
-// that queue -- 15-16 k frames/s whatever the shape, the same as doing the three stages one after the other.  (Kernels that
-// read / write the caller's pinned memory themselves, no copy commands at all, were measured too: 15-16 k, k_desc then stalls on
-// PCIe writes while it occupies the CUs.)  With in-order lanes a copy can only ever delay its own lane.
-// The caller's buffers should be pinned (xfh_host_alloc / xfh_host_register): with pageable memory the HIP runtime stages
-// every copy through its own bounce buffers and blocks the calling thread -- still correct, much slower.
+// Three designs were built and traced before this one (profiles/r03_host_pipeline.md, profiles/r04_host_batch_probe.log):
+//  (1) upload stream | kernel stream | download stream per lane, events between them: the kernels of sub-batch t+1 did not start before the DOWNLOAD of
+//      sub-batch t had finished although nothing orders them.  The runtime multiplexes all HIP streams of a process onto four hardware queues; an event
+//      wait is a barrier packet in the waiting stream's queue, and a barrier that waits for a millisecond-long copy stalls every stream that shares
+//      the queue: 15-21 k frames/s.  (2) kernels that read / write the caller's pinned memory themselves: 14-17 k (k_desc stalls on PCIe writes while
+//      it occupies the CUs).  (3) round 3: in-order lanes -- a lane's H2D, kernels and D2H on ONE stream, four lanes side by side, no cross-stream
+//      event: 22-26 k by box and by step size.  Its flaw: a lane's next kernels sit BEHIND its own download in the stream, and lanes that started
+//      together stay in phase -- all four compute, then all four copy (22.4 k at 256 frames per step, 25.6 k at 512 on one box).
+//  (4) this file, round 4: the ordering moves to the HOST.  Every lane has a worker thread that drives its sub-batch with blocking waits -- copy in
+//      (copy stream), kernels (the lane ctx' streams), copy out (copy stream) -- so a stream never holds a command that waits for another engine,
+//      and a lane that is copying simply is not in anybody's way.  Sub-batches sit in one queue; whichever lane is free takes the next.  Measured with
+//      tools/host_thread_probe.py before it was built: 28.5 k (4 lanes) - 29.2 k (8) against 30.5-31 k device resident on the same box.
+// A submit of ONE sub-batch (B <= cfg.max_batch: the latency case) runs on the ctx itself, in order on its stream, as before: no thread hand-off.
+// The caller's buffers should be pinned (xfh_host_alloc / xfh_host_register): with pageable memory the HIP runtime stages every copy through its own
+// bounce buffers -- still correct, much slower.
 #include "ctx.h"
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
 #define HIPCK(c, x) do { hipError_t _e = (x); if (_e != hipSuccess) { (c)->hip_err = std::string(#x) + ": " + hipGetErrorString(_e); return XFH_ERR_HIP; } } while (0)
 
+struct PipeJob { const uint8_t* gray; uint8_t* rec_out; int n, H, W, lap0, lap1, slot; };
+struct PipeShared {
+    std::mutex m;
+    std::mutex out_m;                            // ONE download at a time (see lane_main)
+    std::condition_variable cv_job, cv_done;
+    std::deque<PipeJob> q;
+    bool stop = false;
+    int remaining[XFH_PIPE_MAX_BATCHES] = {};    // sub-batches of the slot's submit that have not landed yet
+    int status[XFH_PIPE_MAX_BATCHES] = {};       // first error of the slot's sub-batches
+    int busy = 0;                                // jobs queued or running
+    std::string err;
+};
+
+// one lane: take the next sub-batch, whoever's it is, and drive it to the caller's memory
+static void lane_main(xfh_ctx* parent, int li) {
+    Pipe& P = parent->pipe;
+    PipeShared& S = *P.sh;
+    PipeLane& L = P.lane[li];
+    xfh_ctx* lc = L.ctx;
+    hipSetDevice(parent->cfg.device);
+    const size_t rec = xfh_record_bytes(parent->cfg.nfeatures);
+    for (;;) {
+        PipeJob j;
+        {
+            std::unique_lock<std::mutex> lk(S.m);
+            // (a lane beyond xfh_pipeline_lanes' current number stays asleep; at shutdown every lane helps to empty the queue)
+            S.cv_job.wait(lk, [&] { return S.stop || (!S.q.empty() && li < P.max_lanes); });
+            if (S.q.empty()) return;             // stop, and nothing left to do
+            j = S.q.front(); S.q.pop_front();
+        }
+        const size_t fb = (size_t)j.H * j.W;
+        const char* what = "hipMemcpyAsync (frames)";
+        hipError_t e = hipMemcpyAsync(lc->d_gray, j.gray, (size_t)j.n * fb, hipMemcpyHostToDevice, L.copy);
+        if (e == hipSuccess) e = hipStreamSynchronize(L.copy);
+        if (e == hipSuccess) { what = "run_extract"; e = run_extract(lc, lc->d_gray, j.n, j.H, j.W, j.lap0, j.lap1, lc->d_records); }
+        if (e == hipSuccess) e = hipStreamSynchronize(lc->stream);
+        if (e == hipSuccess) {
+            // One download at a time.  Lanes that start together finish their kernels together, and then their downloads share the one PCIe link, nobody
+            // computes, and the next round starts in phase again -- the pipeline is bistable (the same configuration read 28 k and 19 k frames/s in two
+            // runs).  Taking turns costs a lane nothing it would not lose anyway (the link is the shared resource) and staggers the lanes for good: the
+            // first one through starts its next sub-batch while the second one copies.
+            std::lock_guard<std::mutex> lk(S.out_m);
+            what = "hipMemcpyAsync (records)";
+            e = hipMemcpyAsync(j.rec_out, lc->d_records, (size_t)j.n * rec, hipMemcpyDeviceToHost, L.copy);
+            if (e == hipSuccess) e = hipStreamSynchronize(L.copy);
+        }
+        {
+            std::lock_guard<std::mutex> lk(S.m);
+            if (e != hipSuccess && S.status[j.slot] == XFH_OK) { S.status[j.slot] = XFH_ERR_HIP; S.err = std::string(what) + ": " + hipGetErrorString(e); }
+            --S.remaining[j.slot]; --S.busy;
+        }
+        S.cv_done.notify_all();
+    }
+}
+
+static void pipe_wait_idle(xfh_ctx* c) {          // every queued sub-batch has landed
+    Pipe& P = c->pipe;
+    if (!P.sh) return;
+    std::unique_lock<std::mutex> lk(P.sh->m);
+    P.sh->cv_done.wait(lk, [&] { return P.sh->busy == 0; });
+}
+
 void pipe_destroy(xfh_ctx* c) {
     Pipe& P = c->pipe;
+    if (P.sh) {
+        { std::lock_guard<std::mutex> lk(P.sh->m); P.sh->stop = true; }
+        P.sh->cv_job.notify_all();
+    }
     for (int l = 0; l < P.nlanes; ++l) {
         PipeLane& L = P.lane[l];
-        if (L.ctx && L.ctx != c) xfh_destroy(L.ctx);          // synchronises the lane's own streams first
-        else if (c->stream) hipStreamSynchronize(c->stream);
-        for (int k = 0; k < XFH_PIPE_MAX_BATCHES; ++k) if (L.done[k]) hipEventDestroy(L.done[k]);
+        if (L.thread) { std::thread* t = (std::thread*)L.thread; t->join(); delete t; }      // drains the queue first (lane_main only leaves on an empty queue)
+        if (L.copy) { hipStreamSynchronize(L.copy); hipStreamDestroy(L.copy); }
+        if (L.ctx) xfh_destroy(L.ctx);            // synchronises the lane's own streams first
         L = PipeLane();
     }
     P.nlanes = 0;
-    P.b_head = P.b_count = 0;
+    if (c->stream && P.inline_busy) hipStreamSynchronize(c->stream);
+    for (int k = 0; k < XFH_PIPE_MAX_BATCHES; ++k) if (P.inline_done[k]) { hipEventDestroy(P.inline_done[k]); P.inline_done[k] = nullptr; }
+    delete P.sh; P.sh = nullptr;
+    P.b_head = P.b_count = 0; P.inline_busy = false;
 }
 
 int pipe_reshare_weights(xfh_ctx* c) {
-    for (int l = 1; l < c->pipe.nlanes; ++l) {
+    pipe_wait_idle(c);                            // no lane is in the middle of a sub-batch while its weight pointers change
+    for (int l = 0; l < c->pipe.nlanes; ++l) {
         xfh_ctx* t = c->pipe.lane[l].ctx;
         HIPCK(c, hipStreamSynchronize(t->stream));
         const int rc = ctx_share_weights(c, t);
@@ -53,28 +129,26 @@ int pipe_reshare_weights(xfh_ctx* c) {
     return XFH_OK;
 }
 
-// lanes [0, want) exist afterwards
+// worker lanes [0, want) exist and run afterwards
 static int pipe_ready(xfh_ctx* c, int want) {
     Pipe& P = c->pipe;
+    if (!P.sh) P.sh = new PipeShared();
     while (P.nlanes < want) {
         PipeLane& L = P.lane[P.nlanes];
         L = PipeLane();
-        if (P.nlanes == 0) L.ctx = c;
-        else {
-            xfh_ctx* t = nullptr;
-            xfh_config cfg = c->cfg;
-            cfg.flags |= XFH_FLAG_SERIAL_BRANCH;       // one stream per lane (the keypoint branch inline): the lanes are the concurrency here; measured
-                                                        // 25.2-25.7 k frames/s against 18-23 k with a second stream per lane (profiles/r03_host_pipeline.md)
-            const int rc = xfh_create(&cfg, &t);
-            if (rc != XFH_OK) return rc;
-            t->is_lane = true;
-            L.ctx = t;
-            const int rs = ctx_share_weights(c, t);
-            if (rs != XFH_OK) { xfh_destroy(t); L = PipeLane(); return rs; }
-        }
+        xfh_ctx* t = nullptr;
+        xfh_config cfg = c->cfg;
+        const int rc = xfh_create(&cfg, &t);
+        if (rc != XFH_OK) return rc;
+        t->is_lane = true;
+        const int rs = ctx_share_weights(c, t);
+        if (rs != XFH_OK) { xfh_destroy(t); return rs; }
+        if (hipStreamCreateWithFlags(&L.copy, hipStreamNonBlocking) != hipSuccess) { xfh_destroy(t); L = PipeLane(); c->hip_err = "hipStreamCreateWithFlags (lane copy stream)"; return XFH_ERR_HIP; }
+        L.ctx = t;
+        const int li = P.nlanes;
         ++P.nlanes;                                   // from here on pipe_destroy cleans the lane up
-        if (xfh_verbose()) fprintf(stderr, "[xfh] ctx %p: pipeline lane %d = ctx %p\n", (void*)c, P.nlanes - 1, (void*)L.ctx);
-        for (int k = 0; k < XFH_PIPE_MAX_BATCHES; ++k) HIPCK(c, hipEventCreateWithFlags(&L.done[k], hipEventDisableTiming));
+        L.thread = new std::thread(lane_main, c, li);
+        if (xfh_verbose()) fprintf(stderr, "[xfh] ctx %p: pipeline lane %d = ctx %p + worker thread\n", (void*)c, li, (void*)L.ctx);
     }
     return XFH_OK;
 }
@@ -94,7 +168,8 @@ int xfh_host_unregister(void* p) { return !p || hipHostUnregister(p) == hipSucce
 
 int xfh_pipeline_lanes(xfh_ctx* c, int lanes) {
     if (!c || lanes < 1 || lanes > XFH_PIPE_MAX_LANES) return XFH_ERR_INVALID_ARG;
-    c->pipe.max_lanes = lanes;                         // lanes already built stay; a smaller number simply leaves them unused
+    c->pipe.max_lanes = lanes;                         // lanes already built stay; with a smaller number the surplus ones sleep
+    if (c->pipe.sh) c->pipe.sh->cv_job.notify_all();
     return XFH_OK;
 }
 
@@ -108,42 +183,39 @@ int xfh_extract_batch_submit(xfh_ctx* c, const uint8_t* gray, int B, int H, int 
     HIPCK(c, hipSetDevice(c->cfg.device));
     Pipe& P = c->pipe;
     if (P.b_count >= XFH_PIPE_MAX_BATCHES) return XFH_ERR_INVALID_ARG;      // wait for the oldest batch first
-    const int S = c->cfg.max_batch, nsub = (B + S - 1) / S, nl = nsub < P.max_lanes ? nsub : P.max_lanes;
-    int rc = pipe_ready(c, nl);
-    if (rc != XFH_OK) return rc;
-    XfhRange range("xfh:batch_submit");
+    const int S = c->cfg.max_batch, nsub = (B + S - 1) / S;
     const size_t rec = xfh_record_bytes(c->cfg.nfeatures), fb = (size_t)H * W;
     const int slot = (P.b_head + P.b_count) % XFH_PIPE_MAX_BATCHES;
-    unsigned used = 0;
-    // a failure in the middle leaves earlier sub-batches queued (they will still copy into records_out): the lanes touched so far are waited for
-    // before the error is returned, so that a failed submit never leaves anything of this call in flight (xfh_extract_batch_wait could not cover it)
-    auto fail = [&](int code) {
-        for (int l = 0; l < nl; ++l) if (used >> l & 1) hipStreamSynchronize(P.lane[l].ctx->stream);
-        return code;
-    };
-    for (int j = 0; j < nsub; ++j) {
-        const int n = B - j * S < S ? B - j * S : S;
-        const int li = nl == 1 ? 0 : (int)(P.next % (unsigned)nl);             // a call of one sub-batch always runs on the ctx itself
-        ++P.next;
-        PipeLane& L = P.lane[li];
-        xfh_ctx* lc = L.ctx;
-        L.busy = true;
-        used |= 1u << li;
-        hipError_t e = hipMemcpyAsync(lc->d_gray, gray + (size_t)j * S * fb, (size_t)n * fb, hipMemcpyHostToDevice, lc->stream);
-        if (e != hipSuccess) { c->hip_err = std::string("hipMemcpyAsync (frames): ") + hipGetErrorString(e); return fail(XFH_ERR_HIP); }
-        {
-            const int flags = lc->cfg.flags;
-            if (nl > 1) lc->cfg.flags |= XFH_FLAG_SERIAL_BRANCH;            // lane 0 is the caller's ctx: same rule while it works as a lane
-            e = run_extract(lc, lc->d_gray, n, H, W, lap0, lap1, lc->d_records);
-            lc->cfg.flags = flags;
-            if (e != hipSuccess) { c->hip_err = std::string("run_extract: ") + hipGetErrorString(e); return fail(XFH_ERR_HIP); }
-        }
-        e = hipMemcpyAsync((uint8_t*)records_out + (size_t)j * S * rec, lc->d_records, (size_t)n * rec, hipMemcpyDeviceToHost, lc->stream);
-        if (e != hipSuccess) { c->hip_err = std::string("hipMemcpyAsync (records): ") + hipGetErrorString(e); return fail(XFH_ERR_HIP); }
+    XfhRange range("xfh:batch_submit");
+    if (nsub == 1) {
+        // one sub-batch: on the ctx itself, in order on its stream.  A failure in the middle leaves earlier commands queued (they may still copy
+        // into records_out): the stream is waited for before the error goes back, so that a failed submit never leaves anything of this call in flight
+        if (!P.inline_done[slot]) HIPCK(c, hipEventCreateWithFlags(&P.inline_done[slot], hipEventDisableTiming));
+        auto fail = [&](const char* what, hipError_t e) { c->hip_err = std::string(what) + ": " + hipGetErrorString(e); hipStreamSynchronize(c->stream); return XFH_ERR_HIP; };
+        P.inline_busy = true;
+        hipError_t e = hipMemcpyAsync(c->d_gray, gray, (size_t)B * fb, hipMemcpyHostToDevice, c->stream);
+        if (e != hipSuccess) return fail("hipMemcpyAsync (frames)", e);
+        if ((e = run_extract(c, c->d_gray, B, H, W, lap0, lap1, c->d_records)) != hipSuccess) return fail("run_extract", e);
+        if ((e = hipMemcpyAsync(records_out, c->d_records, (size_t)B * rec, hipMemcpyDeviceToHost, c->stream)) != hipSuccess) return fail("hipMemcpyAsync (records)", e);
+        if ((e = hipEventRecord(P.inline_done[slot], c->stream)) != hipSuccess) return fail("hipEventRecord", e);
+        P.slot_inline[slot] = true;
+        ++P.b_count;
+        return XFH_OK;
     }
-    // the batch is complete when the last download of every lane it touched is: one event per lane, waited for by the HOST
-    for (int l = 0; l < nl; ++l) if (used >> l & 1) HIPCK(c, hipEventRecord(P.lane[l].done[slot], P.lane[l].ctx->stream));
-    P.lanes_of[slot] = used;
+    const int nl = nsub < P.max_lanes ? nsub : P.max_lanes;
+    const int rc = pipe_ready(c, nl);
+    if (rc != XFH_OK) return rc;
+    {
+        std::lock_guard<std::mutex> lk(P.sh->m);
+        P.sh->remaining[slot] = nsub; P.sh->status[slot] = XFH_OK;
+        for (int j = 0; j < nsub; ++j) {
+            const int n = B - j * S < S ? B - j * S : S;
+            P.sh->q.push_back(PipeJob{gray + (size_t)j * S * fb, (uint8_t*)records_out + (size_t)j * S * rec, n, H, W, lap0, lap1, slot});
+        }
+        P.sh->busy += nsub;
+    }
+    P.sh->cv_job.notify_all();
+    P.slot_inline[slot] = false;
     ++P.b_count;
     return XFH_OK;
 }
@@ -153,22 +225,30 @@ int xfh_extract_batch_wait(xfh_ctx* c) {
     Pipe& P = c->pipe;
     if (P.b_count <= 0) return XFH_ERR_INVALID_ARG;             // nothing outstanding
     HIPCK(c, hipSetDevice(c->cfg.device));
-    for (int l = 0; l < P.nlanes; ++l) if (P.lanes_of[P.b_head] >> l & 1) HIPCK(c, hipEventSynchronize(P.lane[l].done[P.b_head]));
+    const int slot = P.b_head;
+    int rc = XFH_OK;
+    if (P.slot_inline[slot]) {
+        const hipError_t e = hipEventSynchronize(P.inline_done[slot]);
+        if (e != hipSuccess) { c->hip_err = std::string("hipEventSynchronize: ") + hipGetErrorString(e); rc = XFH_ERR_HIP; }
+    } else {
+        std::unique_lock<std::mutex> lk(P.sh->m);
+        P.sh->cv_done.wait(lk, [&] { return P.sh->remaining[slot] == 0; });
+        rc = P.sh->status[slot];
+        if (rc != XFH_OK) c->hip_err = P.sh->err;
+    }
     P.b_head = (P.b_head + 1) % XFH_PIPE_MAX_BATCHES; --P.b_count;
-    return XFH_OK;
+    return rc;
 }
 
 int xfh_extract_batch_drain(xfh_ctx* c) {
     if (!c) return XFH_ERR_INVALID_ARG;
     HIPCK(c, hipSetDevice(c->cfg.device));
-    for (int l = 0; l < c->pipe.nlanes; ++l) {
-        PipeLane& L = c->pipe.lane[l];
-        if (!L.busy) continue;
-        HIPCK(c, hipStreamSynchronize(L.ctx->stream));          // the download is the last command of every sub-batch
-        L.busy = false;
-    }
-    c->pipe.b_head = c->pipe.b_count = 0;
-    return XFH_OK;
+    Pipe& P = c->pipe;
+    int rc = XFH_OK;
+    while (P.b_count > 0) { const int r = xfh_extract_batch_wait(c); if (rc == XFH_OK) rc = r; }
+    pipe_wait_idle(c);
+    if (P.inline_busy) { HIPCK(c, hipStreamSynchronize(c->stream)); P.inline_busy = false; }
+    return rc;
 }
 
 int xfh_extract_batch(xfh_ctx* c, const uint8_t* gray, int B, int H, int W, int lap0, int lap1, void* records_out) {
