@@ -89,6 +89,44 @@ public:
         _matches.reserve(n);
         for (int k = 0; k < n; ++k) _matches.emplace_back(DMatch(i1[k], i2[k], d[k]));
     }
+    // One frame against several partners in ONE call (the tracker's frame against previous frame / key frames / loop candidates; the reference
+    // calls match() once per pair, ORBmatcher.cc:358-372): xfh_match_mnn_prepared_batch_device -- one persistent GEMM launch over the tiles of
+    // all pairs + one launch for the mutual check and the output.  _matches[p] = what matchPrepared(d_image1, n1, d_images2[p], n2[p]) gives.
+    void matchPreparedMany(const void* d_image1, int n1, const std::vector<const void*>& d_images2, const std::vector<int>& n2,
+                           std::vector<std::vector<DMatch>>& _matches, float min_cossim = -1.f) {
+        const int P = (int)d_images2.size();
+        _matches.assign(P, std::vector<DMatch>());
+        if (P == 0 || n1 <= 0) return;
+        std::vector<size_t> off(P + 1, 0);
+        std::vector<int> nm(P);
+        for (int p = 0; p < P; ++p) { nm[p] = n2[p] <= 0 ? 1 : (n1 < n2[p] ? n1 : n2[p]); off[p + 1] = off[p] + (((size_t)nm[p] * 12 + 63) & ~(size_t)63); }
+        const size_t bytes = off[P] + (size_t)P * 4 + 64;
+        if (bytes > d_out_bytes) {
+            if (d_out) xfh_dev_free(d_out);
+            d_out = nullptr; d_out_bytes = 0;
+            if (xfh_dev_alloc(&d_out, bytes) != XFH_OK) throw std::runtime_error("XFmatcher::matchPreparedMany: out of device memory");
+            d_out_bytes = bytes;
+        }
+        char* o = (char*)d_out;
+        std::vector<const void*> a1(P, d_image1);
+        std::vector<int> vn1(P, n1);
+        std::vector<int*> p1(P), p2(P); std::vector<float*> pd(P);
+        for (int p = 0; p < P; ++p) { p1[p] = (int*)(o + off[p]); p2[p] = (int*)(o + off[p] + 4 * (size_t)nm[p]); pd[p] = (float*)(o + off[p] + 8 * (size_t)nm[p]); }
+        int* d_cnt = (int*)(o + off[P]);
+        int rc = xfh_match_mnn_prepared_batch_device(ctx, P, a1.data(), vn1.data(), d_images2.data(), n2.data(), min_cossim, p1.data(), p2.data(), pd.data(), d_cnt);
+        if (rc == XFH_OK) rc = xfh_synchronize(ctx);
+        if (rc != XFH_OK) throw std::runtime_error(std::string("XFmatcher::matchPreparedMany: ") + xfh_strerror(rc));
+        std::vector<int> cnt(P, 0);
+        xfh_memcpy_d2h(cnt.data(), d_cnt, (size_t)P * 4);
+        for (int p = 0; p < P; ++p) {
+            const int n = cnt[p];
+            if (n < 0 || n > nm[p]) throw std::runtime_error("XFmatcher::matchPreparedMany: the device reported a collector time-out (n_matches < 0)");
+            i1.resize(n); i2.resize(n); d.resize(n);
+            if (n > 0) { xfh_memcpy_d2h(i1.data(), p1[p], 4 * (size_t)n); xfh_memcpy_d2h(i2.data(), p2[p], 4 * (size_t)n); xfh_memcpy_d2h(d.data(), pd[p], 4 * (size_t)n); }
+            _matches[p].reserve(n);
+            for (int k = 0; k < n; ++k) _matches[p].emplace_back(DMatch(i1[k], i2[k], d[k]));
+        }
+    }
     ~XFmatcher() { if (d_out) xfh_dev_free(d_out); }
     XFmatcher(const XFmatcher&) = delete;
     XFmatcher& operator=(const XFmatcher&) = delete;

@@ -72,6 +72,17 @@ int main(int argc, char** argv) {
             bm.match(da, db, mh);
             if (mp.size() != mh.size() || mp.empty()) return 8;
             for (size_t k = 0; k < mp.size(); ++k) if (mp[k].queryIdx != mh[k].queryIdx || mp[k].trainIdx != mh[k].trainIdx) return 8;
+            {   // one frame against several partners in one call == the pair-by-pair calls (here: frame 0 against frame 1, itself, frame 1 again)
+                std::vector<std::vector<XFmatcher::DMatch>> many;
+                std::vector<XFmatcher::DMatch> self;
+                bm.matchPreparedMany(d_img, nf, {(const void*)((char*)d_img + ib), (const void*)d_img, (const void*)((char*)d_img + ib)}, {nf, nf, nf}, many);
+                bm.matchPrepared(d_img, nf, d_img, nf, self);
+                if (many.size() != 3 || many[0].size() != mp.size() || many[2].size() != mp.size() || many[1].size() != self.size()) return 10;
+                for (size_t k = 0; k < mp.size(); ++k)
+                    if (many[0][k].queryIdx != mp[k].queryIdx || many[0][k].trainIdx != mp[k].trainIdx || many[0][k].distance != mp[k].distance ||
+                        many[2][k].trainIdx != mp[k].trainIdx) return 10;
+                for (size_t k = 0; k < self.size(); ++k) if (many[1][k].queryIdx != self[k].queryIdx || many[1][k].trainIdx != self[k].trainIdx) return 10;
+            }
             char id[XFH_UNIQUE_ID_BYTES];
             XFextractor::commUniqueId(id);
             bx.commCreate(id, 0, 1);
