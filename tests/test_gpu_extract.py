@@ -491,8 +491,8 @@ def test_match_records_drops_padding_pairs(gpu_lib, oracle_mod):
 
 def test_host_visible_batch_pipeline(gpu_lib, oracle_mod, weights_dense):
     """xfh_extract_batch / _submit / _wait (host frames in, host records out): a call of B frames with B far above
-    cfg.max_batch is cut into sub-batches that rotate over the lanes (own activations and streams, shared weights), with H2D,
-    kernels and D2H on separate streams.  Pinned and pageable caller buffers, blocking and asynchronous form, ragged last
+    cfg.max_batch is cut into sub-batches that go into one queue drained by the lanes (own activations and streams, shared weights, a worker
+    thread each that drives copy in / kernels / copy out).  Pinned and pageable caller buffers, blocking and asynchronous form, ragged last
     sub-batch, several submits outstanding: every record equals the one a lone serial ctx produces for the frame, bit for bit;
     frame 0 is checked against the oracle."""
     from xfeatslam_amd.extractor import Context
@@ -560,6 +560,57 @@ def test_host_visible_batch_pipeline(gpu_lib, oracle_mod, weights_dense):
     for h in houts + [hin]:
         h.free()
     ctx.close()
+
+
+def test_batch_pipeline_queue_limits_and_teardown(gpu_lib, weights_dense):
+    """the ring of outstanding submits (XFH_MAX_BATCHES_INFLIGHT = 8: the ninth is refused until one is waited for), submits of one sub-batch (they
+    run on the ctx itself) between submits of many (worker lanes), in order; and xfh_destroy with submits still outstanding: the lanes finish
+    what is queued, then the ctx goes away -- no hang, no write after the call returns"""
+    from xfeatslam_amd.extractor import Context
+    L = gpu_lib
+    _, blob = weights_dense
+    H, W, nf, S = 96, 128, 256, 4
+    n = 3 * S + 1
+    fr = synth.frames(n, H, W, seed=321)
+    ref = Context(nfeatures=nf, max_height=H, max_width=W, max_batch=n); ref.load_weights(blob)
+    rb = ref.rec_bytes
+    d_in = capi.DeviceBuffer(fr.nbytes).upload(fr); d_rec = capi.DeviceBuffer(n * rb)
+    capi.check(L.xfh_extract_batch_device(ref.h, d_in.ptr, n, H, W, 0, 0, d_rec.ptr), ref.h)
+    ref.synchronize()
+    want = d_rec.download(np.uint8, n * rb)
+    ref.close()
+    ctx = _ctx(nf, H, W, B=S); ctx.load_weights(blob)
+    hin = capi.HostBuffer(fr.nbytes); hin.array[:] = fr.reshape(-1)
+    houts = [capi.HostBuffer(n * rb) for _ in range(8)]
+    sizes = [n, S, n, 2, n, S - 1, n, n]                    # many sub-batches (lanes) and single ones (the ctx itself), alternating
+    for h, b in zip(houts, sizes):
+        capi.check(L.xfh_extract_batch_submit(ctx.h, hin.ptr, b, H, W, 0, 0, h.ptr), ctx.h)
+    assert L.xfh_extract_batch_submit(ctx.h, hin.ptr, n, H, W, 0, 0, houts[0].ptr) == 1       # the ring is full
+    for h, b in zip(houts, sizes):
+        capi.check(L.xfh_extract_batch_wait(ctx.h), ctx.h)                                    # oldest first
+        assert records_equal(ctx, h.array[:b * rb], want[:b * rb], b), b
+    assert L.xfh_extract_batch_wait(ctx.h) == 1
+    # teardown with work in flight
+    for h in houts[:4]:
+        h.array[:] = 0
+        capi.check(L.xfh_extract_batch_submit(ctx.h, hin.ptr, n, H, W, 0, 0, h.ptr), ctx.h)
+    ctx.close()                                              # xfh_destroy: returns when the lanes are done
+    for h in houts[:4]:
+        assert records_equal(_RecView(nf, rb), h.array, want, n)      # (the ctx is gone: a layout-only view parses the records)
+    for h in houts + [hin]:
+        h.free()
+    d_in.free(); d_rec.free()
+
+
+class _RecView:
+    """parse_records without a live ctx (the layout only depends on nfeatures)"""
+    def __init__(self, nf, rb):
+        self.nfeatures, self.rec_bytes = nf, rb
+        self.kps_off = int(capi.lib().xfh_record_kps_offset()); self.desc_off = int(capi.lib().xfh_record_desc_offset(nf))
+
+    def parse_records(self, raw, B):
+        from xfeatslam_amd.extractor import Context
+        return Context.parse_records(self, raw, B)
 
 
 def test_eval_bn_modes_through_the_pipeline_lanes(gpu_lib, weights_dense):
