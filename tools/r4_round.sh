@@ -19,8 +19,9 @@ bash tools/pmc_calib.sh > $O/pmc_calib.out 2>&1
 PMC_LEGS="--only-match-leg --match-iters 10 --cpu-frames 0" PMC_BENCH_ARGS="--streams 1 --batch 64" bash tools/pmc_kernels.sh > $O/pmck.out 2>&1
 rm -rf $O/pmck1_B64 $O/pmck2_B64; mv $O/pmck1 $O/pmck1_B64; mv $O/pmck2 $O/pmck2_B64
 PMC_BENCH_ARGS="--streams 1 --batch 256" bash tools/pmc_kernels.sh >> $O/pmck.out 2>&1
+rm -rf $O/pmck1_B256 $O/pmck2_B256; mv $O/pmck1 $O/pmck1_B256; mv $O/pmck2 $O/pmck2_B256
 ( timeout 200 python tools/host_batch_probe.py 512 "64x4,64x5,64x6,64x8,48x6,32x8" ) > $O/host_batch_probe.log 2>&1
 python tools/queue_view.py $(ls $O/prof/*kernel_trace.csv | head -1) > $O/queue_view.txt 2>&1
-ls $O/prof $O/prof_serial $O/prof_serial64 $O/pmck1 $O/pmck1_B64 | head -40
+ls $O/prof $O/prof_serial $O/prof_serial64 $O/pmck1_B256 $O/pmck1_B64 | head -40
 tail -3 $O/pytest_gpu.log; cat $O/smoke.log | tail -2
 echo round done
