@@ -42,6 +42,11 @@ int xfh_bench_mnn_gemm_batch(xfh_ctx* ctx, int n_pairs, const void* const* d_ima
                              int iters, double* us_per_launch, double* sclk_mhz);
 int xfh_bench_match_batch(xfh_ctx* ctx, int n_pairs, const void* const* d_image1, const int* n1, const void* const* d_image2, const int* n2, float min_cossim,
                           int* const* d_idx1, int* const* d_idx2, float* const* d_dist, int* d_n_matches, int iters, double* us_per_call);
+/* The work plan of the many-pairs GEMM for a list of pair shapes on `num_cu` workgroups (host arithmetic only, no GPU, no ctx: xfeatslam_amd/csrc/mnn_seg_plan.h).
+ * Outputs: *tiles, *workgroups; per pair tile0[p] (first tile), planes_max[p] (row-key planes reserved per d1 row); wg_lo[w] for w = 0 .. *workgroups
+ * (workgroup w owns the tiles [wg_lo[w], wg_lo[w + 1])); *keys = u64 entries of the key buffer.  n_pairs <= 16; wg_lo needs num_cu + 1 slots. */
+int xfh_debug_match_plan(int n_pairs, const int* n1, const int* n2, int num_cu, int* tiles, int* workgroups, int* tile0, int* planes_max, int* wg_lo,
+                         unsigned long long* keys);
 const char* xfh_kernel_name(int kernel_id);
 
 /* intermediate tensors of frame `frame` of the last extract call, copied to host as float

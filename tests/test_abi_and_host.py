@@ -261,6 +261,67 @@ def test_panel_layout_is_conflict_free():
                     assert len(slots) == 16
 
 
+def test_many_pairs_work_plan_invariants():
+    """xfeatslam_amd/csrc/mnn_seg_plan.h (the plan of xfh_match_mnn_prepared_batch_device, shared by the host, k_mnn_gemm_seg and k_mnn_post): for random mixes of
+    pair shapes and workgroup counts the workgroups' tile ranges partition the tile sequence into G non-empty, contiguous, balanced pieces; every d1 panel
+    (a run of P2 consecutive tiles) is touched by a run of consecutive workgroups whose count never exceeds what the key buffer reserves for it, and the
+    row-key plane index 2 * (w - w_first) + group the GEMM writes stays below the plane count k_mnn_post reads for that panel."""
+    L = capi.lib()
+    rng = np.random.RandomState(7)
+    shapes = [[(4096, 4096)] * 8, [(4096, 4096)], [(1, 5)], [(300, 200), (1, 5), (5, 1), (129, 127), (257, 4097), (1000, 777)], [(4096, 4096)] * 16]
+    for _ in range(40):
+        P = int(rng.randint(1, 17))
+        shapes.append([(int(rng.randint(1, 6000)), int(rng.randint(1, 6000))) for _ in range(P)])
+    for sh in shapes:
+        for num_cu in (256, 1, 7, 100, 304):
+            P = len(sh)
+            n1 = (C.c_int * P)(*[a for a, _ in sh]); n2 = (C.c_int * P)(*[b for _, b in sh])
+            T, G, keys = C.c_int(), C.c_int(), C.c_ulonglong()
+            tile0 = (C.c_int * P)(); pmax = (C.c_int * P)(); lo = (C.c_int * (num_cu + 1))()
+            assert L.xfh_debug_match_plan(P, n1, n2, num_cu, C.byref(T), C.byref(G), tile0, pmax, lo, C.byref(keys)) == 0
+            P1 = [(a + 255) // 256 for a, _ in sh]; P2 = [(b + 255) // 256 for _, b in sh]
+            assert T.value == sum(a * b for a, b in zip(P1, P2)) and G.value == min(T.value, num_cu)
+            lo = list(lo)[:G.value + 1]
+            assert lo[0] == 0 and lo[-1] == T.value and all(b > a for a, b in zip(lo, lo[1:]))          # a partition into non-empty ranges
+            sizes = [b - a for a, b in zip(lo, lo[1:])]
+            assert max(sizes) - min(sizes) <= 1                                                           # balanced
+            wg_of = np.repeat(np.arange(G.value), sizes)
+            assert np.array_equal(wg_of, (np.arange(T.value, dtype=np.int64) * G.value) // T.value)     # = tile * G / T, the form the kernels use
+            need = 0
+            for p in range(P):
+                assert tile0[p] == sum(a * b for a, b in zip(P1[:p], P2[:p]))
+                for by in range(P1[p]):
+                    t0 = tile0[p] + by * P2[p]
+                    ws = wg_of[t0:t0 + P2[p]]
+                    assert np.all(np.diff(ws) >= 0) and np.all(np.diff(ws) <= 1)                          # consecutive workgroups
+                    planes = 2 * (int(ws[-1]) - int(ws[0]) + 1)
+                    assert planes <= pmax[p], (sh, num_cu, p, by, planes, pmax[p])
+                need += (pmax[p] * P1[p] + P1[p] * P2[p] + P1[p]) * 256
+            assert keys.value == need
+    assert L.xfh_debug_match_plan(0, None, None, 256, None, None, None, None, None, None) == 1
+
+
+def test_match_gemm_register_contract():
+    """k_mnn_gemm_img and k_mnn_gemm_seg run two waves per SIMD on a budget of 256 VGPRs each: accumulators 128 + (seg: the d1 strip 64 + operands 32).  A spill
+    inside the K loop would put scratch traffic in front of every MFMA group; the one spill that exists (a 64-bit constant of the rare new-d1-panel path of
+    k_mnn_gemm_seg) must stay the only one."""
+    import re
+    import shutil
+    import subprocess
+    if not shutil.which("c++filt") or not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("needs hipcc and c++filt")
+    out = subprocess.run(["bash", os.path.join(ROOT, "tools", "kres.sh"), "kernels_mnn_gemm.hip", "-fno-honor-nans"], capture_output=True, text=True, timeout=600).stdout
+    rows = {}
+    for line in out.splitlines():
+        m = re.match(r"(?:void )?(\S.*?)\s+vgpr\s+(\d+)\s+agpr\s+(\d+)\s+scratch\s+(\d+)\s+occ\s+(\d+)", line)
+        if m:
+            rows[m.group(1)] = tuple(int(x) for x in m.groups()[1:])
+    img = [k for k in rows if k.startswith("k_mnn_gemm_img")]; seg = [k for k in rows if k.startswith("k_mnn_gemm_seg")]
+    assert len(img) == 1 and len(seg) == 1, out[-1500:]
+    assert rows[img[0]][2] == 0 and rows[img[0]][0] + rows[img[0]][1] <= 256 and rows[img[0]][3] >= 2, rows[img[0]]
+    assert rows[seg[0]][2] <= 16 and rows[seg[0]][0] + rows[seg[0]][1] <= 256 and rows[seg[0]][3] >= 2, rows[seg[0]]
+
+
 def test_kernel_occupancy_contract():
     """The throughput kernels sit at register-count edges: the dominant 3x3 64->64 convolution and its block_fusion.0 instance run
     two 8-wave workgroups per CU (<= 128 VGPRs), and a refactor that nudges the allocator over the edge halves their occupancy

@@ -1,7 +1,7 @@
 #!/bin/bash
-# per-kernel register / scratch / LDS use of one HIP source (clang's kernel-resource-usage remarks): tools/kres.sh kernels_conv.hip > out.txt
+# per-kernel register / scratch / LDS use of one HIP source (clang's kernel-resource-usage remarks): tools/kres.sh kernels_conv.hip [extra flag] > out.txt
 cd "$(dirname "$0")/../xfeatslam_amd/csrc"
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Rpass-analysis=kernel-resource-usage -c "$1" -o /tmp/kres_$$.o 2>&1 |
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Rpass-analysis=kernel-resource-usage $2 -c "$1" -o /tmp/kres_$$.o 2>&1 |
   python3 -c '
 import re, sys, subprocess
 cur = None; rows = []

@@ -111,6 +111,7 @@ SYMBOLS = [
     ("xfh_timing_enable", _i, [_vp, _i, C.c_uint]),
     ("xfh_timing_read", _i, [_vp, _pi, C.POINTER(C.c_double)]),
     ("xfh_bench_mnn_gemm", _i, [_vp, _vp, _i, _vp, _i, _i, C.POINTER(C.c_double)]),
+    ("xfh_debug_match_plan", _i, [_i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("xfh_bench_sclk", _i, [_vp, _i, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     ("xfh_bench_mnn_gemm_batch", _i, [_vp, _i, _vp, _vp, _vp, _vp, _i, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     ("xfh_bench_match_batch", _i, [_vp, _i, _vp, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp, _vp, _i, C.POINTER(C.c_double)]),

@@ -2,6 +2,7 @@
 // Built with hipcc for gfx950 only.  There is no CPU path: without a HIP device every
 // compute entry point fails with XFH_ERR_NO_DEVICE / XFH_ERR_HIP.
 #include "ctx.h"
+#include "mnn_seg_plan.h"
 
 #include <dlfcn.h>
 #include <math.h>
@@ -872,6 +873,17 @@ int xfh_bench_match_prepared(xfh_ctx* c, const void* image1, int n1, const void*
 int xfh_bench_match_raw(xfh_ctx* c, const float* d1, int n1, const float* d2, int n2, float min_cossim,
                         int* idx1, int* idx2, float* dist, int* n_matches, int iters, double* us_per_call) {
     return bench_match(c, false, d1, n1, d2, n2, min_cossim, idx1, idx2, dist, n_matches, iters, us_per_call);
+}
+int xfh_debug_match_plan(int n_pairs, const int* n1, const int* n2, int num_cu, int* tiles, int* workgroups, int* tile0, int* planes_max, int* wg_lo, unsigned long long* keys) {
+    if (n_pairs < 1 || n_pairs > MNN_MAX_JOBS || !n1 || !n2 || num_cu < 1 || !tiles || !workgroups || !tile0 || !planes_max || !wg_lo || !keys) return XFH_ERR_INVALID_ARG;
+    MnnPairIn in[MNN_MAX_JOBS];
+    for (int p = 0; p < n_pairs; ++p) { if (n1[p] < 1 || n2[p] < 1) return XFH_ERR_INVALID_ARG; in[p] = MnnPairIn{nullptr, n1[p], nullptr, n2[p]}; }
+    MnnBatch jb;
+    *keys = (unsigned long long)mnn_seg_plan(in, n_pairs, num_cu, nullptr, &jb);
+    *tiles = jb.T; *workgroups = jb.G;
+    for (int p = 0; p < n_pairs; ++p) { tile0[p] = jb.job[p].tile0; planes_max[p] = mnn_seg_planes_max(jb.job[p].P2, jb.T, jb.G); }
+    for (int w = 0; w <= jb.G; ++w) wg_lo[w] = mnn_seg_lo(w, jb.T, jb.G);
+    return XFH_OK;
 }
 int xfh_bench_mnn_gemm_batch(xfh_ctx* c, int n_pairs, const void* const* image1, const int* n1, const void* const* image2, const int* n2, int iters, double* us_per_launch,
                              double* sclk_mhz) {
