@@ -17,6 +17,10 @@
 //        pass), and only the keypoints (header + 28 B per row) and the match list come back.  Same keypoints and the same match lists as the
 //        default mode, bit for bit.  --valid-only (with --fast): xfh_match_records_device, i.e. pairs that touch a padding slot are dropped
 //        (NOT what the reference's match() returns).
+//   --window K (with --fast): every frame is matched against its K predecessors (the tracker's previous frame and the key frames / loop candidates
+//        behind it: one ORBmatcher::match per pair in the reference, src/ORBmatcher.cc:358-372) in ONE call, xfh_match_mnn_prepared_batch_device.  The
+//        pair (t - 1, t) is what the default mode reports; --dump-window file: per frame the number of partners, then per partner its frame index and
+//        the (idx1 = partner's slot, idx2 = this frame's slot, dist) list.
 //
 // Build: g++ -std=c++17 -O2 -Iinclude examples/frontend_replay.cpp -Lxfeatslam_amd -lxfeat_hip -lz -o frontend_replay
 #define XFEAT_NO_OPENCV 1
@@ -62,11 +66,14 @@ int main(int argc, char** argv) {
     if (argc < 4) { fprintf(stderr, "usage: see the header of examples/frontend_replay.cpp\n"); return 2; }
     FILE* dump = nullptr;
     bool fast = false, valid_only = false;
+    int window = 1; FILE* dumpw = nullptr;
     for (int i = 4; i < argc; ++i) {
         if (std::string(argv[i]) == "--dump" && i + 1 < argc) dump = fopen(argv[i + 1], "wb");
         if (std::string(argv[i]) == "--rgb" && i + 1 < argc) g_rgb = atoi(argv[i + 1]);
         if (std::string(argv[i]) == "--fast") fast = true;
         if (std::string(argv[i]) == "--valid-only") valid_only = true;
+        if (std::string(argv[i]) == "--window" && i + 1 < argc) window = atoi(argv[i + 1]);
+        if (std::string(argv[i]) == "--dump-window" && i + 1 < argc) dumpw = fopen(argv[i + 1], "wb");
     }
     const int nfeatures = getenv("XFH_NFEATURES") ? atoi(getenv("XFH_NFEATURES")) : 1000;     // TUM1.yaml: ORBextractor.nFeatures 1000
     std::vector<std::string> files;
@@ -92,12 +99,15 @@ int main(int argc, char** argv) {
     // --fast: device buffers of the C ABI path (two generations: frame t and frame t - 1)
     xfh_ctx* ctx = extractor.context();
     const size_t rec_bytes = xfh_record_bytes(nfeatures), img_bytes = xfh_match_image_bytes(nfeatures);
-    void* d_gray = nullptr; void* d_rec[2] = {nullptr, nullptr}; void* d_img[2] = {nullptr, nullptr}; void* d_out = nullptr;
+    if (window < 1 || window > 15) { fprintf(stderr, "--window 1 .. 15\n"); return 2; }
+    const int NG = window + 1;                                                                  // generations kept in HBM: this frame and its `window` predecessors
+    void* d_gray = nullptr; std::vector<void*> d_rec(NG, nullptr), d_img(NG, nullptr); void* d_out = nullptr;
+    std::vector<int> gen_valid(NG, 0);
     std::vector<unsigned char> h_head(xfh_record_desc_offset(nfeatures));
     std::vector<int> h_i1(nfeatures), h_i2(nfeatures); std::vector<float> h_d(nfeatures);
     if (fast) {
-        bool ok = xfh_dev_alloc(&d_gray, (size_t)im.rows * im.cols) == XFH_OK && xfh_dev_alloc(&d_out, (size_t)nfeatures * 12 + 64) == XFH_OK;
-        for (int g = 0; g < 2; ++g) ok = ok && xfh_dev_alloc(&d_rec[g], rec_bytes) == XFH_OK && xfh_dev_alloc(&d_img[g], img_bytes) == XFH_OK;
+        bool ok = xfh_dev_alloc(&d_gray, (size_t)im.rows * im.cols) == XFH_OK && xfh_dev_alloc(&d_out, (size_t)window * ((size_t)nfeatures * 12 + 64)) == XFH_OK;
+        for (int g = 0; g < NG; ++g) ok = ok && xfh_dev_alloc(&d_rec[g], rec_bytes) == XFH_OK && xfh_dev_alloc(&d_img[g], img_bytes) == XFH_OK;
         if (!ok) { fprintf(stderr, "out of device memory\n"); return 1; }
     }
     int prev_valid = 0;
@@ -110,15 +120,48 @@ int main(int argc, char** argv) {
             if (ret < 0) { fprintf(stderr, "empty image at %d\n", ni); return 1; }
             if (!prev.empty() && !desc.empty()) matcher.match(prev, desc, matches);
         } else {
-            const int g = ni & 1;
+            const int g = ni % NG, gp = (ni + NG - 1) % NG;          // this frame's generation, the previous frame's
             char* o = (char*)d_out;
+            const size_t ostride = (size_t)nfeatures * 12 + 64;      // per partner: n_matches, then idx1 / idx2 / dist
             int rc = xfh_memcpy_h2d(d_gray, im.data, (size_t)im.rows * im.cols);
             if (rc == XFH_OK) rc = xfh_extract_batch_device_images(ctx, (const uint8_t*)d_gray, 1, im.rows, im.cols, lap[0], lap[1], d_rec[g], d_img[g]);
             const bool have_pair = ni > 0 && prev_valid > 0;          // (the reference releases the descriptors of a frame without keypoints: nothing to match)
-            if (rc == XFH_OK && have_pair) {
-                if (valid_only) rc = xfh_match_records_device(ctx, d_rec[g ^ 1], d_img[g ^ 1], d_rec[g], d_img[g], -1.f, (int*)(o + 64), (int*)(o + 64 + 4 * (size_t)nfeatures),
+            std::vector<int> partners;                                // frames ni - 1, ni - 2, ... that have keypoints (the first one is the default mode's pair)
+            for (int k = 1; k <= window && k <= ni; ++k) if (gen_valid[(ni + NG - k) % NG] > 0) partners.push_back(ni - k);
+            if (rc == XFH_OK && window > 1 && !partners.empty()) {
+                // one call for all partners: pair p = (partner's image, this frame's image)
+                const int P = (int)partners.size();
+                std::vector<const void*> a1(P), a2(P, d_img[g]); std::vector<int> nn(P, nfeatures);
+                std::vector<int*> p1(P), p2(P); std::vector<float*> pd(P);
+                for (int p = 0; p < P; ++p) {
+                    a1[p] = d_img[partners[p] % NG];
+                    p1[p] = (int*)(o + p * ostride + 64); p2[p] = (int*)(o + p * ostride + 64 + 4 * (size_t)nfeatures); pd[p] = (float*)(o + p * ostride + 64 + 8 * (size_t)nfeatures);
+                }
+                std::vector<int> cnt(P, 0);
+                void* d_cnt = nullptr;
+                if (xfh_dev_alloc(&d_cnt, (size_t)P * 4 + 16) != XFH_OK) { fprintf(stderr, "out of device memory\n"); return 1; }
+                rc = xfh_match_mnn_prepared_batch_device(ctx, P, a1.data(), nn.data(), a2.data(), nn.data(), -1.f, p1.data(), p2.data(), pd.data(), (int*)d_cnt);
+                if (rc == XFH_OK) rc = xfh_synchronize(ctx);
+                if (rc == XFH_OK) rc = xfh_memcpy_d2h(cnt.data(), d_cnt, (size_t)P * 4);
+                xfh_dev_free(d_cnt);
+                if (rc == XFH_OK) for (int p = 0; p < P; ++p) xfh_memcpy_h2d(o + p * ostride, &cnt[p], 4);     // n_matches where the one-pair path puts it
+                if (rc == XFH_OK && dumpw) {
+                    fwrite(&P, 4, 1, dumpw);
+                    for (int p = 0; p < P; ++p) {
+                        const int nm = cnt[p];
+                        if (nm < 0 || nm > nfeatures) { fprintf(stderr, "fast path: the matcher reported a time-out\n"); return 1; }
+                        std::vector<int> w1(nm), w2(nm); std::vector<float> wd(nm);
+                        if (nm > 0) { xfh_memcpy_d2h(w1.data(), p1[p], 4 * (size_t)nm); xfh_memcpy_d2h(w2.data(), p2[p], 4 * (size_t)nm); xfh_memcpy_d2h(wd.data(), pd[p], 4 * (size_t)nm); }
+                        fwrite(&partners[p], 4, 1, dumpw); fwrite(&nm, 4, 1, dumpw);
+                        for (int q = 0; q < nm; ++q) { fwrite(&w1[q], 4, 1, dumpw); fwrite(&w2[q], 4, 1, dumpw); fwrite(&wd[q], 4, 1, dumpw); }
+                    }
+                }
+                if (!(have_pair && partners[0] == ni - 1)) { const int zero = 0; xfh_memcpy_h2d(o, &zero, 4); }
+            } else if (rc == XFH_OK && dumpw && window > 1) { const int P = 0; fwrite(&P, 4, 1, dumpw); }
+            if (rc == XFH_OK && have_pair && window == 1) {
+                if (valid_only) rc = xfh_match_records_device(ctx, d_rec[gp], d_img[gp], d_rec[g], d_img[g], -1.f, (int*)(o + 64), (int*)(o + 64 + 4 * (size_t)nfeatures),
                                                               (float*)(o + 64 + 8 * (size_t)nfeatures), (int*)o);
-                else rc = xfh_match_mnn_prepared_device(ctx, d_img[g ^ 1], nfeatures, d_img[g], nfeatures, -1.f, (int*)(o + 64), (int*)(o + 64 + 4 * (size_t)nfeatures),
+                else rc = xfh_match_mnn_prepared_device(ctx, d_img[gp], nfeatures, d_img[g], nfeatures, -1.f, (int*)(o + 64), (int*)(o + 64 + 4 * (size_t)nfeatures),
                                                         (float*)(o + 64 + 8 * (size_t)nfeatures), (int*)o);
             }
             if (rc == XFH_OK) rc = xfh_synchronize(ctx);
@@ -136,6 +179,7 @@ int main(int argc, char** argv) {
                 for (int q = 0; q < nm; ++q) matches.emplace_back(XFmatcher::DMatch(h_i1[q], h_i2[q], h_d[q]));
             }
             prev_valid = hdr[0];
+            gen_valid[g] = hdr[0];
         }
         total_matches += (long)matches.size();
         const auto t2 = std::chrono::steady_clock::now();
@@ -170,7 +214,8 @@ int main(int argc, char** argv) {
     std::sort(vTimesTrack.begin(), vTimesTrack.end());                                         // rgbd_tum.cc:128-139
     double tot = 0; for (double t : vTimesTrack) tot += t;
     if (dump) fclose(dump);
-    if (fast) { xfh_dev_free(d_gray); xfh_dev_free(d_out); for (int g = 0; g < 2; ++g) { xfh_dev_free(d_rec[g]); xfh_dev_free(d_img[g]); } }
+    if (dumpw) fclose(dumpw);
+    if (fast) { xfh_dev_free(d_gray); xfh_dev_free(d_out); for (int g = 0; g < NG; ++g) { xfh_dev_free(d_rec[g]); xfh_dev_free(d_img[g]); } }
     printf("-------\n\nframes: %d  keypoints/frame: %.1f  mutual matches/frame pair: %.1f  inliers/frame pair: %.1f\n", n, (double)total_valid / n,
            n > 1 ? (double)total_matches / (n - 1) : 0.0, n > 1 ? (double)total_inliers / (n - 1) : 0.0);
     printf("median front-end time: %f\nmean front-end time: %f\n", vTimesTrack[n / 2], tot / n);

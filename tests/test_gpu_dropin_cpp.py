@@ -121,6 +121,26 @@ def test_frontend_replay_matches_oracle(gpu_lib, oracle_mod, tmp_path):
         assert np.array_equal(m_val["q"], m_all["q"][keep]) and np.array_equal(m_val["t"], m_all["t"][keep]) and np.array_equal(m_val["d"], m_all["d"][keep], equal_nan=True), i
         dropped += int((~keep).sum())
     assert all(np.array_equal(fv[i][1], frames[i][1]) for i in range(n))
+    # --window 3: every frame against its three predecessors in ONE call (xfh_match_mnn_prepared_batch_device); the pair (t - 1, t) is the default mode's,
+    # every partner's list is the oracle's match of the two padded descriptor blocks
+    dump_w, dump_ww = str(tmp_path / "dump_w.bin"), str(tmp_path / "dump_ww.bin")
+    rw = subprocess.run([exe, str(tmp_path / "w.xfhw"), str(tmp_path / "assoc.txt"), str(tmp_path), "--dump", dump_w, "--fast", "--window", "3", "--dump-window", dump_ww],
+                        capture_output=True, text=True, env=dict(os.environ, XFH_NFEATURES=str(nf)))
+    assert rw.returncode == 0, rw.stderr
+    assert open(dump_w, "rb").read() == open(dump, "rb").read()
+    descs = [orc.extract(grays[i], nf, (0, 0))[1] for i in range(n)]
+    raw = np.fromfile(dump_ww, np.uint8)
+    off = 0
+    for i in range(n):
+        P = int(raw[off:off + 4].view(np.int32)[0]); off += 4
+        assert P == min(i, 3), (i, P)
+        for p in range(P):
+            partner, nm = (int(v) for v in raw[off:off + 8].view(np.int32)); off += 8
+            assert partner == i - 1 - p
+            rec = raw[off:off + 12 * nm].view(np.dtype([("q", "<i4"), ("t", "<i4"), ("d", "<f4")])); off += 12 * nm
+            a = oracle_mod.match_mnn(descs[partner], descs[i])
+            assert np.array_equal(a[0], rec["q"]) and np.array_equal(a[1], rec["t"]) and np.array_equal(a[2], rec["d"], equal_nan=True), (i, partner)
+    assert off == len(raw)
 
 
 def test_frontend_replay_example(gpu_lib, tmp_path):
