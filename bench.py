@@ -761,12 +761,6 @@ def legs(out, args, lib, capi, synth, Context, ctx, blob, frames, d_in, d_recb, 
     for _ in range(30):
         match_batch()
     ctx.synchronize()
-    ctx.timing_enable(capi.K["MNN_GEMM_SEG"])
-    for _ in range(max(20, args.match_iters // P)):
-        match_batch()
-    ctx.synchronize()
-    n_seg, ms_seg = ctx.timing_read()
-    ctx.timing_enable(0)
     bk = bcnt.download(np.int32, P)
     batch_lists = [(bout.download(np.int32, int(bk[k]), k * 12 * nf), bout.download(np.int32, int(bk[k]), k * 12 * nf + 4 * nf),
                     bout.download(np.float32, int(bk[k]), k * 12 * nf + 8 * nf)) for k in range(P)]
@@ -778,7 +772,11 @@ def legs(out, args, lib, capi, synth, Context, ctx, blob, frames, d_in, d_recb, 
         same = same and nk == int(bk[k]) and np.array_equal(mout.download(np.int32, nk), batch_lists[k][0]) and \
             np.array_equal(mout.download(np.int32, nk, 4 * nf), batch_lists[k][1]) and np.array_equal(mout.download(np.float32, nk, 8 * nf), batch_lists[k][2])
     c_bat, c_seg = C.c_double(0.0), C.c_double(0.0)
+    # whole calls back to back from a C loop (no foreign-function gap between the calls), the GEMM's dispatches carrying HIP events
+    ctx.timing_enable(capi.K["MNN_GEMM_SEG"])
     capi.check(lib.xfh_bench_match_batch(ctx.h, P, t_img1, t_n, t_img2, t_n, -1.0, t_i1, t_i2, t_ds, bcnt.ptr, max(20, args.match_iters // P), C.byref(c_bat)), ctx.h)
+    n_seg, ms_seg = ctx.timing_read()
+    ctx.timing_enable(0)
     sclk_in = C.c_double(0.0)
     capi.check(lib.xfh_bench_mnn_gemm_batch(ctx.h, P, t_img1, t_n, t_img2, t_n, 100, C.byref(c_seg), C.byref(sclk_in)), ctx.h)
     sclk, cpm = C.c_double(0.0), C.c_double(0.0)
@@ -795,7 +793,8 @@ def legs(out, args, lib, capi, synth, Context, ctx, blob, frames, d_in, d_recb, 
         "roofline": {"kernel": "k_mnn_gemm_seg", "bound": "mfma", "achieved": seg_flop / (seg_us * 1e-6) / 1e12 if n_seg else 0.0, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": seg_flop / (seg_us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS if n_seg else 0.0, "mfma_busy": pmc_busy("k_mnn_gemm_seg"), "mfma_busy_source": PMC_BUSY_SRC,
                      "avg_launch_us": seg_us, "launches": n_seg, "flops_per_launch": seg_flop,
-                     "measured": "HIP events attached to every dispatch of the kernel inside the loop of batched calls (the rocprofv3 --kernel-trace view)",
+                     "measured": "HIP events attached to every dispatch of the kernel inside the C loop of batched calls (xfh_bench_match_batch: GEMM, post, GEMM, post, ... back to back; "
+                                 "the rocprofv3 --kernel-trace view)",
                      "steady_state": {"wall_us_per_launch": c_seg.value, "frac": seg_flop / (c_seg.value * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS,
                                       "measured": "xfh_bench_mnn_gemm_batch: 100 launches of the kernel alone back to back, wall time between two stream events / 100"}}}
     # the clock the f32 MFMA peak is priced at (2.4 GHz -> 157.3 TFLOP/s) is not the clock the GPU holds under this load
