@@ -12,13 +12,15 @@
 //     (global_load_lds_dwordx4: the global image IS the LDS image) while the current tile's MFMAs run;
 //   * the 8 waves are two GROUPS of four, one wave of each per SIMD: group X owns the d2 rows 0..127 of every panel, group Y
 //     the rows 128..255 (own half of each buffer, own DMAs, own epilogue scratch).  With SKEW the groups run half a tile apart:
-//     while X's waves issue the MFMAs of tile s (alone on the matrix pipe, 256 MFMAs back to back), Y's waves are in the
-//     epilogue of tile s-1 -- LDS transposition, barrier waits, key stores -- and vice versa: the epilogue's latency hides
-//     behind the other group's matrix work (its ~190 VALU instructions still share the vector pipe).  Both groups execute the
-//     same number of s_barriers (a barrier closes every half-tile phase), so one WG-wide barrier serves both;
-//   * arg-max level 1 as in k_mnn_gemm_img (value maxima only, v_max3), but the d1-row keys stay in a register across the
-//     tiles of a d1 panel (one u64 per lane: lane <-> d1 row) and go to the row's key plane once, and the d2-row keys are
-//     merged across the group's waves from VALUES in LDS (no packing / shuffling per lane and tile).
+//     while X's waves issue the MFMAs of tile s, Y's waves are in the epilogue of tile s-1 -- LDS transposition, barrier waits,
+//     key stores -- and vice versa.  On gfx950 the f32 MFMA and the VALU are ONE pipe (tools/probes/pipe_probe.hip,
+//     profiles/r04_pipe_probe.log: a plain VALU instruction costs its full time in the same wave, and the other wave's VALU
+//     instructions starve while MFMAs are ready), so this hides the epilogue's LATENCY, not its ~300 VALU instructions; it is
+//     worth 133 us against 137-147 in lockstep at 8 pairs.  Both groups execute the same number of s_barriers (a barrier closes
+//     every half-tile phase), so one WG-wide barrier serves both;
+//   * arg-max level 1 as in k_mnn_gemm_img (value maxima only, v_max3), but the d1-row result stays in registers across the
+//     tiles of a d1 panel (a running (value, d2 row group) per lane: lane <-> d1 row) and goes to the row's key plane once, and
+//     the d2-row maxima are merged across the group's waves from VALUES in LDS (no key packing / 64-bit shuffles per lane and tile).
 //
 //   planes: partC[d1 panel][d2 row]  (as before), partR[2 * (w - w_first(row panel)) + group][d1 row]; k_mnn_post derives the
 //   number of planes of a d1 panel from (T, G, tile0, P2) with the same integer arithmetic (mnn_seg_plan.h).
@@ -30,7 +32,7 @@
 #define MNN_SEG_CV_PITCH 272                      // floats per row of the column-value scratch (h = 1 lanes land 32 banks away)
 #define MNN_SEG_LDS_FLOATS (2 * MNN_PANEL_FLOATS + 16 * MNN_SEG_CV_PITCH)
 
-template <int SKEW, int DBG = 0>                  // DBG (probes only): 1 = no epilogue (timing), 2 = phase stamps of workgroup 0, 3 = HW_ID per wave (both into job 0's partR)
+template <int SKEW, int DBG = 0>                  // DBG (probes only): 1 = no epilogue (timing), 2 = phase stamps of workgroup 0, 3 = HW_ID per wave (into job 0's partR)
 __global__ __launch_bounds__(512, 2)
 void k_mnn_gemm_seg(const MnnBatch jb) {
     __shared__ __attribute__((aligned(1024))) float smem[MNN_SEG_LDS_FLOATS];   // two d2 panel buffers, column-value scratch
