@@ -291,11 +291,22 @@ def test_running_folded_mode(gpu_lib, oracle_mod):
     from xfeatslam_amd.extractor import Context
     w = WT.make_synthetic(1234, 6.0, with_bn=True)
     blob = WT.pack_blob(w)
-    for B, H, W in ((2, 160, 224), (12, 96, 128)):                     # consumer-fold regime and persistent-kernel regime
+    for B, H, W in ((2, 160, 224), (12, 96, 128), (1, 480, 640)):      # batches <= 8 (riders, single-frame tiles, three-stage head chain), persistent-kernel regime, one VGA frame
         fr = synth.frames(B, H, W, seed=5)
         ctx = Context(nfeatures=512, max_height=H, max_width=W, max_batch=B, bn_mode=2)
         ctx.load_weights(blob)
         recs = ctx.extract_batch(fr, (0, 100))
+        if B <= 8:
+            # the same frames as the head of a 12-frame batch: other kernels and tilings (two streams instead of riders, k_conv_mfma_p / k_chain1x1<2>
+            # instead of the single-frame forms), the same accumulation order per output -- identical records
+            big = Context(nfeatures=512, max_height=H, max_width=W, max_batch=12, bn_mode=2)
+            big.load_weights(blob)
+            recs12 = big.extract_batch(np.concatenate([fr, synth.frames(12 - B, H, W, seed=77)]), (0, 100))
+            big.close()
+            for b in range(B):
+                for f in recs[b][0].dtype.names:
+                    assert np.array_equal(recs[b][0][f], recs12[b][0][f]), (B, b, f)
+                assert np.array_equal(recs[b][1], recs12[b][1]) and recs[b][2:4] == recs12[b][2:4], (B, b)
         ctx1 = Context(nfeatures=512, max_height=H, max_width=W, max_batch=B, bn_mode=1)
         ctx1.load_weights(blob)
         recs1 = ctx1.extract_batch(fr, (0, 100))

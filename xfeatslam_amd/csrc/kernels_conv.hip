@@ -741,15 +741,16 @@ void k_conv_mfma(ConvArgs a) {
 // that the host's 150 tiles leave idle.  Host and rider never touch each other's tensors.  256 threads: the kp4 rider uses the first 128
 // (the other two waves leave at once; a terminated wave does not take part in s_barrier).
 enum { RIDE_UNFOLD = 0 /* keypoint_head.0 */, RIDE_BN = 1 /* keypoint_head.1 / .2 */, RIDE_KP4 = 2 /* keypoint_head.3 + softmax */ };
-template <int CIN, int COUT, int KS, int ST, int WM, int WN, int NT, int WW, int PRO, int CBMAX, int TPC, int RIDER>
+// EPI: EPI_STATS (batch statistics / eval() statistics from the weight file) or EPI_BIAS_RELU (folded BatchNorms) for host and rider alike.
+template <int CIN, int COUT, int KS, int ST, int WM, int WN, int NT, int WW, int PRO, int CBMAX, int TPC, int RIDER, int EPI = EPI_STATS>
 __global__ __launch_bounds__(256)
 void k_conv_mfma_ride(ConvArgs a, int n_host, ConvArgs r, Kp4Args k) {
     static_assert(WM * WN == 4, "256 threads");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int blk = blockIdx.x;
-    if (blk < n_host) conv_mfma_body<CIN, COUT, KS, ST, WM, WN, NT, WW, PRO, EPI_STATS, CBMAX, TPC>(a, blk, blockIdx.z, smem);
+    if (blk < n_host) conv_mfma_body<CIN, COUT, KS, ST, WM, WN, NT, WW, PRO, EPI, CBMAX, TPC>(a, blk, blockIdx.z, smem);
     else if constexpr (RIDER == RIDE_KP4) { if (threadIdx.x < 4 * HK4_PX) heads_kp4_body(k, blk - n_host, blockIdx.z, smem); }
-    else conv_mfma_body<64, 64, 1, 1, 4, 1, 2, 16, RIDER == RIDE_UNFOLD ? PRO_UNFOLD : PRO_BN, EPI_STATS>(r, blk - n_host, blockIdx.z, smem);
+    else conv_mfma_body<64, 64, 1, 1, 4, 1, 2, 16, RIDER == RIDE_UNFOLD ? PRO_UNFOLD : PRO_BN, EPI>(r, blk - n_host, blockIdx.z, smem);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1362,9 +1363,9 @@ void k_conv_mfma16(ConvArgs a) {
 
 // ------------------------------------------------------------------------------------
 // k_chain1x1: consecutive 1x1 convolutions 64 -> 64 at 1/8 resolution in ONE pass over the pixels, wherever nothing but a bias
-// (and a ReLU) separates them.  In use: block_fusion.2 -> heatmap_head.0 (fusion.2 is a bare Conv2d, XFeat.cc:75) for B > 8 in
-// every BatchNorm mode; the template also covers three stages and bias+ReLU hand-overs (the folded-BatchNorm head chains), which
-// were measured and are not instantiated (launch_fusion_chain).  Persistent like k_conv_mfma_p (same tiles, same K order, hence
+// (and a ReLU) separates them.  In use: block_fusion.2 -> heatmap_head.0 (fusion.2 is a bare Conv2d, XFeat.cc:75) in
+// every BatchNorm mode and batch size, and block_fusion.2 -> heatmap_head.0 -> heatmap_head.1 (bias+ReLU hand-over) for batches <= 8 with
+// folded BatchNorms, where a launch is mostly fixed cost; the three-stage chains measured slower at 256 frames (launch_fusion_chain).  Persistent like k_conv_mfma_p (same tiles, same K order, hence
 // the same bits per layer); the output of a stage goes from the MFMA's C/D layout (lane = channel, registers = pixels) straight
 // back into the wave's own 32 pixel rows of the LDS tile in the A-operand layout (k-permuted channels) -- a 1x1 convolution needs
 // no other wave's pixels, so there is no barrier between the stages and the handed-on map is not read back from HBM.
@@ -1375,7 +1376,9 @@ struct ChainArgs {
     const float* w2; const float* bias2;      // stage 2 (NL == 3)
     float* mid_out; size_t mid_stride;        // MID_BIAS_STORE: where stage 0's map is stored
 };
-template <int NL, int WM, int PRO, int MID0, int EPI>
+// SSTAT (batches <= 8): the producer's statistics are staged in LDS per frame -- folded from its partials by this workgroup when no
+// k_bn_finalize runs (stage_stat) -- instead of being read from the finalized slots.
+template <int NL, int WM, int PRO, int MID0, int EPI, bool SSTAT = false>
 __global__ __launch_bounds__(64 * WM)
 void k_chain1x1(ChainArgs ca, int ntile, int total) {
     constexpr int CIN = 64, COUT = 64, NT = 2, WW = 16, WH = 2, TH = WM * WH, TW = WW;
@@ -1389,6 +1392,9 @@ void k_chain1x1(ChainArgs ca, int ntile, int total) {
     float* s_in = smem;
     float* s_w = smem + IN_FLOATS;               // NL weight matrices
     double* s_red = (double*)(s_w + NL * W_FLOATS);
+    float* s_stat = (float*)(s_red + WM * COUTP * 2);      // SSTAT: mean[64], rstd[64] of the current frame
+    static_assert(!SSTAT || sizeof(double) * 512 <= sizeof(float) * IN_FLOATS, "bn_fold scratch in the input tile");
+    int stat_b = -1;
 
     const int t = threadIdx.x;
     {
@@ -1424,7 +1430,11 @@ void k_chain1x1(ChainArgs ca, int ntile, int total) {
     auto store_tile = [&](int tile) {
         f32x4 m0, m1, r0, r1;
         if constexpr (PRO == PRO_BN) {
-            const float* st = a.st.stat + (size_t)(tile / ntile) * 2 * CIN + g * 8;
+            if constexpr (SSTAT) {                          // (s_in is free here: the previous tile's last reader is behind a barrier)
+                const int b = tile / ntile;
+                if (b != stat_b) { stage_stat<16>(a.st, b, CIN, tile - b * ntile == 0, s_stat, (double*)s_in, t, NTHR); stat_b = b; }
+            }
+            const float* st = SSTAT ? s_stat + g * 8 : a.st.stat + (size_t)(tile / ntile) * 2 * CIN + g * 8;
             m0 = *(const f32x4*)st; m1 = *(const f32x4*)(st + 4); r0 = *(const f32x4*)(st + CIN); r1 = *(const f32x4*)(st + CIN + 4);
         }
 #pragma unroll
@@ -1845,7 +1855,7 @@ static ConvArgs stats_layer_args(xfh_ctx* c, int li, const float* in, size_t in_
     c->npart[li] = *ntile;
     return a;
 }
-template <int CIN, int COUT, int KS, int ST, int WM, int WN, int NT, int WW, int PRO, int CBMAX, int TPC, int RIDER>
+template <int CIN, int COUT, int KS, int ST, int WM, int WN, int NT, int WW, int PRO, int CBMAX, int TPC, int RIDER, int EPI = EPI_STATS>
 static hipError_t ride_launch(xfh_ctx* c, const ConvArgs& a, int n_host, const ConvArgs& r, const Kp4Args& k, int n_rider, int B, int layer) {
     constexpr int WH = 32 / WW, TH = WM * WH, TW = WW, COUTP = WN * NT * 32;
     constexpr int TIH = (TH - 1) * ST + KS, TIW = (TW - 1) * ST + KS;
@@ -1858,12 +1868,12 @@ static hipError_t ride_launch(xfh_ctx* c, const ConvArgs& a, int n_host, const C
     constexpr size_t LDS = LDS_HOST > LDS_RIDER ? LDS_HOST : LDS_RIDER;
     static_assert(LDS <= 160 * 1024, "LDS budget");
     static_assert(sizeof(double) * WM * COUTP * 2 <= LDS_HOST && sizeof(double) * 512 <= sizeof(float) * (size_t)TIH * TIW * (CIN + 4), "scratch");
-    auto kern = k_conv_mfma_ride<CIN, COUT, KS, ST, WM, WN, NT, WW, PRO, CBMAX, TPC, RIDER>;
+    auto kern = k_conv_mfma_ride<CIN, COUT, KS, ST, WM, WN, NT, WW, PRO, CBMAX, TPC, RIDER, EPI>;
     XFH_SET_LDS_ATTR_ONCE(c, kern, LDS);
     launch_k(c, XFH_K_CONV_MFMA, layer, kern, dim3(n_host + n_rider, 1, B), dim3(256), LDS, a, n_host, r, k);
     return hipGetLastError();
 }
-bool ride_mode(const xfh_ctx* c, int B) { return consumer_fold(B) && c->cfg.bn_mode != XFH_BN_RUNNING_FOLDED && !c->no_ride; }      // (A/B on one box: +9.5 % at 2 frames, +5.5 % at 4, even at 8)
+bool ride_mode(const xfh_ctx* c, int B) { return consumer_fold(B) && !c->no_ride; }      // (A/B on one box: +9.5 % at 2 frames, +5.5 % at 4, even at 8)
 // host: BasicLayer li in 3 .. 6 (block1.3, block2.0, block2.1, block3.0); rider: step li - 3 of the keypoint branch
 hipError_t launch_layer_with_rider(xfh_ctx* c, int li, const float* in, size_t in_stride, int src, int pro, int Hin, int Win, int B,
                                    const float* K1h, size_t k1h_stride) {
@@ -1871,26 +1881,31 @@ hipError_t launch_layer_with_rider(xfh_ctx* c, int li, const float* in, size_t i
     const size_t xs = (size_t)c->Hmax * c->Wmax;
     int nh = 0, nr = 0;
     ConvArgs r{}; Kp4Args k{};
+    const bool folded = c->cfg.bn_mode == XFH_BN_RUNNING_FOLDED;       // folded BatchNorms: relu(. + bias) in the epilogue of host and rider, no statistics
     switch (li) {
         case 3: {
             ConvArgs a = stats_layer_args(c, li, in, in_stride, src, pro, Hin, Win, B, 8, 16, &nh); a.w = c->w.alt[li];
             r = stats_layer_args(c, 20, c->X, xs, -1, PRO_UNFOLD, h8, w8, B, 8, 16, &nr);
+            if (folded) { a.bias = c->w.bn_bias[li]; r.bias = c->w.bn_bias[20]; return ride_launch<8, 24, 3, 2, 4, 1, 1, 16, PRO_BN, 64, 9, RIDE_UNFOLD, EPI_BIAS_RELU>(c, a, nh, r, k, nr, B, li); }
             return ride_launch<8, 24, 3, 2, 4, 1, 1, 16, PRO_BN, 64, 9, RIDE_UNFOLD>(c, a, nh, r, k, nr, B, li);
         }
         case 4: {
             ConvArgs a = stats_layer_args(c, li, in, in_stride, src, pro, Hin, Win, B, 8, 16, &nh); a.w = c->w.alt[li];
             r = stats_layer_args(c, 21, c->raw[20], c->raw_stride[20], 20, PRO_BN, h8, w8, B, 8, 16, &nr);
+            if (folded) { a.bias = c->w.bn_bias[li]; r.bias = c->w.bn_bias[21]; return ride_launch<24, 24, 3, 1, 4, 1, 1, 16, PRO_B2IN, 64, 9, RIDE_BN, EPI_BIAS_RELU>(c, a, nh, r, k, nr, B, li); }
             return ride_launch<24, 24, 3, 1, 4, 1, 1, 16, PRO_B2IN, 64, 9, RIDE_BN>(c, a, nh, r, k, nr, B, li);
         }
         case 5: {
             ConvArgs a = stats_layer_args(c, li, in, in_stride, src, pro, Hin, Win, B, 8, 16, &nh); a.w = c->w.alt[li];
             r = stats_layer_args(c, 22, c->raw[21], c->raw_stride[21], 21, PRO_BN, h8, w8, B, 8, 16, &nr);
+            if (folded) { a.bias = c->w.bn_bias[li]; r.bias = c->w.bn_bias[22]; return ride_launch<24, 24, 3, 1, 4, 1, 1, 16, PRO_BN, 64, 9, RIDE_BN, EPI_BIAS_RELU>(c, a, nh, r, k, nr, B, li); }
             return ride_launch<24, 24, 3, 1, 4, 1, 1, 16, PRO_BN, 64, 9, RIDE_BN>(c, a, nh, r, k, nr, B, li);
         }
         case 6: {
             ConvArgs a = stats_layer_args(c, li, in, in_stride, src, pro, Hin, Win, B, 8, 16, &nh); a.w = c->w.alt[li];
             k = Kp4Args{(const float*)c->raw[22], stat_src(c, 22, B), c->raw_stride[22], (const float*)c->w.kp3_w, (const float*)c->w.kp3_b, h8, w8, const_cast<float*>(K1h), k1h_stride};
             nr = (h8 * w8 + HK4_PX - 1) / HK4_PX;
+            if (folded) { a.bias = c->w.bn_bias[li]; return ride_launch<24, 64, 3, 2, 4, 1, 2, 16, PRO_BN, 64, 3, RIDE_KP4, EPI_BIAS_RELU>(c, a, nh, r, k, nr, B, li); }
             return ride_launch<24, 64, 3, 2, 4, 1, 2, 16, PRO_BN, 64, 3, RIDE_KP4>(c, a, nh, r, k, nr, B, li);
         }
         default: return hipErrorInvalidValue;
@@ -1916,28 +1931,17 @@ hipError_t launch_block1_stats(xfh_ctx* c, const StatSrc& xs, int H, int W, int 
     return hipGetLastError();
 }
 
-// block_fusion.2: Conv2d(64,64,1) with bias, no BN (src/XFeat.cc:75) -> feats
-hipError_t launch_fusion_out(xfh_ctx* c, int Hh, int Wh, int B) {
-    ConvArgs a{};
-    a.in = c->raw[17]; a.st = stat_src(c, 17, B); a.in_stride = c->raw_stride[17]; a.Hin = Hh; a.Win = Wh;
-    a.w = c->w.fus2; a.bias = c->w.fus2_bias;
-    a.out = c->feats; a.out_stride = c->raw_stride[17]; a.Hout = Hh; a.Wout = Wh;
-    a.part = nullptr; a.part_stride = 0;
-    if (persistent(B)) return conv_mfma_p_launch<64, 64, 1, 1, 4, 1, 2, 16, PRO_BN, EPI_BIAS>(c, a, B, nullptr, 23);
-    return conv_mfma_launch<64, 64, 1, 1, 4, 1, 2, 16, PRO_BN, EPI_BIAS>(c, a, B, nullptr, 23);
-}
-
 // ---- chains of 1x1 layers (k_chain1x1) ----------------------------------------------------------
-template <int NL, int WM, int PRO, int MID0, int EPI>
+template <int NL, int WM, int PRO, int MID0, int EPI, bool SSTAT = false>
 static hipError_t chain_launch(xfh_ctx* c, const ChainArgs& ca, int B, int* npart_out, int layer) {
     constexpr int TH = 2 * WM, TW = 16;
-    constexpr size_t LDS = sizeof(float) * ((size_t)TH * TW * 68 + (size_t)NL * 64 * 68) + sizeof(double) * WM * 64 * 2;
+    constexpr size_t LDS = sizeof(float) * ((size_t)TH * TW * 68 + (size_t)NL * 64 * 68 + (SSTAT ? 128 : 0)) + sizeof(double) * WM * 64 * 2;
     static_assert(LDS <= 160 * 1024, "LDS budget");
     ChainArgs aa = ca;
     aa.a.tiles_x = (ca.a.Wout + TW - 1) / TW;
     const int ntile = aa.a.tiles_x * ((ca.a.Hout + TH - 1) / TH);
     if (npart_out) *npart_out = ntile;
-    auto kern = k_chain1x1<NL, WM, PRO, MID0, EPI>;
+    auto kern = k_chain1x1<NL, WM, PRO, MID0, EPI, SSTAT>;
     XFH_SET_LDS_ATTR_ONCE(c, kern, LDS);
     const int total = ntile * B;
     const int per_cu = (int)((160 * 1024) / LDS);
@@ -1950,7 +1954,6 @@ static hipError_t chain_launch(xfh_ctx* c, const ChainArgs& ca, int B, int* npar
 // (fusion.2 is a bare Conv2d), heatmap_head.1 too when the BatchNorms are folded.  *done = number of head layers computed.
 hipError_t launch_fusion_chain(xfh_ctx* c, int Hh, int Wh, int B, int* done) {
     *done = 0;
-    if (!persistent(B)) return launch_fusion_out(c, Hh, Wh, B);
     const bool folded = c->cfg.bn_mode == XFH_BN_RUNNING_FOLDED;
     ChainArgs ca{};
     ConvArgs& a = ca.a;
@@ -1960,6 +1963,27 @@ hipError_t launch_fusion_chain(xfh_ctx* c, int Hh, int Wh, int B, int* done) {
     ca.w1 = c->w.mfma[18];
     int np = 0;
     hipError_t e;
+    if (!persistent(B) && folded) {
+        // folded BatchNorms, batches <= 8: block_fusion.2 -> heatmap_head.0 -> heatmap_head.1 in ONE launch.  A launch of one frame's 40 tiles is
+        // 7-10 us of mostly fixed time (boundary, weights, ramp); the three-stage form that loses 3 % at 256 frames (below) saves two of them here
+        ca.bias1 = c->w.bn_bias[18]; ca.w2 = c->w.mfma[19]; ca.bias2 = c->w.bn_bias[19];
+        a.out = c->raw[19]; a.out_stride = c->raw_stride[19];
+        e = chain_launch<3, 4, PRO_BN, MID_BIAS_STORE, EPI_BIAS_RELU>(c, ca, B, &np, 19);
+        if (e != hipSuccess) return e;
+        c->lh[18] = Hh; c->lw[18] = Wh; c->npart[18] = np; c->lh[19] = Hh; c->lw[19] = Wh; c->npart[19] = np;
+        *done = 2;
+        return hipSuccess;
+    }
+    if (consumer_fold(B)) {
+        // batches <= 8, BatchNorm statistics per frame or from the weight file: block_fusion.2 -> heatmap_head.0 in one launch as for B > 8,
+        // the statistics of block_fusion.1 folded from its partials by each workgroup like every other consumer of this regime does
+        a.out = c->raw[18]; a.out_stride = c->raw_stride[18]; a.part = c->part[18]; a.part_stride = c->part_stride[18];
+        e = chain_launch<2, 4, PRO_BN, MID_BIAS_STORE, EPI_STATS, true>(c, ca, B, &np, 18);
+        if (e != hipSuccess) return e;
+        c->lh[18] = Hh; c->lw[18] = Wh; c->npart[18] = np;
+        *done = 1;
+        return hipSuccess;
+    }
     if (!folded) {
         a.out = c->raw[18]; a.out_stride = c->raw_stride[18]; a.part = c->part[18]; a.part_stride = c->part_stride[18];
         e = chain_launch<2, 4, PRO_BN, MID_BIAS_STORE, EPI_STATS>(c, ca, B, &np, 18);

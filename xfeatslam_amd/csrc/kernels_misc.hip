@@ -899,7 +899,6 @@ void k_desc(const float* __restrict__ feats, size_t m_stride, const float* __res
 // ---------------------------------------------------------------------------------------------
 // pipeline
 hipError_t launch_basic_layer(xfh_ctx* c, int li, const float* in, size_t in_stride, int src, int pro, int Hin, int Win, int B);
-hipError_t launch_fusion_out(xfh_ctx* c, int Hh, int Wh, int B);
 hipError_t launch_block1_stats(xfh_ctx* c, const StatSrc& xs, int H, int W, int B);
 hipError_t launch_fusion_chain(xfh_ctx* c, int Hh, int Wh, int B, int* done);
 hipError_t launch_finalize_image(xfh_ctx* c, int B, int npart, double count);
@@ -994,7 +993,7 @@ hipError_t run_extract(xfh_ctx* c, const uint8_t* d_gray, int B, int H0, int W0,
     // pyramid fusion: block_fusion.0 builds x3 + up2(x4) + up4(x5) while staging
     CK(launch_basic_layer(c, 16, c->raw[8], c->raw_stride[8], 8, PRO_FUSE, h8, w8, B));
     CK(launch_basic_layer(c, 17, c->raw[16], c->raw_stride[16], 16, PRO_BN, h8, w8, B));
-    // block_fusion.2 and the heatmap head; for B > 8 fusion.2 and heatmap_head.0 (no BatchNorm between them) are one kernel
+    // block_fusion.2 and the heatmap head: fusion.2 and heatmap_head.0 (no BatchNorm between them) are one kernel, with folded BatchNorms and B <= 8 heatmap_head.1 too
     int head_done = 0;
     CK(launch_fusion_chain(c, h8, w8, B, &head_done));
     if (head_done < 1) CK(launch_basic_layer(c, 18, c->feats, c->raw_stride[17], -1, PRO_PLAIN, h8, w8, B));
