@@ -8,7 +8,8 @@ from xfeatslam_amd.extractor import Context
 lib = capi.lib()
 H, W = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (480, 640)
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 300
-ctx = Context(nfeatures=4096, max_height=H, max_width=W, max_batch=1); ctx.load_weights(WT.pack_blob(WT.make_synthetic(1234, 3.0)))
+MODE = int(os.environ.get("B1_MODE", "0"))      # BatchNorm mode: 0 batch statistics, 1 eval() statistics, 2 folded
+ctx = Context(nfeatures=4096, max_height=H, max_width=W, max_batch=1, bn_mode=MODE); ctx.load_weights(WT.pack_blob(WT.make_synthetic(1234, 3.0, with_bn=MODE != 0)))
 fr = synth.frames(1, H, W, seed=42)
 din = capi.DeviceBuffer(fr.nbytes).upload(fr); rec = capi.DeviceBuffer(ctx.rec_bytes)
 for _ in range(20): capi.check(lib.xfh_extract_batch_device(ctx.h, din.ptr, 1, H, W, 0, 0, rec.ptr), ctx.h)
