@@ -1761,7 +1761,7 @@ static hipError_t launch_basic_layer_t(xfh_ctx* c, int li, const float* in, size
         case 7: case 17: case 16:
             // the dominant 3x3 64->64 instance: 8x16 pixels x 64 channels per workgroup, 8 waves (4 x 2), 32-channel weight
             // chunks (67 KB LDS -> 2 workgroups per CU); measured 70 us vs 77 us for the 4-wave / 64-channel-chunk form at
-            // B = 16 (profiles/r01_conv_cfg.log).  Single frame: 2x16 pixels per workgroup, 2 waves, three taps per chunk.
+            // B = 16 (profiles/r01_conv_cfg.log); 6x16 / 10x16 pixels on 6 / 10 waves (no wasted rows at VGA) 770 -> 959 / 888 us at B = 256 (round 4).  Single frame: 2x16 pixels per workgroup, 2 waves, three taps per chunk.
             // block_fusion.0 (16) builds its input x3 + up2(x4) + up4(x5) while staging.
             if (small_batch(B)) {
                 a.w = c->w.m16[li];
