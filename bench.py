@@ -655,15 +655,25 @@ def legs(out, args, lib, capi, synth, Context, ctx, blob, frames, d_in, d_recb, 
 
     def match():
         capi.check(lib.xfh_match_mnn_device(ctx.h, d1p, nf, d2p, nf, -1.0, *mo), ctx.h)
-    for _ in range(300):            # the clocks settle over a few hundred of these ~30 us calls
-        match()
-    ctx.synchronize()
-    ctx.timing_enable(capi.K["MNN_GEMM"])
+    # The GPU needs ~20 ms of continuous load to reach the clock it then holds (tools/gemm_b2b.py: the same 300 GEMM launches read 0.67, 0.70, 0.73,
+    # 0.743, 0.743, ... of the peak in consecutive 6-ms windows after a pause), and every leg below starts after host-side work during which the
+    # GPU was idle.  So each measured loop is preceded by WARM_MS of the SAME calls from a C loop (no foreign-function gaps), untimed.
+    WARM_MS = 60.0
+    c_warm = C.c_double(0.0)
+
+    def warm_raw():
+        capi.check(lib.xfh_bench_match_raw(ctx.h, d1p, nf, d2p, nf, -1.0, *mo, int(WARM_MS * 1e3 / 32.0), C.byref(c_warm)), ctx.h)
+    warm_raw()
     t0 = time.perf_counter()
     for _ in range(args.match_iters):
         match()
     ctx.synchronize()
     match_dt = (time.perf_counter() - t0) / args.match_iters
+    warm_raw()
+    c_raw = C.c_double(0.0)
+    capi.check(lib.xfh_bench_match_raw(ctx.h, d1p, nf, d2p, nf, -1.0, *mo, max(args.match_iters, 50), C.byref(c_raw)), ctx.h)       # wall time per call, no events on the dispatches
+    ctx.timing_enable(capi.K["MNN_GEMM"])
+    capi.check(lib.xfh_bench_match_raw(ctx.h, d1p, nf, d2p, nf, -1.0, *mo, max(args.match_iters, 50), C.byref(c_warm)), ctx.h)      # the same loop with an event pair on every GEMM dispatch
     n_gemm, ms_gemm = ctx.timing_read()
     ctx.timing_enable(0)
     n_matches = int(mout.download(np.int32, 1, 12 * nf)[0])
@@ -685,25 +695,28 @@ def legs(out, args, lib, capi, synth, Context, ctx, blob, frames, d_in, d_recb, 
         hand1, hand2 = imgs.ptr, imgs.ptr + ib
     else:
         hand1, hand2 = img1.ptr, img2.ptr
-    c_prep, c_raw = C.c_double(0.0), C.c_double(0.0)
-    capi.check(lib.xfh_bench_match_prepared(ctx.h, hand1, nf, hand2, nf, -1.0, *mo, max(args.match_iters, 50), C.byref(c_prep)), ctx.h)
+    c_prep = C.c_double(0.0)
+
+    def warm_prepared():
+        capi.check(lib.xfh_bench_match_prepared(ctx.h, hand1, nf, hand2, nf, -1.0, *mo, int(WARM_MS * 1e3 / 27.0), C.byref(c_warm)), ctx.h)
+    # the hand-off call from a C loop, its GEMM dispatches carrying HIP events (GEMM, post, GEMM, post, ... back to back)
+    warm_prepared()
+    capi.check(lib.xfh_bench_match_prepared(ctx.h, hand1, nf, hand2, nf, -1.0, *mo, max(args.match_iters, 50), C.byref(c_prep)), ctx.h)   # wall time per call, no events on the dispatches
+    ctx.timing_enable(capi.K["MNN_GEMM"])
+    capi.check(lib.xfh_bench_match_prepared(ctx.h, hand1, nf, hand2, nf, -1.0, *mo, max(args.match_iters, 50), C.byref(c_warm)), ctx.h)   # the same loop with an event pair on every GEMM dispatch
+    n_gemm_p, ms_gemm_p = ctx.timing_read()
+    ctx.timing_enable(0)
     n_matches_h = int(mout.download(np.int32, 1, 12 * nf)[0])
     hh = (mout.download(np.int32, n_matches_h), mout.download(np.int32, n_matches_h, 4 * nf))
-    capi.check(lib.xfh_bench_match_raw(ctx.h, d1p, nf, d2p, nf, -1.0, *mo, max(args.match_iters, 50), C.byref(c_raw)), ctx.h)
 
     def match_prepared():
         capi.check(lib.xfh_match_mnn_prepared_device(ctx.h, img1.ptr, nf, img2.ptr, nf, -1.0, *mo), ctx.h)
-    for _ in range(100):
-        match_prepared()
-    ctx.synchronize()
-    ctx.timing_enable(capi.K["MNN_GEMM"])
+    warm_prepared()
     t0 = time.perf_counter()
     for _ in range(args.match_iters):
         match_prepared()
     ctx.synchronize()
     prep_dt = (time.perf_counter() - t0) / args.match_iters
-    n_gemm_p, ms_gemm_p = ctx.timing_read()
-    ctx.timing_enable(0)
     n_matches_p = int(mout.download(np.int32, 1, 12 * nf)[0])
     hp = (mout.download(np.int32, n_matches_p), mout.download(np.int32, n_matches_p, 4 * nf))
     # host API
@@ -717,11 +730,16 @@ def legs(out, args, lib, capi, synth, Context, ctx, blob, frames, d_in, d_recb, 
         ctx.match_mnn(d1h, d2h)
     host_match_dt = (time.perf_counter() - t0) / 50
     gemm_b2b = C.c_double(0.0)
-    capi.check(lib.xfh_bench_mnn_gemm(ctx.h, img1.ptr, nf, img2.ptr, nf, 300, C.byref(gemm_b2b)), ctx.h)
+    gemm_b2b_windows = []
+    for _ in range(12):                                     # consecutive windows of 300 launches; the last one is reported (the list shows the ramp)
+        capi.check(lib.xfh_bench_mnn_gemm(ctx.h, img1.ptr, nf, img2.ptr, nf, 300, C.byref(gemm_b2b)), ctx.h)
+        gemm_b2b_windows.append(round(gemm_b2b.value, 2))
     gemm_us_raw = ms_gemm / max(n_gemm, 1) * 1e3
-    gemm_us = ms_gemm_p / max(n_gemm_p, 1) * 1e3
-    gemm_tf = 2.0 * nf * nf * 64 / (gemm_us * 1e-6) / 1e12 if n_gemm_p else 0.0
-    n_gemm = n_gemm_p
+    gemm_us_disp = ms_gemm_p / max(n_gemm_p, 1) * 1e3                  # per-dispatch events inside the hand-off call loop
+    gemm_us = gemm_b2b.value                                            # HIP events around a region of 300 back-to-back launches / 300 (last window)
+    gemm_flop = 2.0 * nf * nf * 64
+    gemm_tf = gemm_flop / (gemm_us * 1e-6) / 1e12 if gemm_us else 0.0
+    n_gemm = 300
     out["match"] = {"pairs_per_s": nf * nf / (c_prep.value * 1e-6), "us_per_call": c_prep.value, "n1": nf, "n2": nf, "n_matches": n_matches_h,
                     "call": "device-resident hand-off: the two frames' prepared images come out of xfh_extract_batch_device_images, the match is "
                             "xfh_match_mnn_prepared_device (k_mnn_gemm_img + k_mnn_post), calls back to back from a C loop (xfh_bench_match_prepared: "
@@ -737,14 +755,20 @@ def legs(out, args, lib, capi, synth, Context, ctx, blob, frames, d_in, d_recb, 
                     "roofline": {"kernel": "k_mnn_gemm_img", "bound": "mfma", "achieved": gemm_tf, "peak": PEAK_F32_MFMA_TFLOPS,
                                  "unit": "TFLOP/s", "frac": gemm_tf / PEAK_F32_MFMA_TFLOPS,
                                  "traffic": (traffic or {}).get("gemm_bytes_per_launch"), "mfma_busy": pmc_busy("k_mnn_gemm_img"), "mfma_busy_source": PMC_BUSY_SRC, "avg_launch_us": gemm_us,
-                                 "launches": n_gemm, "flops_per_launch": 2.0 * nf * nf * 64,
-                                 "measured": "HIP events attached to every dispatch of the kernel inside the loop of two-launch calls on prepared images (the hand-off "
-                                             "call; the view rocprofv3 --kernel-trace gives.  In a busy stream these timestamps overlap the neighbouring kernels: "
-                                             "their sum exceeds the wall time, DESIGN.md 5)",
-                                 "in_raw_rows_call": {"avg_launch_us": gemm_us_raw, "frac": 2.0 * nf * nf * 64 / (gemm_us_raw * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS if gemm_us_raw else 0.0,
-                                                      "note": "the same events inside the three-launch loop (k_rownorm_img in front)"},
-                                 "steady_state": {"wall_us_per_launch": gemm_b2b.value, "frac": 2.0 * nf * nf * 64 / (gemm_b2b.value * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                                                  "measured": "xfh_bench_mnn_gemm: 300 launches of the kernel alone back to back, wall time between two stream events / 300"}}}
+                                 "launches": n_gemm, "flops_per_launch": gemm_flop, "windows_us": gemm_b2b_windows,
+                                 "measured": "two HIP events on the kernel's stream around a region of 300 launches of the kernel back to back (xfh_bench_mnn_gemm), elapsed / 300; "
+                                             "twelve such regions in a row (windows_us), the last one reported.  The GPU reaches the clock it then holds only after ~20 ms of "
+                                             "continuous load: the first windows after an idle gap read 0.67-0.70, the settled ones 0.74 (tools/gemm_b2b.py; rounds 1-3 timed this "
+                                             "kernel inside the ramp).  rocprofv3 --kernel-trace of the same loop gives the same average for the settled launches "
+                                             "(profiles/r04_gemm_b2b.md)",
+                                 "per_dispatch_events_in_call_loop": {
+                                     "avg_launch_us": gemm_us_disp, "frac": gemm_flop / (gemm_us_disp * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS if gemm_us_disp else 0.0, "launches": n_gemm_p,
+                                     "note": "an event pair attached to every GEMM dispatch (hipExtLaunchKernelGGL) inside the C loop of two-launch hand-off calls (GEMM, post, GEMM, post, ...), "
+                                             "after 60 ms of the same calls.  This view is longer than the kernel: the instrumented dispatch itself costs time (the same loop without the "
+                                             "events runs 4-5 us per call faster: us_per_call), and in a busy queue the timestamps of neighbouring dispatches overlap (their sum exceeds "
+                                             "the wall time, DESIGN.md 5).  Rounds 1-3 reported this figure, measured cold, as the roofline"},
+                                 "in_raw_rows_call": {"avg_launch_us": gemm_us_raw, "frac": gemm_flop / (gemm_us_raw * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS if gemm_us_raw else 0.0,
+                                                      "note": "per-dispatch events inside the C loop of three-launch calls (k_rownorm_img in front), same warm-up"}}}
 
     # ---- many pairs in one call: frame 0 against P partners (the tracker's frame against previous frame / key frames / loop candidates; the
     # reference calls ORBmatcher::match once per pair).  One persistent GEMM launch (k_mnn_gemm_seg) + one post launch for all pairs.
@@ -777,15 +801,21 @@ def legs(out, args, lib, capi, synth, Context, ctx, blob, frames, d_in, d_recb, 
             np.array_equal(mout.download(np.int32, nk, 4 * nf), batch_lists[k][1]) and np.array_equal(mout.download(np.float32, nk, 8 * nf), batch_lists[k][2])
     c_bat, c_seg = C.c_double(0.0), C.c_double(0.0)
     # whole calls back to back from a C loop (no foreign-function gap between the calls), the GEMM's dispatches carrying HIP events
+    capi.check(lib.xfh_bench_match_batch(ctx.h, P, t_img1, t_n, t_img2, t_n, -1.0, t_i1, t_i2, t_ds, bcnt.ptr, int(WARM_MS * 1e3 / (21.0 * P)) + 1, C.byref(c_warm)), ctx.h)   # warm-up (above)
+    capi.check(lib.xfh_bench_match_batch(ctx.h, P, t_img1, t_n, t_img2, t_n, -1.0, t_i1, t_i2, t_ds, bcnt.ptr, max(40, args.match_iters // P), C.byref(c_bat)), ctx.h)    # wall time per call, no events
     ctx.timing_enable(capi.K["MNN_GEMM_SEG"])
-    capi.check(lib.xfh_bench_match_batch(ctx.h, P, t_img1, t_n, t_img2, t_n, -1.0, t_i1, t_i2, t_ds, bcnt.ptr, max(20, args.match_iters // P), C.byref(c_bat)), ctx.h)
+    capi.check(lib.xfh_bench_match_batch(ctx.h, P, t_img1, t_n, t_img2, t_n, -1.0, t_i1, t_i2, t_ds, bcnt.ptr, max(40, args.match_iters // P), C.byref(c_warm)), ctx.h)   # with an event pair per GEMM dispatch
     n_seg, ms_seg = ctx.timing_read()
     ctx.timing_enable(0)
     sclk_in = C.c_double(0.0)
-    capi.check(lib.xfh_bench_mnn_gemm_batch(ctx.h, P, t_img1, t_n, t_img2, t_n, 100, C.byref(c_seg), C.byref(sclk_in)), ctx.h)
+    seg_windows = []
+    for _ in range(6):
+        capi.check(lib.xfh_bench_mnn_gemm_batch(ctx.h, P, t_img1, t_n, t_img2, t_n, 100, C.byref(c_seg), C.byref(sclk_in)), ctx.h)
+        seg_windows.append(round(c_seg.value, 2))
     sclk, cpm = C.c_double(0.0), C.c_double(0.0)
     capi.check(lib.xfh_bench_sclk(ctx.h, 4096, C.byref(sclk), C.byref(cpm)), ctx.h)
-    seg_us = ms_seg / max(n_seg, 1) * 1e3
+    seg_us_disp = ms_seg / max(n_seg, 1) * 1e3                           # per-dispatch events inside the call loop
+    seg_us = c_seg.value                                                # events around 100 back-to-back launches / 100 (last window)
     seg_flop = 2.0 * nf * nf * 64 * P
     peak_at_sclk = PEAK_F32_MFMA_TFLOPS * sclk_in.value / 2400.0         # 157.3 TFLOP/s = 256 CUs x 256 flop/clk x 2.4 GHz
     out["match"]["batched"] = {
@@ -794,18 +824,20 @@ def legs(out, args, lib, capi, synth, Context, ctx, blob, frames, d_in, d_recb, 
         "call": f"xfh_match_mnn_prepared_batch_device: frame 0's prepared image against the images of {P} partner frames (as written by xfh_extract_batch_device_images), "
                 "k_mnn_gemm_seg + k_mnn_post_batch, calls back to back from a C loop (xfh_bench_match_batch: wall time between two stream events / calls)",
         "pair_lists_equal_pair_by_pair_calls": bool(same),
-        "roofline": {"kernel": "k_mnn_gemm_seg", "bound": "mfma", "achieved": seg_flop / (seg_us * 1e-6) / 1e12 if n_seg else 0.0, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                     "frac": seg_flop / (seg_us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS if n_seg else 0.0, "mfma_busy": pmc_busy("k_mnn_gemm_seg"), "mfma_busy_source": PMC_BUSY_SRC,
-                     "avg_launch_us": seg_us, "launches": n_seg, "flops_per_launch": seg_flop,
-                     "measured": "HIP events attached to every dispatch of the kernel inside the C loop of batched calls (xfh_bench_match_batch: GEMM, post, GEMM, post, ... back to back; "
-                                 "the rocprofv3 --kernel-trace view)",
-                     "steady_state": {"wall_us_per_launch": c_seg.value, "frac": seg_flop / (c_seg.value * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                                      "measured": "xfh_bench_mnn_gemm_batch: 100 launches of the kernel alone back to back, wall time between two stream events / 100"}}}
+        "roofline": {"kernel": "k_mnn_gemm_seg", "bound": "mfma", "achieved": seg_flop / (seg_us * 1e-6) / 1e12 if seg_us else 0.0, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                     "frac": seg_flop / (seg_us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS if seg_us else 0.0, "mfma_busy": pmc_busy("k_mnn_gemm_seg"), "mfma_busy_source": PMC_BUSY_SRC,
+                     "avg_launch_us": seg_us, "launches": 100, "flops_per_launch": seg_flop, "windows_us": seg_windows,
+                     "measured": "two HIP events on the kernel's stream around a region of 100 launches of the kernel back to back (xfh_bench_mnn_gemm_batch), elapsed / 100; six such "
+                                 "regions in a row after 60 ms of batched calls (windows_us), the last one reported (clock ramp and method: match.roofline.measured)",
+                     "per_dispatch_events_in_call_loop": {
+                         "avg_launch_us": seg_us_disp, "frac": seg_flop / (seg_us_disp * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS if n_seg else 0.0, "launches": n_seg,
+                         "note": "an event pair attached to every GEMM dispatch inside the C loop of batched calls (xfh_bench_match_batch: GEMM, post, GEMM, post, ...): includes the "
+                                 "instrumented dispatch's own cost and the overlap of neighbouring timestamps (match.roofline.per_dispatch_events_in_call_loop)"}}}
     # the clock the f32 MFMA peak is priced at (2.4 GHz -> 157.3 TFLOP/s) is not the clock the GPU holds under this load
     out["match"]["sclk_under_f32_mfma_load"] = {
         "sclk_mhz": sclk_in.value, "sclk_mhz_mfma_loop_on_constant_operands": sclk.value, "cycles_per_mfma_oldest_wave": cpm.value, "peak_at_sclk_TFLOPs": peak_at_sclk,
         "frac_of_peak_at_sclk": {"k_mnn_gemm_img": gemm_tf / peak_at_sclk if peak_at_sclk else None,
-                                 "k_mnn_gemm_seg": seg_flop / (seg_us * 1e-6) / 1e12 / peak_at_sclk if (peak_at_sclk and n_seg) else None},
+                                 "k_mnn_gemm_seg": seg_flop / (seg_us * 1e-6) / 1e12 / peak_at_sclk if (peak_at_sclk and seg_us) else None},
         "measured": "sclk_mhz: shader clocks (s_memtime) per 100 MHz reference tick (s_memrealtime) that workgroup 0 of k_mnn_gemm_seg saw across one launch of the batched "
                     "GEMM (xfh_bench_mnn_gemm_batch); the second figure: xfh_bench_sclk, every SIMD issuing v_mfma_f32_32x32x2_f32 back to back on constant operands. "
                     "f32 MFMAs and VALU instructions share the SIMD's vector pipe on gfx950 (profiles/r04_pipe_probe.log), so the ceiling of the GEMM with its arg-max "
