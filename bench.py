@@ -125,6 +125,8 @@ def main():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--streams", type=int, default=4, help="sub-batches in flight per GPU (one ctx with its own HIP streams each)")
     ap.add_argument("--match-iters", type=int, default=300)
+    ap.add_argument("--match-warm-ms", type=float, default=60.0, help="untimed C-loop calls in front of every measured loop of the match leg (the GPU's clock settles "
+                                                                     "over ~20 ms of load); profiler passes that only count per launch set 0")
     ap.add_argument("--match-pairs", type=int, default=8, help="pairs of the batched match leg (frame 0 against this many partner frames in one call)")
     ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the bounded all-core CPU-baseline sample (0 = skip)")
     ap.add_argument("--gather", choices=["allgather", "root", "compact"], default="allgather",
@@ -658,7 +660,7 @@ def legs(out, args, lib, capi, synth, Context, ctx, blob, frames, d_in, d_recb, 
     # The GPU needs ~20 ms of continuous load to reach the clock it then holds (tools/gemm_b2b.py: the same 300 GEMM launches read 0.67, 0.70, 0.73,
     # 0.743, 0.743, ... of the peak in consecutive 6-ms windows after a pause), and every leg below starts after host-side work during which the
     # GPU was idle.  So each measured loop is preceded by WARM_MS of the SAME calls from a C loop (no foreign-function gaps), untimed.
-    WARM_MS = 60.0
+    WARM_MS = max(args.match_warm_ms, 0.5)
     c_warm = C.c_double(0.0)
 
     def warm_raw():
@@ -731,7 +733,7 @@ def legs(out, args, lib, capi, synth, Context, ctx, blob, frames, d_in, d_recb, 
     host_match_dt = (time.perf_counter() - t0) / 50
     gemm_b2b = C.c_double(0.0)
     gemm_b2b_windows = []
-    for _ in range(12):                                     # consecutive windows of 300 launches; the last one is reported (the list shows the ramp)
+    for _ in range(12 if args.match_warm_ms > 0 else 1):    # consecutive windows of 300 launches; the last one is reported (the list shows the ramp)
         capi.check(lib.xfh_bench_mnn_gemm(ctx.h, img1.ptr, nf, img2.ptr, nf, 300, C.byref(gemm_b2b)), ctx.h)
         gemm_b2b_windows.append(round(gemm_b2b.value, 2))
     gemm_us_raw = ms_gemm / max(n_gemm, 1) * 1e3
@@ -809,7 +811,7 @@ def legs(out, args, lib, capi, synth, Context, ctx, blob, frames, d_in, d_recb, 
     ctx.timing_enable(0)
     sclk_in = C.c_double(0.0)
     seg_windows = []
-    for _ in range(6):
+    for _ in range(6 if args.match_warm_ms > 0 else 1):
         capi.check(lib.xfh_bench_mnn_gemm_batch(ctx.h, P, t_img1, t_n, t_img2, t_n, 100, C.byref(c_seg), C.byref(sclk_in)), ctx.h)
         seg_windows.append(round(c_seg.value, 2))
     sclk, cpm = C.c_double(0.0), C.c_double(0.0)
