@@ -67,6 +67,39 @@ def test_extraction_soak(gpu_lib, oracle_mod, H, W, B, iters):
         ctx.close(); busy.close()
 
 
+@pytest.mark.parametrize("H,W,B,iters,mode", [(96, 160, 2, 800, 2), (480, 640, 1, 500, 2), (96, 160, 8, 600, 2), (96, 160, 2, 600, 1), (96, 160, 40, 300, 2)])
+def test_extraction_soak_eval_modes(gpu_lib, H, W, B, iters, mode):
+    """the eval()-BatchNorm modes have kernels of their own in the small-batch regime (round 4: riders with the bias + ReLU epilogue, the three-stage
+    1x1 chain of the heads, the two-stage chain that folds its producer's partials): every record of every iteration bit-identical to the first
+    (which tests/test_gpu_extract.py::test_running_stats_mode / test_running_folded_mode compare with the oracle)"""
+    from xfeatslam_amd.extractor import Context
+    lib = capi.lib()
+    nf = 512 if H < 480 else 4096
+    blob = WT.pack_blob(WT.make_synthetic(1234, 6.0, with_bn=True))
+    frames = synth.frames(B, H, W, seed=23)
+    ctx = Context(nfeatures=nf, max_height=H, max_width=W, max_batch=B, bn_mode=mode)
+    busy, kick, bufs = _busy_ctx(lib, WT.pack_blob(WT.make_synthetic(1234, 6.0)), synth.frames(4, 96, 160, seed=5))
+    try:
+        ctx.load_weights(blob)
+        din = capi.DeviceBuffer(frames.nbytes).upload(frames)
+        rec = capi.DeviceBuffer(B * ctx.rec_bytes).upload(np.zeros(B * ctx.rec_bytes, np.uint8))
+        first = None
+        for it in range(iters):
+            if it % 2:
+                kick()
+            capi.check(lib.xfh_extract_batch_device(ctx.h, din.ptr, B, H, W, 0, 0, rec.ptr), ctx.h)
+            ctx.synchronize()
+            raw = rec.download(np.uint8, B * ctx.rec_bytes)
+            if first is None:
+                first = raw
+                assert all(r[2] > 0 for r in ctx.parse_records(raw, B))          # keypoints were found
+            else:
+                assert np.array_equal(raw, first), f"iteration {it}: records differ from iteration 0 (first byte {int(np.argmax(raw != first))})"
+        busy.synchronize()
+    finally:
+        ctx.close(); busy.close()
+
+
 @pytest.mark.parametrize("n1,n2,iters", [(4096, 4096, 6000), (1000, 777, 4000), (257, 4097, 4000)])
 def test_prepared_match_soak(gpu_lib, oracle_mod, n1, n2, iters):
     """back-to-back prepared-image matches (k_mnn_gemm_img + k_mnn_post: LDS-DMA pipeline, plane keys, collectors that poll the pairs the writers
