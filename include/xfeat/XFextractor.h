@@ -126,8 +126,9 @@ public:
     //                           cv::OutputArray descriptors, std::vector<int>& vLappingArea)   (include/XFextractor.h:41-43)
 #if XFEAT_HAVE_OPENCV
     // With OpenCV the signature is the reference's own, so every call site compiles unchanged whatever array type it passes
-    // (Frame.cc:611-618 passes cv::Mat, cv::Mat(), std::vector<cv::KeyPoint>, cv::Mat).  NOT compiled in this repository's image
-    // (no OpenCV headers): written against the OpenCV 4.5 API (_InputArray::getMat / empty, _OutputArray::create / getMat / release).
+    // (Frame.cc:611-618 passes cv::Mat, cv::Mat(), std::vector<cv::KeyPoint>, cv::Mat).  Written against the OpenCV 4.5 API (_InputArray::getMat /
+    // empty, _OutputArray::create / getMat / release).  This repository's image has no OpenCV: the branch is compiled and run by
+    // tests/cpp/cv_branch_test.cpp against tests/stubs/opencv_api -- an API-shaped stand-in for exactly these members -- never against the real library.
     int operator()(cv::InputArray _image, cv::InputArray /*_mask: ignored, as in the reference*/, std::vector<cv::KeyPoint>& _keypoints,
                    cv::OutputArray _descriptors, std::vector<int>& vLappingArea) {
         if (_image.empty()) return -1;                       // :253-254

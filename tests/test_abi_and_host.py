@@ -105,6 +105,22 @@ def test_cpp_dropin_compiles_and_links():
     assert r.returncode == 0, r.stderr
 
 
+def test_cpp_dropin_opencv_branch_compiles():
+    """the wrappers' `#if XFEAT_HAVE_OPENCV` branch (the reference's cv::InputArray / cv::OutputArray signature, include/XFextractor.h:41-43) is
+    type-checked by a compiler: tests/cpp/cv_branch_test.cpp against tests/stubs/opencv_api, an API-shaped stand-in for the few cv:: members
+    the branch uses (NOT OpenCV: the image has none; tests/test_gpu_dropin_cpp.py runs the program)"""
+    out = "/tmp/xfh_cv_branch_test"
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "tests", "stubs", "opencv_api"),
+           os.path.join(ROOT, "tests", "cpp", "cv_branch_test.cpp"), "-L" + os.path.join(ROOT, "xfeatslam_amd"), "-lxfeat_hip",
+           "-Wl,-rpath," + os.path.join(ROOT, "xfeatslam_amd"), "-Wl,-rpath,/opt/rocm/lib", "-o", out]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    # and the product headers never see the stand-in by themselves: without it on the include path they take the cvlite branch
+    probe = '#include "xfeat/XFextractor.h"\nstatic_assert(XFEAT_HAVE_OPENCV == 0, "no OpenCV in this image");\nint main() { return 0; }\n'
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I" + os.path.join(ROOT, "include"), "-x", "c++", "-"], input=probe, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
 def test_host_code_under_sanitizers(tmp_path):
     """libxfeat_hip's HOST code built with AddressSanitizer + UBSan (make -C xfeatslam_amd/csrc asan; device code is not
     instrumented): tests/cpp/asan_host_test.cpp drives every entry point that needs no GPU, hostile compact shards included"""

@@ -41,6 +41,23 @@ def test_cpp_dropin_end_to_end(gpu_lib, oracle_mod, tmp_path):
     assert np.array_equal(a[0], m["q"]) and np.array_equal(a[1], m["t"])
 
 
+def test_cpp_dropin_opencv_branch(gpu_lib, tmp_path):
+    """the `#if XFEAT_HAVE_OPENCV` branch of the wrappers -- the reference's own operator()(cv::InputArray, cv::InputArray, vector<cv::KeyPoint>&,
+    cv::OutputArray, vector<int>&) (include/XFextractor.h:41-43) -- compiled and run against tests/stubs/opencv_api (API-shaped, NOT OpenCV:
+    the image has none): same records as the C ABI, empty / three-channel / padded-row inputs, a non-continuous destination, submit / collect,
+    the matcher on cv::Mat / cv::DMatch (tests/cpp/cv_branch_test.cpp: the exit code names the failed check)"""
+    exe = str(tmp_path / "cv_branch_test")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "tests", "stubs", "opencv_api"),
+                           os.path.join(ROOT, "tests", "cpp", "cv_branch_test.cpp"), "-L" + os.path.join(ROOT, "xfeatslam_amd"), "-lxfeat_hip",
+                           "-Wl,-rpath," + os.path.join(ROOT, "xfeatslam_amd"), "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    blob = WT.pack_blob(WT.make_synthetic(1234, 6.0))
+    H, W, nf = 192, 256, 600
+    (tmp_path / "w.xfhw").write_bytes(blob)
+    (tmp_path / "img.raw").write_bytes(synth.image(H, W, 8).tobytes())
+    r = subprocess.run([exe, str(tmp_path / "w.xfhw"), str(tmp_path / "img.raw"), str(H), str(W), str(nf), "0", "100"], capture_output=True, text=True)
+    assert r.returncode == 0 and "cv branch ok" in r.stdout, (r.returncode, r.stdout, r.stderr)
+
+
 def _read_dump(path, n_frames):
     raw = open(path, "rb").read()
     o = 0
