@@ -458,6 +458,30 @@ __device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[NT], float* __
     const bool full = rows_left >= WH && cols_left >= WW;          // wave-uniform
     const int lane_off = 4 * h * COUT + co0;
     const int rowstride = Wout * COUT;
+    auto value = [&](int n, int r, float* dst, float bv) {
+        float v = acc[n][r];
+        if constexpr (EPI != EPI_STATS) v += bv;
+        if constexpr (EPI == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
+        dst[lane_off] = v;
+        if constexpr (EPI == EPI_STATS) { const double dv = (double)v; sum[n] += dv; sq[n] = fma(dv, dv, sq[n]); }
+    };
+    // Two copies of the loop under ONE wave-uniform branch: written as `ok = full ? cok : (...)` inside a single loop the compiler kept a
+    // predicate (v_cmp / v_cndmask / s_and_saveexec / s_cbranch_execz) around every one of the 16 * NT values also for the tiles inside the map
+    // -- 50 VALU instructions and 80 scalar ones per wave and tile on the pipe the MFMAs use (a seventh of the 1x1 layers' vector work).
+    if (full) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            sum[n] = 0.0; sq[n] = 0.0;
+            if (COUT % 32 == 0 || co0 + n * 32 < COUT) {          // (one predicate per channel tile where the channels are padded)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int pb = (r & 3) + 8 * (r >> 2);         // + 4*h
+                    value(n, r, wave_out + (pb / WW) * rowstride + (pb % WW) * COUT + n * 32, bias[n]);
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         const int co = co0 + n * 32;
@@ -469,14 +493,7 @@ __device__ __forceinline__ void conv_epilogue(const f32x16 (&acc)[NT], float* __
             const int pb = (r & 3) + 8 * (r >> 2);                 // + 4*h
             const int prow = pb / WW, pcol = pb % WW;              // compile-time; pcol + 4*h < WW
             float* dst = wave_out + prow * rowstride + pcol * COUT + n * 32;      // uniform
-            const bool ok = full ? cok : (cok && prow < rows_left && pcol + 4 * h < cols_left);
-            if (ok) {
-                float v = acc[n][r];
-                if constexpr (EPI != EPI_STATS) v += bv;
-                if constexpr (EPI == EPI_BIAS_RELU) v = fmaxf(v, 0.f);
-                dst[lane_off] = v;
-                if constexpr (EPI == EPI_STATS) { const double dv = (double)v; sum[n] += dv; sq[n] = fma(dv, dv, sq[n]); }
-            }
+            if (cok && prow < rows_left && pcol + 4 * h < cols_left) value(n, r, dst, bv);
         }
     }
 }
