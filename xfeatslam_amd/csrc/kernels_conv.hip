@@ -614,7 +614,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs a, const int tile,
                     v1[q] = v1[q] + (pl * s_stat[2 * CIN + g * 8 + 4 + q] + s_stat[3 * CIN + g * 8 + 4 + q]);
                 }
             }
-            if (!ok) { v0 = f32x4{0.f, 0.f, 0.f, 0.f}; v1 = v0; }
+            if constexpr (KS > 1) { if (!ok) { v0 = f32x4{0.f, 0.f, 0.f, 0.f}; v1 = v0; } }       // Conv2d zero padding; a 1x1 layer's overhang pixels feed only outputs that are never stored
             // k permutation inside each group of 8: position 4*(k&1) + (k>>1)
             float* d = s_in + pix * CP + g * 8;
             *(f32x4*)d = f32x4{v0.x, v0.z, v1.x, v1.z};
@@ -836,7 +836,8 @@ void k_conv_mfma_p(ConvArgs a, int ntile, int total) {
                 const int cy = min(max(gy, 0), a.Hin - 1), cx = min(max(gx, 0), a.Win - 1);
                 const float* p = PRO == PRO_UNFOLD ? in + ((cy * 8 + g) * (a.Win * 8) + cx * 8) : in + (cy * a.Win + cx) * CIN;
                 v0[k] = *(const f32x4*)p; v1[k] = *(const f32x4*)(p + 4);
-                inside |= (gy == cy && gx == cx) ? (1u << k) : 0u;
+                // (a pixel of the tile's overhang keeps the clamped pixel's values: in a 1x1 convolution it feeds nothing but its own output
+                // pixel, which the epilogue neither stores nor counts -- zeroing it cost 8 v_cndmask per item on the pipe the MFMAs use)
             } else {                              // 3x3 layers (24 -> 24, 8 -> 24): the branchy form measured 3-5 % faster there
                 v0[k] = f32x4{0.f, 0.f, 0.f, 0.f}; v1[k] = v0[k];
                 if (t < NE && item < NITEM && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win) {
@@ -864,7 +865,7 @@ void k_conv_mfma_p(ConvArgs a, int ntile, int total) {
             const int item = t + k * NE;
             if (t < NE && item < NITEM) {
                 f32x4 x0 = v0[k], x1 = v1[k];
-                const bool in_img = inside & (1u << k);
+                [[maybe_unused]] const bool in_img = inside & (1u << k);
                 if constexpr (KS == 1) {
                     float xm = 0.f, xr = 1.f;
                     if constexpr (PRO == PRO_UNFOLD) { const int fb = tile / ntile; xm = a.xstat[fb * 2]; xr = a.xstat[fb * 2 + 1]; }
@@ -875,7 +876,6 @@ void k_conv_mfma_p(ConvArgs a, int ntile, int total) {
                             x0[q] = fmaxf((x0[q] - m0[q]) * r0[q], 0.f);
                             x1[q] = fmaxf((x1[q] - m1[q]) * r1[q], 0.f);
                         }
-                        x0[q] = in_img ? x0[q] : 0.f; x1[q] = in_img ? x1[q] : 0.f;      // tile overhang
                     }
                 } else if constexpr (PRO == PRO_BN || PRO == PRO_B2IN) {
                     if (in_img) {
@@ -1428,20 +1428,17 @@ void k_chain1x1(ChainArgs ca, int ntile, int total) {
     const int wm = wave;
 
     f32x4 v0[NIT], v1[NIT];
-    unsigned inside = 0u;
     auto load_tile = [&](int tile) {
         const int b = tile / ntile, tl = tile - b * ntile;
         const int tx0 = (tl % a.tiles_x) * TW, ty0 = (tl / a.tiles_x) * TH;
         const float* in = a.in + (size_t)b * a.in_stride + g * 8;
-        inside = 0u;
 #pragma unroll
         for (int k = 0; k < NIT; ++k) {
             const int pix = (t + k * NTHR) / G;
             const int gy = ty0 + pix / TW, gx = tx0 + pix % TW;
             const int cy = min(gy, a.Hin - 1), cx = min(gx, a.Win - 1);
             const float* p = in + (cy * a.Win + cx) * CIN;
-            v0[k] = *(const f32x4*)p; v1[k] = *(const f32x4*)(p + 4);
-            inside |= (gy == cy && gx == cx) ? (1u << k) : 0u;
+            v0[k] = *(const f32x4*)p; v1[k] = *(const f32x4*)(p + 4);       // (overhang pixels keep the clamped pixel's values: k_conv_mfma_p)
         }
     };
     auto store_tile = [&](int tile) {
@@ -1459,14 +1456,12 @@ void k_chain1x1(ChainArgs ca, int ntile, int total) {
             const int item = t + k * NTHR;
             if (NITEM % NTHR != 0 && item >= NITEM) continue;
             f32x4 x0 = v0[k], x1 = v1[k];
-            const bool in_img = inside & (1u << k);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 if constexpr (PRO == PRO_BN) {
                     x0[q] = fmaxf((x0[q] - m0[q]) * r0[q], 0.f);
                     x1[q] = fmaxf((x1[q] - m1[q]) * r1[q], 0.f);
                 }
-                x0[q] = in_img ? x0[q] : 0.f; x1[q] = in_img ? x1[q] : 0.f;
             }
             float* d = s_in + (item / G) * CP + g * 8;
             *(f32x4*)d = f32x4{x0.x, x0.z, x1.x, x1.z};
