@@ -8,7 +8,10 @@
  *   - convolutions accumulate in fp32 as one fmaf chain per output, K ordered (ky,kx,ci),
  *     starting from 0; a bias, where the layer has one, is added after the chain;
  *   - BatchNorm/InstanceNorm statistics are fp64 (mean, biased variance), applied in
- *     fp32 as (x - mean) * rstd   [reference: training-mode BN, SURVEY.md Q1];
+ *     fp32 as ONE fused multiply-add  x * alpha + beta  with alpha = rstd, beta = -(mean * rstd) (both fp32) -- the arithmetic of
+ *     ATen's batch_norm / instance_norm CPU kernels (alpha = invstd * weight, beta = bias - mean * alpha, out = x * alpha + beta
+ *     compiled to an fma: bit-identical on every element, tests/test_oracle.py::test_norm_apply_is_atens_fma)
+ *     [reference: training-mode BN, SURVEY.md Q1];
  *   - L2 norms use an fp64 sum of squares, then fp32 sqrt/max/divide.
  * Build: see oracle/Makefile (-O2 -mavx2 -mfma -ffp-contract=off -fopenmp).
  */
@@ -45,7 +48,7 @@ struct xfo_ctx {
     float* fus2_w; float fus2_b[64];    /* [ci][co] */
     float heat2_w[64]; float heat2_b;
     float* kp3_w; float kp3_b[65];      /* [ci][65] */
-    float* bn_stat[XFO_NUM_LAYERS];     /* optional running statistics as (mean[C], rstd[C]) */
+    float* bn_stat[XFO_NUM_LAYERS];     /* optional running statistics as (beta[C] = -mean * rstd, alpha[C] = rstd) */
     int bn_mode;                        /* 0 = batch statistics (the reference), 1 = running statistics */
     int rescale;                        /* 0 = the reference's Long-typed no-op (Q2), 1 = float rescale to input coordinates */
     /* intermediates of the last call */
@@ -117,8 +120,9 @@ xfo_ctx* xfo_create(const void* blob, size_t nbytes) {
         if (rm && rv && (int)dm[0] == LAYERS[i].cout && (int)dv[0] == LAYERS[i].cout) {
             c->bn_stat[i] = (float*)malloc(sizeof(float) * 2 * LAYERS[i].cout);
             for (int ch = 0; ch < LAYERS[i].cout; ++ch) {
-                c->bn_stat[i][ch] = rm[ch];
-                c->bn_stat[i][LAYERS[i].cout + ch] = (float)(1.0 / sqrt((double)rv[ch] + 1e-5));
+                const float rs = (float)(1.0 / sqrt((double)rv[ch] + 1e-5));
+                c->bn_stat[i][ch] = -(rm[ch] * rs);
+                c->bn_stat[i][LAYERS[i].cout + ch] = rs;
             }
         }
     }
@@ -215,7 +219,7 @@ static void resize_bilinear(const float* in, int Hi, int Wi, int C, float* out, 
 
 /* batch statistics over n rows of C channels: fp64 mean and biased variance, eps 1e-5
  * (BatchNorm2d(affine=false) in training mode, src/XFeat.cc:19; InstanceNorm2d(1),
- * src/XFeat.cc:32,149).  stat[0..C) = mean, stat[C..2C) = rstd. */
+ * src/XFeat.cc:32,149).  stat[0..C) = beta = -(mean * rstd), stat[C..2C) = alpha = rstd (fp32; see the header). */
 static void batch_stats(const float* x, int64_t n, int C, float* stat) {
     double* s = (double*)calloc((size_t)C * 2, sizeof(double));
     const int nt = NT();
@@ -250,18 +254,19 @@ static void batch_stats(const float* x, int64_t n, int C, float* stat) {
     for (int t = 0; t < nt; ++t) for (int c = 0; c < C; ++c) s[C + c] += part[(size_t)t * C + c];
     for (int c = 0; c < C; ++c) {
         double var = s[C + c] / (double)n;
-        stat[c] = (float)s[c];
-        stat[C + c] = (float)(1.0 / sqrt(var + 1e-5));
+        const float rs = (float)(1.0 / sqrt(var + 1e-5));
+        stat[c] = -((float)s[c] * rs);
+        stat[C + c] = rs;
     }
     free(part); free(s);
 }
 
-/* BN apply + ReLU: relu((x - mean) * rstd), src/XFeat.cc:19-20 */
+/* BN apply + ReLU: relu(fma(x, alpha, beta)), src/XFeat.cc:19-20 */
 static void bn_relu(const float* raw, int64_t n, int C, const float* stat, float* act) {
 #pragma omp parallel for num_threads(NT()) schedule(static)
     for (int64_t i = 0; i < n; ++i)
         for (int c = 0; c < C; ++c) {
-            float v = (raw[i * C + c] - stat[c]) * stat[C + c];
+            float v = fmaf(raw[i * C + c], stat[C + c], stat[c]);
             act[i * C + c] = v > 0.f ? v : 0.f;
         }
 }
@@ -421,7 +426,7 @@ int xfo_extract(xfo_ctx* c, const uint8_t* gray, int H0, int W0, int nfeatures, 
     batch_stats(x, (int64_t)H * W, 1, xst);
     float* xh = (float*)malloc(sizeof(float) * (size_t)H * W);
 #pragma omp parallel for num_threads(NT()) schedule(static)
-    for (int64_t i = 0; i < (int64_t)H * W; ++i) xh[i] = (x[i] - xst[0]) * xst[1];
+    for (int64_t i = 0; i < (int64_t)H * W; ++i) xh[i] = fmaf(x[i], xst[1], xst[0]);
 
     int Ho, Wo;
     /* :152 block1 */

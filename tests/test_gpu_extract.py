@@ -650,7 +650,7 @@ def test_exact_score_tie_straddles_the_cut(gpu_lib, oracle_mod, weights_dense):
     H, W = 256, 320
     orc = oracle_mod.Oracle(blob)
     checked = same_pair = 0
-    for seed in (26, 36, 46):
+    for seed in (16, 42, 50):
         img = synth.image(H, W, seed)
         full = _ctx(8192, H, W); full.load_weights(blob)
         full.extract_batch(img[None])

@@ -364,11 +364,11 @@ static int load_weights_impl(xfh_ctx* c, const void* blob, size_t nbytes) {
         if (rc != XFH_OK) return rc;
         if (running) {
             // statistics slots of every frame: the file's values, or the identity when they are folded into the weights (the stored
-            // maps are then already activated, and relu((x - 0) * 1) leaves them unchanged in every consumer); k_bn_finalize is never launched
+            // maps are then already activated, and relu(fma(x, 1, -0)) leaves them unchanged in every consumer); k_bn_finalize is never launched
             std::vector<float> st((size_t)c->cfg.max_batch * 2 * L.cout);
             for (int b = 0; b < c->cfg.max_batch; ++b)
                 for (int ch = 0; ch < L.cout; ++ch) {
-                    st[(size_t)b * 2 * L.cout + ch] = folded ? 0.f : mean[ch];
+                    st[(size_t)b * 2 * L.cout + ch] = folded ? -0.f : -(mean[ch] * rstd[ch]);       // (beta, alpha) as bn_fold stores them: x * alpha + beta in one fma
                     st[(size_t)b * 2 * L.cout + L.cout + ch] = folded ? 1.f : rstd[ch];
                 }
             HIPCK(c, hipMemcpy(c->stat[i], st.data(), st.size() * sizeof(float), hipMemcpyHostToDevice));

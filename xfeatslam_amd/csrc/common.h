@@ -93,13 +93,17 @@ __device__ __forceinline__ void bn_fold(const double* __restrict__ p, int npart,
         const double mean = S / count;
         double var = SS / count - mean * mean;
         if (var < 0.0) var = 0.0;
-        stat[c] = (float)mean;
-        stat[C + c] = (float)(1.0 / sqrt(var + 1e-5));
+        // stored as (beta, alpha) = (-mean * rstd, rstd), both fp32: the layer is applied as ONE fma, x * alpha + beta -- the arithmetic of ATen's
+        // batch_norm / instance_norm on the CPU (alpha = invstd, beta = bias - mean * alpha, out = fma(x, alpha, beta): bit for bit on every element,
+        // tests/test_oracle.py::test_norm_apply_is_atens_fma), and one instruction instead of two on the pipe the MFMAs use
+        const float rstd = (float)(1.0 / sqrt(var + 1e-5));
+        stat[c] = -((float)mean * rstd);
+        stat[C + c] = rstd;
     }
     __syncthreads();
 }
 
-// statistics of a producer layer as a consumer sees them: either finalised (stat: [B][2*C] mean, rstd) or, for small
+// statistics of a producer layer as a consumer sees them: either finalised (stat: [B][2*C]: beta = -mean * rstd, alpha = rstd) or, for small
 // batches, still as fp64 partials that every workgroup of the consumer folds itself (bn_fold; the same order, hence the
 // same bits as k_bn_finalize) -- workgroup 0 of each frame publishes the result to stat_out for the debug API and for
 // consumers that do not fold

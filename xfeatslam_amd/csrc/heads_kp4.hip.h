@@ -66,7 +66,7 @@ __device__ __forceinline__ void heads_kp4_body(const Kp4Args ka, int block, int 
     for (int k = 0; k < 4; ++k) {
         const int item = t + k * 4 * HK4_PX, ip = item >> 4, g = item & 15;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) sA[(g * 4 + q) * HK4_LD + ip] = fmaxf((rv[k][q] - st[g * 4 + q]) * st[64 + g * 4 + q], 0.f);
+        for (int q = 0; q < 4; ++q) sA[(g * 4 + q) * HK4_LD + ip] = fmaxf(fmaf(rv[k][q], st[64 + g * 4 + q], st[g * 4 + q]), 0.f);
     }
 #pragma unroll
     for (int k = 0; k < 9; ++k) { const int f = t + k * 4 * HK4_PX; if (f < 64 * 17) *(f32x4*)(sW + f * 4) = wv[k]; }

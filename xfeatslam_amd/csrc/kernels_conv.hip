@@ -86,8 +86,8 @@ __device__ __forceinline__ void ld_act8(const float* __restrict__ raw, const flo
     v0 = *(const f32x4*)p; v1 = *(const f32x4*)(p + 4);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        v0[q] = fmaxf((v0[q] - st[g * 8 + q]) * st[64 + g * 8 + q], 0.f);
-        v1[q] = fmaxf((v1[q] - st[g * 8 + 4 + q]) * st[64 + g * 8 + 4 + q], 0.f);
+        v0[q] = fmaxf(fmaf(v0[q], st[64 + g * 8 + q], st[g * 8 + q]), 0.f);
+        v1[q] = fmaxf(fmaf(v1[q], st[64 + g * 8 + 4 + q], st[g * 8 + 4 + q]), 0.f);
     }
 }
 // bilinear sample (ATen arithmetic: fma(w0, v0, w1*v1) per axis) of relu(bn(raw)) for 8 channels
@@ -180,9 +180,9 @@ void k_block1_stats(const float* __restrict__ X, size_t x_stride, StatSrc xs, in
         const bool iny = gy >= 0 && gy < H;
         const f32x4 v = rv[i];
         const bool inx = iny && gx < W;
-        row[1] = inx ? (v.x - m) * r : 0.f; row[2] = inx ? (v.y - m) * r : 0.f; row[3] = inx ? (v.z - m) * r : 0.f; row[4] = inx ? (v.w - m) * r : 0.f;
-        row[0] = (iny && gx > 0 && gx - 1 < W) ? (rl[i] - m) * r : 0.f;
-        row[5] = (iny && gx + 4 < W) ? (rr[i] - m) * r : 0.f;
+        row[1] = inx ? fmaf(v.x, r, m) : 0.f; row[2] = inx ? fmaf(v.y, r, m) : 0.f; row[3] = inx ? fmaf(v.z, r, m) : 0.f; row[4] = inx ? fmaf(v.w, r, m) : 0.f;
+        row[0] = (iny && gx > 0 && gx - 1 < W) ? fmaf(rl[i], r, m) : 0.f;
+        row[5] = (iny && gx + 4 < W) ? fmaf(rr[i], r, m) : 0.f;
     };
     float win[3][6];
     load_row(0, win[0]);
@@ -290,7 +290,7 @@ void k_conv_direct(ConvArgs a) {
             const int item = t + k * 256, iy = item / XW, ix = item % XW;
             const int gy = ty0 * ST - 2 + iy, gx = tx0 * ST - 2 + ix;
             const bool ok = gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win;
-            if (item < XW * XW) s_x[iy * XS + ix] = ok ? (xv[k] - xm) * xr : 0.f;
+            if (item < XW * XW) s_x[iy * XS + ix] = ok ? fmaf(xv[k], xr, xm) : 0.f;
         }
         __syncthreads();
         for (int pix = t; pix < TI * TI; pix += 256) {
@@ -307,7 +307,7 @@ void k_conv_direct(ConvArgs a) {
                     if constexpr (EPI == EPI_BIAS_RELU) v[q] = fmaxf(acc[q] + a.bias0[q], 0.f);
                     else {
                         const float m = FOLD ? s_stat[q] : st[q], r = FOLD ? s_stat[CIN + q] : st[CIN + q];
-                        v[q] = fmaxf((acc[q] - m) * r, 0.f);
+                        v[q] = fmaxf(fmaf(acc[q], r, m), 0.f);
                     }
                 }
             }
@@ -344,12 +344,12 @@ void k_conv_direct(ConvArgs a) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const float m = FOLD ? s_stat[g * 4 + q] : st[g * 4 + q], r = FOLD ? s_stat[CIN + g * 4 + q] : st[CIN + g * 4 + q];
-                        v[q] = ok ? fmaxf((v[q] - m) * r, 0.f) : 0.f;
+                        v[q] = ok ? fmaxf(fmaf(v[q], r, m), 0.f) : 0.f;
                     }
                     *(f32x4*)(s_in + pix * CIN + g * 4) = v;
                 }
             } else {
-                s_in[pix] = ok ? (iv[k][0].x - st[0]) * st[1] : 0.f;        // InstanceNorm, no ReLU
+                s_in[pix] = ok ? fmaf(iv[k][0].x, st[1], st[0]) : 0.f;        // InstanceNorm, no ReLU
             }
         }
     }
@@ -595,15 +595,15 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs a, const int tile,
             if constexpr (PRO == PRO_UNFOLD) {
                 const float xm = a.xstat[b * 2], xr = a.xstat[b * 2 + 1];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { v0[q] = (v0[q] - xm) * xr; v1[q] = (v1[q] - xm) * xr; }
+                for (int q = 0; q < 4; ++q) { v0[q] = fmaf(v0[q], xr, xm); v1[q] = fmaf(v1[q], xr, xm); }
             }
             if constexpr (PRO == PRO_BN || PRO == PRO_B2IN) {
                 const f32x4 m0 = *(const f32x4*)(s_stat + g * 8), m1 = *(const f32x4*)(s_stat + g * 8 + 4);
                 const f32x4 q0 = *(const f32x4*)(s_stat + CIN + g * 8), q1 = *(const f32x4*)(s_stat + CIN + g * 8 + 4);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    v0[q] = fmaxf((v0[q] - m0[q]) * q0[q], 0.f);
-                    v1[q] = fmaxf((v1[q] - m1[q]) * q1[q], 0.f);
+                    v0[q] = fmaxf(fmaf(v0[q], q0[q], m0[q]), 0.f);
+                    v1[q] = fmaxf(fmaf(v1[q], q1[q], m1[q]), 0.f);
                 }
             }
             if constexpr (PRO == PRO_B2IN) {            // x1 + skip1(x): AvgPool4 of the normalised image, 1x1 conv with bias (XFeat.cc:36-39,153)
@@ -632,8 +632,8 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs a, const int tile,
             v1 = *(const f32x4*)(p + 4);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                v0[q] = fmaxf((v0[q] - s_stat[g * 8 + q]) * s_stat[CIN + g * 8 + q], 0.f);
-                v1[q] = fmaxf((v1[q] - s_stat[g * 8 + 4 + q]) * s_stat[CIN + g * 8 + 4 + q], 0.f);
+                v0[q] = fmaxf(fmaf(v0[q], s_stat[CIN + g * 8 + q], s_stat[g * 8 + q]), 0.f);
+                v1[q] = fmaxf(fmaf(v1[q], s_stat[CIN + g * 8 + 4 + q], s_stat[g * 8 + 4 + q]), 0.f);
             }
             // x3 + up2(x4) + up4(x5) with ATen's bilinear arithmetic (XFeat.cc:159-166)
             f32x4 u0, u1, w0, w1;
@@ -871,18 +871,18 @@ void k_conv_mfma_p(ConvArgs a, int ntile, int total) {
                     if constexpr (PRO == PRO_UNFOLD) { const int fb = tile / ntile; xm = a.xstat[fb * 2]; xr = a.xstat[fb * 2 + 1]; }
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        if constexpr (PRO == PRO_UNFOLD) { x0[q] = (x0[q] - xm) * xr; x1[q] = (x1[q] - xm) * xr; }
+                        if constexpr (PRO == PRO_UNFOLD) { x0[q] = fmaf(x0[q], xr, xm); x1[q] = fmaf(x1[q], xr, xm); }
                         if constexpr (PRO == PRO_BN) {
-                            x0[q] = fmaxf((x0[q] - m0[q]) * r0[q], 0.f);
-                            x1[q] = fmaxf((x1[q] - m1[q]) * r1[q], 0.f);
+                            x0[q] = fmaxf(fmaf(x0[q], r0[q], m0[q]), 0.f);
+                            x1[q] = fmaxf(fmaf(x1[q], r1[q], m1[q]), 0.f);
                         }
                     }
                 } else if constexpr (PRO == PRO_BN || PRO == PRO_B2IN) {
                     if (in_img) {
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            x0[q] = fmaxf((x0[q] - m0[q]) * r0[q], 0.f);
-                            x1[q] = fmaxf((x1[q] - m1[q]) * r1[q], 0.f);
+                            x0[q] = fmaxf(fmaf(x0[q], r0[q], m0[q]), 0.f);
+                            x1[q] = fmaxf(fmaf(x1[q], r1[q], m1[q]), 0.f);
                             if constexpr (PRO == PRO_B2IN) { x0[q] = x0[q] + (pl[k] * w0[q] + c0[q]); x1[q] = x1[q] + (pl[k] * w1[q] + c1[q]); }
                         }
                     }
@@ -1062,8 +1062,8 @@ void k_conv_mfma_t(ConvArgs a, int ntile, int total) {
                 const bool in_img = inside & (1u << k);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    x0[q] = fmaxf((x0[q] - m0[q]) * r0[q], 0.f);
-                    x1[q] = fmaxf((x1[q] - m1[q]) * r1[q], 0.f);
+                    x0[q] = fmaxf(fmaf(x0[q], r0[q], m0[q]), 0.f);
+                    x1[q] = fmaxf(fmaf(x1[q], r1[q], m1[q]), 0.f);
                     x0[q] = in_img ? x0[q] : 0.f; x1[q] = in_img ? x1[q] : 0.f;
                 }
                 float* d = s_in + (item / G) * CP + g * 8;
@@ -1265,8 +1265,8 @@ void k_conv_mfma16(ConvArgs a) {
         const f32x4 q0 = *(const f32x4*)(s_stat + CIN + g * 8), q1 = *(const f32x4*)(s_stat + CIN + g * 8 + 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            v0[e] = fmaxf((v0[e] - m0[e]) * q0[e], 0.f);
-            v1[e] = fmaxf((v1[e] - m1[e]) * q1[e], 0.f);
+            v0[e] = fmaxf(fmaf(v0[e], q0[e], m0[e]), 0.f);
+            v1[e] = fmaxf(fmaf(v1[e], q1[e], m1[e]), 0.f);
         }
         if constexpr (PRO == PRO_FUSE) {                // x3 + up2(x4) + up4(x5) with ATen's bilinear arithmetic (XFeat.cc:159-166)
             // no branch around the sixteen tap loads of an item (clamped coordinates; what lies outside the image is zeroed below): behind
@@ -1459,8 +1459,8 @@ void k_chain1x1(ChainArgs ca, int ntile, int total) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 if constexpr (PRO == PRO_BN) {
-                    x0[q] = fmaxf((x0[q] - m0[q]) * r0[q], 0.f);
-                    x1[q] = fmaxf((x1[q] - m1[q]) * r1[q], 0.f);
+                    x0[q] = fmaxf(fmaf(x0[q], r0[q], m0[q]), 0.f);
+                    x1[q] = fmaxf(fmaf(x1[q], r1[q], m1[q]), 0.f);
                 }
             }
             float* d = s_in + (item / G) * CP + g * 8;

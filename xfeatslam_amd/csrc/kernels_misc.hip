@@ -108,7 +108,7 @@ void k_norm_aux(const float* __restrict__ X, size_t x_stride, StatSrc xs, int H,
         const int y = by * 4 + i, xx = bx * 4;
         f32x4 v = *(const f32x4*)(x + (size_t)y * W + xx);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { v[j] = (v[j] - m) * r; s += v[j]; }
+        for (int j = 0; j < 4; ++j) { v[j] = fmaf(v[j], r, m); s += v[j]; }
     }
     pool[(size_t)b * pool_stride + q] = s / 16.0f;
 }
@@ -143,7 +143,7 @@ void k_heads_heat(const float* __restrict__ rawH, StatSrc sH,     // heatmap_hea
     for (int k = 0; k < 16; ++k) {
         const int item = t + k * HF_PX, lp = item >> 4, g = item & 15;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) sA[(g * 4 + j) * HF_LD + lp] = fmaxf((rv[k][j] - st[g * 4 + j]) * st[64 + g * 4 + j], 0.f);
+        for (int j = 0; j < 4; ++j) sA[(g * 4 + j) * HF_LD + lp] = fmaxf(fmaf(rv[k][j], st[64 + g * 4 + j], st[g * 4 + j]), 0.f);
     }
     __syncthreads();
     float acc = 0.f;
@@ -181,7 +181,7 @@ void k_heads_kp(const float* __restrict__ rawK, StatSrc sK,      // keypoint_hea
     for (int k = 0; k < 16; ++k) {
         const int item = t + k * HF_PX, lp = item >> 4, g = item & 15;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) sA[(g * 4 + j) * HF_LD + lp] = fmaxf((rv[k][j] - st[g * 4 + j]) * st[64 + g * 4 + j], 0.f);
+        for (int j = 0; j < 4; ++j) sA[(g * 4 + j) * HF_LD + lp] = fmaxf(fmaf(rv[k][j], st[64 + g * 4 + j], st[g * 4 + j]), 0.f);
     }
     __syncthreads();
     float acc[65];
@@ -309,7 +309,7 @@ void k_nms_score(const float* __restrict__ K1h, size_t k_stride, const float* __
             const int item = t + q * 256, cell = item >> 4, g = item & 15;
             if (item < NMS_HC * 16)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) s_act[cell * 65 + g * 4 + j] = fmaxf((hv[q][j] - s_hst[g * 4 + j]) * s_hst[64 + g * 4 + j], 0.f);
+                for (int j = 0; j < 4; ++j) s_act[cell * 65 + g * 4 + j] = fmaxf(fmaf(hv[q][j], s_hst[64 + g * 4 + j], s_hst[g * 4 + j]), 0.f);
         }
     }
     __syncthreads();
