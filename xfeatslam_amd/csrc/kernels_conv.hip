@@ -1274,6 +1274,9 @@ void k_conv_mfma16(ConvArgs a) {
             const int cy = min(max(gy, 0), a.Hin - 1), cx = min(max(gx, 0), a.Win - 1);
             f32x4 u0, u1, w0, w1;
             up_bilinear8(a.r4 + (size_t)b * a.s4, s_stat + 128, a.H4, a.W4, a.Hin, a.Win, cy, cx, g, u0, u1);
+            // the 16-wave form has 128 registers per thread: with the taps of both maps in flight at once (64 registers) it spilled nine of them;
+            // there the second map's taps are issued after the first map is combined (one more round trip on 2-32-frame batches with > 256 tiles)
+            if constexpr (NTHR > 512) __builtin_amdgcn_sched_barrier(0);
             up_bilinear8(a.r5 + (size_t)b * a.s5, s_stat + 256, a.H5, a.W5, a.Hin, a.Win, cy, cx, g, w0, w1);
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v0[e] = (v0[e] + u0[e]) + w0[e]; v1[e] = (v1[e] + u1[e]) + w1[e]; }
