@@ -439,6 +439,15 @@ void k_conv_direct(ConvArgs a) {
 // (The conv kernels issue their VALU instructions on the same pipe as the f32 MFMA: PMC showed 2.5-9 VALU
 // instructions per MFMA in these kernels, most of them address arithmetic.)  Statistics: fp64 (sum, sum^2) per channel
 // over the lane's valid pixels in register order -- the order is part of the numerics contract.
+// Weight chunks through BUFFER loads: resource = the layer's weight matrix (wave-uniform, four SGPRs), per-lane 32-bit byte offset, the chunk as the
+// scalar offset -- `buffer_load_dwordx4 v, v_off, s[rsrc], s_chunk offen`, no vector arithmetic per load.  As `base + (size_t)chunk * WCH + (size_t)f * 4`
+// every chunk's loads carried a 64-bit vector add of their own (v_lshl_add_u64 / v_add_co + v_addc: ~50 VALU instructions per wave and tile in the
+// 3x3 64 -> 64 instance, on the pipe the MFMAs use).
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wbuf_make(const float* w) { return __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, 0x7fffffff, 0x00020000); }
+__device__ __forceinline__ f32x4 wbuf_ld(__amdgpu_buffer_rsrc_t r, int f /* quad index of the lane */, int chunk_float_off /* wave-uniform */) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (unsigned)f * 16u, chunk_float_off * 4, 0));
+}
 // the lane's NT bias values; issued before the K loop so that the epilogue never waits for a global load
 template <int COUT, int NT, int EPI>
 __device__ __forceinline__ void conv_bias(const float* __restrict__ bias, int co0, float (&bv)[NT]) {
@@ -545,12 +554,13 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs a, const int tile,
     // share a CU; the kernels that run one workgroup of four waves per CU waited at every chunk for the next one's weights (1.6 us per
     // chunk of 0.85 us of MFMAs in the stride-2 64 -> 64 layer at 256 frames)
     f32x4 wreg[PD][NWLD];
+    const __amdgpu_buffer_rsrc_t wrs = wbuf_make(a.w);
 #pragma unroll
     for (int c = 0; c < PD; ++c)
 #pragma unroll
         for (int q = 0; q < NWLD; ++q) {
             const int f = t + q * NTHR;
-            if (c < NCHUNK && f < WCH / 4) wreg[c][q] = *(const f32x4*)(a.w + (size_t)c * WCH + (size_t)f * 4);
+            if (c < NCHUNK && f < WCH / 4) wreg[c][q] = wbuf_ld(wrs, f, c * WCH);
         }
     // ---- the raw input tile: every load of a thread is issued here, before the statistics are staged and before the first use
     // (clamped addresses, no branches around the loads: behind a per-item branch they run one memory round trip after the other,
@@ -654,7 +664,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs a, const int tile,
         if (f < WCH / 4) {
             const int n = f / (KC / 4), c4 = f % (KC / 4);
             *(f32x4*)(s_w + n * WS + c4 * 4) = wreg[0][q];
-            if (PD < NCHUNK) wreg[0][q] = *(const f32x4*)(a.w + (size_t)PD * WCH + (size_t)f * 4);
+            if (PD < NCHUNK) wreg[0][q] = wbuf_ld(wrs, f, PD * WCH);
         }
     }
     __syncthreads();
@@ -695,14 +705,13 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs a, const int tile,
         }
         if (ch + 1 < NCHUNK) {                              // chunk ch + 1 (issued PD chunks ago) -> the other LDS buffer; its register set takes chunk ch + 1 + PD
             float* wd = s_w + ((ch + 1) & 1) * W_FLOATS;
-            const float* wsrc = a.w + (size_t)(ch + 1 + PD) * WCH;
 #pragma unroll
             for (int q = 0; q < NWLD; ++q) {
                 const int f = t + q * NTHR;
                 if (f < WCH / 4) {
                     const int n = f / (KC / 4), c4 = f % (KC / 4);
                     *(f32x4*)(wd + n * WS + c4 * 4) = wreg[(ch + 1) % PD][q];
-                    if (ch + 1 + PD < NCHUNK) wreg[(ch + 1) % PD][q] = *(const f32x4*)(wsrc + (size_t)f * 4);
+                    if (ch + 1 + PD < NCHUNK) wreg[(ch + 1) % PD][q] = wbuf_ld(wrs, f, (ch + 1 + PD) * WCH);
                 }
             }
         }
@@ -1025,12 +1034,13 @@ void k_conv_mfma_t(ConvArgs a, int ntile, int total) {
     // visible by the barrier in between), chunk c + 2 moves from its registers to the buffer chunk c - 1 has just left, and that register set is refilled
     // with chunk c + 5.  ONE barrier per chunk, at its start, and no wait behind it: the operands of a chunk's first group are read BEFORE the barrier.
     f32x4 wreg[3][NWLD];
+    const __amdgpu_buffer_rsrc_t wrs = wbuf_make(a.w);
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll
         for (int q = 0; q < NWLD; ++q) {
             const int f = t + q * NTHR;
-            if (f < WCH / 4) wreg[c][q] = *(const f32x4*)(a.w + (size_t)c * WCH + (size_t)f * 4);
+            if (f < WCH / 4) wreg[c][q] = wbuf_ld(wrs, f, c * WCH);
         }
 
     f32x4 v0[NIT], v1[NIT], m0, m1, r0, r1;
@@ -1075,14 +1085,14 @@ void k_conv_mfma_t(ConvArgs a, int ntile, int total) {
     // ring position rc (compile time, any value with the right residues): its register set -> its LDS buffer; the set is refilled with position rc + 3
     auto push_chunk = [&](int rc) {
         float* wd = s_w + (rc % 3) * W_FLOATS;
-        const float* wsrc = a.w + (size_t)((rc + 3) % NCHUNK) * WCH;
+        const int wsrc_off = ((rc + 3) % NCHUNK) * WCH;
 #pragma unroll
         for (int q = 0; q < NWLD; ++q) {
             const int f = t + q * NTHR;
             if (f < WCH / 4) {
                 const int n = f / (CB / 4), c4 = f % (CB / 4);
                 *(f32x4*)(wd + n * WS + c4 * 4) = wreg[rc % 3][q];
-                wreg[rc % 3][q] = *(const f32x4*)(wsrc + (size_t)f * 4);
+                wreg[rc % 3][q] = wbuf_ld(wrs, f, wsrc_off);
             }
         }
     };
@@ -1226,6 +1236,7 @@ void k_conv_mfma16(ConvArgs a) {
     const float* in = a.in + (size_t)b * a.in_stride;
     const int co0 = blockIdx.y * COUTW;                    // first output channel of this workgroup
     const float* wg = a.w + (size_t)co0 * KC;              // its rows of chunk 0
+    const __amdgpu_buffer_rsrc_t wrs = wbuf_make(wg);
 
     XFH_STAMP(a, 0);
     // weight chunks in flight: PD of them, in a ring of register sets (chunk c in set c % PD).  With one chunk ahead the K loop of a
@@ -1236,7 +1247,7 @@ void k_conv_mfma16(ConvArgs a) {
 #pragma unroll
         for (int q = 0; q < NWLD; ++q) {
             const int f = t + q * NTHR;
-            if (c < NCHUNK && f < WCW / 4) wreg[c][q] = *(const f32x4*)(wg + (size_t)c * WCH + (size_t)f * 4);
+            if (c < NCHUNK && f < WCW / 4) wreg[c][q] = wbuf_ld(wrs, f, c * WCH);
         }
     f32x4 r0[NIT], r1[NIT];
 #pragma unroll
@@ -1296,7 +1307,7 @@ void k_conv_mfma16(ConvArgs a) {
             if (f < WCW / 4) {
                 const int n = f / (KC / 4), c4 = f % (KC / 4);
                 *(f32x4*)(s_w + c * W_FLOATS + n * WS + c4 * 4) = wreg[c][q];
-                if (c + PD < NCHUNK) wreg[c][q] = *(const f32x4*)(wg + (size_t)(c + PD) * WCH + (size_t)f * 4);
+                if (c + PD < NCHUNK) wreg[c][q] = wbuf_ld(wrs, f, (c + PD) * WCH);
             }
         }
     __syncthreads();
@@ -1330,14 +1341,14 @@ void k_conv_mfma16(ConvArgs a) {
             for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kb][j], bv[kb][j], acc, 0, 0, 0);
         if (ch + 2 < NCHUNK) {                              // chunk ch + 2 (issued PD chunks ago) -> the buffer chunk ch - 1 was read from; its register set takes chunk ch + 2 + PD
             float* wd = s_w + ((ch + 2) % 3) * W_FLOATS;
-            const float* wsrc = wg + (size_t)(ch + 2 + PD) * WCH;
+            const int wsrc_off = (ch + 2 + PD) * WCH;
 #pragma unroll
             for (int u = 0; u < NWLD; ++u) {
                 const int f = t + u * NTHR;
                 if (f < WCW / 4) {
                     const int n = f / (KC / 4), c4 = f % (KC / 4);
                     *(f32x4*)(wd + n * WS + c4 * 4) = wreg[(ch + 2) % PD][u];
-                    if (ch + 2 + PD < NCHUNK) wreg[(ch + 2) % PD][u] = *(const f32x4*)(wsrc + (size_t)f * 4);
+                    if (ch + 2 + PD < NCHUNK) wreg[(ch + 2) % PD][u] = wbuf_ld(wrs, f, wsrc_off);
                 }
             }
         }
