@@ -185,6 +185,7 @@ int xfh_create(const xfh_config* cfg, xfh_ctx** out) {
     }
     A(c->skip_pool, sizeof(float) * B * (xs / 16));
     A(c->feats, sizeof(float) * B * c->raw_stride[17]);
+    if (B > 32) { A(c->act4, sizeof(float) * B * c->raw_stride[11]); A(c->act5, sizeof(float) * B * c->raw_stride[15]); }
     A(c->feat_nrm, sizeof(float) * B * (xs / 64));
     A(c->H1, sizeof(float) * B * (xs / 64));
     A(c->K1h, sizeof(float) * B * xs);
@@ -246,7 +247,7 @@ int xfh_destroy(xfh_ctx* c) {
         for (int i = 0; i < 3; ++i) F(c->w.direct[i]);
         F(c->w.fus2); F(c->w.fus2_bias); F(c->w.skip_w); F(c->w.skip_b); F(c->w.heat2_w); F(c->w.heat2_b); F(c->w.kp3_w); F(c->w.kp3_b);
     }
-    F(c->skip_pool); F(c->feats); F(c->feat_nrm); F(c->H1); F(c->K1h);
+    F(c->skip_pool); F(c->feats); F(c->act4); F(c->act5); F(c->feat_nrm); F(c->H1); F(c->K1h);
     F(c->cand); F(c->cand_count); F(c->slot_src); F(c->sel_key); F(c->sel_n); F(c->d_records);
     if (c->h_records) hipHostFree(c->h_records);
     if (c->h_gray) hipHostFree(c->h_gray);

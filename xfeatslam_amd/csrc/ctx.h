@@ -77,6 +77,7 @@ struct xfh_ctx {
     size_t raw_stride[XFH_NUM_LAYERS] = {};     // floats per frame (at max size)
     size_t part_stride[XFH_NUM_LAYERS] = {};    // doubles per frame
     float* skip_pool = nullptr; float* feats = nullptr;
+    float* act4 = nullptr; float* act5 = nullptr;              // relu(bn(x4)), relu(bn(x5)) for block_fusion.0 at batches > 32 (k_act_pyramid)
     float* H1 = nullptr; float* K1h = nullptr;
     bool no_nms_heat = false;                   // XFH_NO_NMS_HEAT=1 (tests)
     bool no_ride = false;                       // XFH_NO_RIDE=1: no riders (tests)

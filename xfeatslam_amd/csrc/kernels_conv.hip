@@ -51,7 +51,7 @@ struct ConvArgs {
 // PRO_B2IN / PRO_FUSE: the two element-wise glue steps of the backbone computed while staging (no intermediate tensor)
 // PRO_UNFOLD (keypoint_head.0): the input is unfold2d(x-hat, 8) (XFeat.cc:124-133) read straight from the image: channel 8*dy + dx of
 // cell (cy, cx) is pixel (8*cy + dy, 8*cx + dx), InstanceNorm applied while staging; `in` = image X, a.xstat = its statistics
-enum { PRO_PLAIN = 0, PRO_BN = 1, PRO_IN = 2, PRO_B2IN = 3, PRO_FUSE = 4, PRO_L0 = 5, PRO_UNFOLD = 6 };
+enum { PRO_PLAIN = 0, PRO_BN = 1, PRO_IN = 2, PRO_B2IN = 3, PRO_FUSE = 4, PRO_L0 = 5, PRO_UNFOLD = 6, PRO_FUSEA = 7 /* PRO_FUSE on x4 / x5 maps that k_act_pyramid has already activated */ };
 // EPI_STATS: raw map + fp64 statistic partials (BasicLayer in batch-statistics mode); EPI_BIAS: + bias, no statistics
 // (block_fusion.2); EPI_BIAS_RELU: relu(. + bias) -- a BasicLayer whose BatchNorm was folded into weights and bias at load
 // (XFH_BN_RUNNING_FOLDED): the stored map is already activated and its consumers see identity statistics
@@ -81,9 +81,11 @@ __device__ __forceinline__ void lin_coeff_c(int in, int out, int d, int& i0, int
     l1 = lam; l0 = 1.f - lam;
 }
 // 8 channels (group g) of relu(bn(raw)) at one pixel; st: LDS mean[64], rstd[64]
+template <bool ACT = false>       // ACT: the map holds activated values already (k_act_pyramid)
 __device__ __forceinline__ void ld_act8(const float* __restrict__ raw, const float* st, size_t pix, int g, f32x4& v0, f32x4& v1) {
     const float* p = raw + pix * 64 + g * 8;
     v0 = *(const f32x4*)p; v1 = *(const f32x4*)(p + 4);
+    if constexpr (ACT) return;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         v0[q] = fmaxf(fmaf(v0[q], st[64 + g * 8 + q], st[g * 8 + q]), 0.f);
@@ -91,19 +93,43 @@ __device__ __forceinline__ void ld_act8(const float* __restrict__ raw, const flo
     }
 }
 // bilinear sample (ATen arithmetic: fma(w0, v0, w1*v1) per axis) of relu(bn(raw)) for 8 channels
+template <bool ACT = false>
 __device__ __forceinline__ void up_bilinear8(const float* __restrict__ raw, const float* st, int Hi, int Wi, int Ho, int Wo, int y, int x, int g, f32x4& o0, f32x4& o1) {
     int y0, y1, x0, x1; float hy0, hy1, wx0, wx1;
     lin_coeff_c(Hi, Ho, y, y0, y1, hy0, hy1);
     lin_coeff_c(Wi, Wo, x, x0, x1, wx0, wx1);
     f32x4 a0, a1, b0, b1, c0, c1, d0, d1;
-    ld_act8(raw, st, (size_t)y0 * Wi + x0, g, a0, a1); ld_act8(raw, st, (size_t)y0 * Wi + x1, g, b0, b1);
-    ld_act8(raw, st, (size_t)y1 * Wi + x0, g, c0, c1); ld_act8(raw, st, (size_t)y1 * Wi + x1, g, d0, d1);
+    ld_act8<ACT>(raw, st, (size_t)y0 * Wi + x0, g, a0, a1); ld_act8<ACT>(raw, st, (size_t)y0 * Wi + x1, g, b0, b1);
+    ld_act8<ACT>(raw, st, (size_t)y1 * Wi + x0, g, c0, c1); ld_act8<ACT>(raw, st, (size_t)y1 * Wi + x1, g, d0, d1);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const float t0 = fmaf(wx0, a0[j], wx1 * b0[j]), u0 = fmaf(wx0, c0[j], wx1 * d0[j]);
         o0[j] = fmaf(hy0, t0, hy1 * u0);
         const float t1 = fmaf(wx0, a1[j], wx1 * b1[j]), u1 = fmaf(wx0, c1[j], wx1 * d1[j]);
         o1[j] = fmaf(hy0, t1, hy1 * u1);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// k_act_pyramid (batches > 32): relu(bn(.)) of the two coarse maps of the pyramid, x4 (1/16) and x5 (1/32), written once.  block_fusion.0 builds its
+// input x3 + up2(x4) + up4(x5) while staging (PRO_FUSE): every staged value takes eight bilinear taps, and activating each tap on the fly cost 3 VALU
+// instructions per tap and channel -- half of that kernel's extra vector work over a plain 3x3 layer, on the pipe its MFMAs use -- for maps that are
+// 1/4 and 1/16 of its own input.  Same fma + max per element, computed once instead of at every use: identical bits.  Needs finalised statistics
+// (k_bn_finalize or the weight file's), hence not for batches <= 8.
+__global__ __launch_bounds__(256)
+void k_act_pyramid(const float* __restrict__ raw4, size_t s4, const float* __restrict__ st4, int n4 /* floats per frame */,
+                   const float* __restrict__ raw5, size_t s5, const float* __restrict__ st5, int n5, float* __restrict__ act4, float* __restrict__ act5) {
+    const int b = blockIdx.z;
+    for (int q = blockIdx.x * 256 + threadIdx.x; q < (n4 + n5) / 4; q += gridDim.x * 256) {
+        const bool five = q >= n4 / 4;
+        const int e = (five ? q - n4 / 4 : q) * 4, ch = e & 63;
+        const float* st = (five ? st5 : st4) + (size_t)b * 128;
+        const size_t off = (size_t)b * (five ? s5 : s4) + e;
+        f32x4 v = *(const f32x4*)((five ? raw5 : raw4) + off);
+        const f32x4 be = *(const f32x4*)(st + ch), al = *(const f32x4*)(st + 64 + ch);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaf(v[j], al[j], be[j]), 0.f);
+        *(f32x4*)((five ? act5 : act4) + off) = v;
     }
 }
 
@@ -567,7 +593,8 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs a, const int tile,
     // and with one or two workgroups per CU nothing else covers that).  PRO_FUSE gathers its taps per item below.
     constexpr int NITEM = TIH * TIW * G;
     constexpr int NIT = (NITEM + NTHR - 1) / NTHR;
-    constexpr bool BATCHED = PRO != PRO_FUSE;
+    constexpr bool FUSE = PRO == PRO_FUSE || PRO == PRO_FUSEA;
+    constexpr bool BATCHED = !FUSE;
     f32x4 r0[BATCHED ? NIT : 1], r1[BATCHED ? NIT : 1];
     float rp[PRO == PRO_B2IN ? NIT : 1];
     if constexpr (BATCHED) {
@@ -583,7 +610,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs a, const int tile,
     }
     XFH_STAMP(a, 1);
     // producer statistics -> LDS (folded here for small batches; s_in is still free and serves as fp64 scratch)
-    if constexpr (PRO == PRO_BN || PRO == PRO_B2IN || PRO == PRO_FUSE) stage_stat(a.st, b, CIN, tile == 0, s_stat, (double*)s_in, t, NTHR);
+    if constexpr (PRO == PRO_BN || PRO == PRO_B2IN || FUSE) stage_stat(a.st, b, CIN, tile == 0, s_stat, (double*)s_in, t, NTHR);
     if constexpr (PRO == PRO_B2IN) {
         for (int q = t; q < CIN; q += NTHR) { s_stat[2 * CIN + q] = a.skip_w[q]; s_stat[3 * CIN + q] = a.skip_b[q]; }
         __syncthreads();
@@ -647,8 +674,8 @@ __device__ __forceinline__ void conv_mfma_body(const ConvArgs a, const int tile,
             }
             // x3 + up2(x4) + up4(x5) with ATen's bilinear arithmetic (XFeat.cc:159-166)
             f32x4 u0, u1, w0, w1;
-            up_bilinear8(a.r4 + (size_t)b * a.s4, s_stat + 128, a.H4, a.W4, a.Hin, a.Win, gy, gx, g, u0, u1);
-            up_bilinear8(a.r5 + (size_t)b * a.s5, s_stat + 256, a.H5, a.W5, a.Hin, a.Win, gy, gx, g, w0, w1);
+            up_bilinear8<PRO == PRO_FUSEA>(a.r4 + (size_t)b * a.s4, s_stat + 128, a.H4, a.W4, a.Hin, a.Win, gy, gx, g, u0, u1);
+            up_bilinear8<PRO == PRO_FUSEA>(a.r5 + (size_t)b * a.s5, s_stat + 256, a.H5, a.W5, a.Hin, a.Win, gy, gx, g, w0, w1);
 #pragma unroll
             for (int q = 0; q < 4; ++q) { v0[q] = (v0[q] + u0[q]) + w0[q]; v1[q] = (v1[q] + u1[q]) + w1[q]; }
         }
@@ -1588,7 +1615,7 @@ static hipError_t conv_mfma_launch(xfh_ctx* c, const ConvArgs& a, int B, int* np
     constexpr int TIH = (TH - 1) * ST + KS, TIW = (TW - 1) * ST + KS;
     constexpr int CB = CIN > CBMAX ? CBMAX : CIN;
     constexpr int NWBUF = (KS * KS * (CIN / CB) / TPC) > 1 ? 2 : 1;
-    constexpr int STATF = PRO == PRO_FUSE ? 384 : (PRO == PRO_B2IN ? 4 * CIN : 2 * CIN);
+    constexpr int STATF = (PRO == PRO_FUSE || PRO == PRO_FUSEA) ? 384 : (PRO == PRO_B2IN ? 4 * CIN : 2 * CIN);
     constexpr size_t LDS = sizeof(float) * ((size_t)TIH * TIW * (CIN + 4) + NWBUF * (size_t)COUTP * (TPC * CB + 4) + STATF);
     static_assert(LDS <= 160 * 1024, "LDS budget");
     static_assert(sizeof(double) * WM * COUTP * 2 <= LDS, "stat scratch");
@@ -1800,7 +1827,14 @@ static hipError_t launch_basic_layer_t(xfh_ctx* c, int li, const float* in, size
                        : t2 > XFH_M16_TALL ? conv_mfma16_launch<64, 64, 1, 16, 4, PRO_BN, EPI>(c, a, B, &np, li) : conv_mfma16_launch<64, 64, 1, 16, 2, PRO_BN, EPI>(c, a, B, &np, li);
             } else {
                 a.w = c->w.alt[li];
-                if (li == 16) e = conv_mfma_launch<64, 64, 3, 1, 4, 2, 1, 16, PRO_FUSE, EPI, 32>(c, a, B, &np, li);
+                if (li == 16) {
+                    // the coarse maps activated once (k_act_pyramid) instead of at every one of block_fusion.0's eight taps per staged value
+                    const int n4 = c->lh[11] * c->lw[11] * 64, n5 = c->lh[15] * c->lw[15] * 64;
+                    hipLaunchKernelGGL(k_act_pyramid, dim3(((n4 + n5) / 4 + 255) / 256, 1, B), dim3(256), 0, c->stream, (const float*)c->raw[11], c->raw_stride[11],
+                                       (const float*)c->stat[11], n4, (const float*)c->raw[15], c->raw_stride[15], (const float*)c->stat[15], n5, c->act4, c->act5);
+                    a.r4 = c->act4; a.r5 = c->act5;
+                    e = conv_mfma_launch<64, 64, 3, 1, 4, 2, 1, 16, PRO_FUSEA, EPI, 32>(c, a, B, &np, li);
+                }
                 else if constexpr ((XFH_CONV_T & 16) != 0) e = conv_mfma_t_launch<64, 64, 3, 1, 4, 2, 1, 16, PRO_BN, EPI, 32>(c, a, B, &np, li);
                 else e = conv_mfma_launch<64, 64, 3, 1, 4, 2, 1, 16, PRO_BN, EPI, 32>(c, a, B, &np, li);
             }
