@@ -86,6 +86,7 @@ for n, d in agg.items():
     elif "k_best2_csr" in n: bytes_, bound = 4096.0 * 64 * (256 + 4) + 4096 * 256, "hbm"      # 64 gathered 256-byte rows per query (L2 resident table)
     elif "k_distinctive_csr" in n: bytes_, bound = 4096.0 * 16 * (256 + 4), "hbm"
     elif "k_block1_stats" in n: bytes_, bound, flops = 4.0 * B * H * W, "valu", 2.0 * H * W * 4 * 9 * B
+    elif "k_act_pyramid" in n: bytes_, bound = 2 * 4.0 * B * 64 * ((H // 16) * (W // 16) + (H // 32) * (W // 32)), "hbm"      # x4 and x5 read and written once
     elif "k_feat_norm" in n: bytes_, bound = 4.0 * B * (H // 8) * (W // 8) * 65, "hbm"
     elif "k_heads_kp" in n:
         bytes_, bound = 4.0 * B * (H // 8 * (W // 8) * 64 + H * W), "valu"
