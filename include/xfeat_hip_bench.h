@@ -50,7 +50,8 @@ int xfh_debug_match_plan(int n_pairs, const int* n1, const int* n2, int num_cu, 
 const char* xfh_kernel_name(int kernel_id);
 
 /* intermediate tensors of frame `frame` of the last extract call, copied to host as float
- * (ids match oracle/xfeat_oracle.h; image-like tensors are NHWC).  count_out = floats. */
+ * (ids match oracle/xfeat_oracle.h; image-like tensors are NHWC).  count_out = floats.
+ * Statistics (XSTAT, STAT0 + layer) are stored as the fma operands they are applied with: [C] beta = -(mean * rstd), then [C] alpha = rstd. */
 enum {
     XFH_T_X = 0, XFH_T_XSTAT = 1, XFH_T_SKIP_POOL = 2,                               /* 3, 4, 5, 7 (unfold2d(x), x1 + skip, fusion input, normalised features) */
     XFH_T_FEATS = 6, XFH_T_H1 = 8, XFH_T_K1H = 9,                                   /* are never materialised on the GPU: fused into consumers */
