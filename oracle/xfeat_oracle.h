@@ -43,7 +43,7 @@ typedef struct {
 
 enum {
     XFO_T_X = 0,        /* [H][W]        image/255 after the resize to multiples of 32 */
-    XFO_T_XSTAT = 1,    /* [2]           InstanceNorm mean, rstd                       */
+    XFO_T_XSTAT = 1,    /* [2]           InstanceNorm beta = -(mean * rstd), alpha = rstd */
     XFO_T_SKIP_POOL = 2,/* [H/4][W/4]    AvgPool4x4 of the normalised image            */
     XFO_T_XUNFOLD = 3,  /* [H/8][W/8][64] unfold2d(xhat, 8)                             */
     XFO_T_B2IN = 4,     /* [H/4][W/4][24] x1 + skip1(x)                                 */
@@ -54,7 +54,7 @@ enum {
     XFO_T_K1H = 9,      /* [H][W]        keypoint heatmap after softmax+depth-to-space  */
     XFO_T_LOGITS = 10,  /* [H/8][W/8][65] keypoint logits (oracle only)                 */
     XFO_T_RAW0 = 16,    /* +i: raw conv output of BasicLayer i (before BN), i = 0..22   */
-    XFO_T_STAT0 = 48,   /* +i: [2][C]  batch mean[C] then rstd[C] of BasicLayer i       */
+    XFO_T_STAT0 = 48,   /* +i: [2][C]  beta[C] = -(mean * rstd) then alpha[C] = rstd of BasicLayer i (applied as fma(x, alpha, beta)) */
     XFO_T_SEL = 80,     /* [N][3]      x, y, score of the top-N list, descending score  */
     XFO_T_CAND = 81     /* [C][3]      x, y, score of every NMS candidate, row-major    */
 };
