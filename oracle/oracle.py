@@ -53,6 +53,7 @@ def lib():
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
         L.xfo_distance_i32.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         L.xfo_descriptor_distance.argtypes = [C.c_void_p, C.c_void_p]
+        L.xfo_expf_array.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
         L.xfo_best2_csr.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 4
         L.xfo_distinctive_csr.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         _lib = L
@@ -124,6 +125,13 @@ def distance_i32(d1: np.ndarray, d2: np.ndarray) -> np.ndarray:
     out = np.zeros((len(d1), len(d2)), np.int32)
     lib().xfo_distance_i32(d1.ctypes.data, len(d1), d2.ctypes.data, len(d2), out.ctypes.data)
     return out
+
+
+def expf(x: np.ndarray) -> np.ndarray:
+    """the oracle's exp(): libtorch's vector exp (see xfeat_oracle.c: xfo_expf)"""
+    x = np.ascontiguousarray(x, np.float32); y = np.empty_like(x)
+    lib().xfo_expf_array(x.ctypes.data, y.ctypes.data, x.size)
+    return y
 
 
 def descriptor_distance(a: np.ndarray, b: np.ndarray) -> int:

@@ -176,6 +176,36 @@ int xfo_get_tensor(xfo_ctx* c, int id, const float** ptr, int64_t* count) {
 
 /* ------------------------------------------------------------------ building blocks */
 
+/* exp() as libtorch's CPU softmax and sigmoid kernels evaluate it: Vectorized<float>::exp() = Sleef_expf{8,16}_u10 in its
+ * FMA form -- q = rint(d * log2(e)); Cody-Waite reduction with two fma; degree-6 Horner polynomial in fma; 1 + (s*s*u + s);
+ * scaling by 2^q as two exact multiplications; 0 below -104, inf above 100.  The reference reaches it through
+ * torch::sigmoid (src/XFeat.cc:82) and F::softmax (src/XFextractor.cc:207).  Probed bit for bit in this container
+ * (tests/test_oracle.py::test_exp_is_atens_vector_exp): torch.sigmoid and F.softmax(dim=1) of a [1,65,h,w] tensor at one thread
+ * reproduce this arithmetic in EVERY element (sequential channel sum, true division); glibc's expf does not (1 % of the elements
+ * differ by an ulp).  With more threads libtorch's own chunk tails go through a scalar loop, i.e. the library is not bit-stable
+ * over thread counts there; the vector form is what all but the last few pixels of a map see. */
+float xfo_expf(float d) {
+    const float qf = rintf(d * 1.442695040888963407359924681001892137426645954152985934135449406931f);
+    const int q = (int)(qf < -300.f ? -300.f : (qf > 300.f ? 300.f : qf));      /* out-of-range arguments are overridden below */
+    float s = fmaf(qf, -0.693145751953125f, d);
+    s = fmaf(qf, -1.428606765330187045e-06f, s);
+    float u = 0.000198527617612853646278381f;
+    u = fmaf(u, s, 0.00139304355252534151077271f);
+    u = fmaf(u, s, 0.00833336077630519866943359f);
+    u = fmaf(u, s, 0.0416664853692054748535156f);
+    u = fmaf(u, s, 0.166666671633720397949219f);
+    u = fmaf(u, s, 0.5f);
+    u = 1.0f + fmaf(s * s, u, s);
+    union { float f; int32_t i; } a, b;
+    a.i = (int32_t)((uint32_t)((q >> 1) + 127) << 23);
+    b.i = (int32_t)((uint32_t)((q - (q >> 1)) + 127) << 23);
+    u = u * a.f * b.f;
+    if (d < -104.f) u = 0.f;
+    if (d > 100.f) u = INFINITY;
+    return u;
+}
+void xfo_expf_array(const float* x, float* y, int64_t n) { for (int64_t i = 0; i < n; ++i) y[i] = xfo_expf(x[i]); }
+
 /* ATen upsample_bilinear2d, align_corners=false (used by F::interpolate at
  * src/XFextractor.cc:198-200 and src/XFeat.cc:159-165): per output index the source
  * coordinate is max(scale*(d+0.5)-0.5, 0) with scale = in/out in fp32.  The libtorch CPU
@@ -485,7 +515,7 @@ int xfo_extract(xfo_ctx* c, const uint8_t* gray, int H0, int W0, int nfeatures, 
         float acc = 0.f;
         for (int ch = 0; ch < 64; ++ch) acc = fmaf(b[p * 64 + ch], c->heat2_w[ch], acc);
         acc += c->heat2_b;
-        H1[p] = 1.0f / (1.0f + expf(-acc));
+        H1[p] = 1.0f / (1.0f + xfo_expf(0.f - acc));
     }
     free(b);
     /* :170 keypoint_head(unfold2d(x, 8)); unfold2d (:124-133): channel = i*8 + j with i the
@@ -515,7 +545,7 @@ int xfo_extract(xfo_ctx* c, const uint8_t* gray, int H0, int W0, int nfeatures, 
         float mx = lg[0];
         for (int k = 1; k < 65; ++k) if (lg[k] > mx) mx = lg[k];
         float e[65]; float sum = 0.f;
-        for (int k = 0; k < 65; ++k) { e[k] = expf(lg[k] - mx); sum += e[k]; }
+        for (int k = 0; k < 65; ++k) { e[k] = xfo_expf(lg[k] - mx); sum += e[k]; }
         for (int i = 0; i < 8; ++i) for (int j = 0; j < 8; ++j)
             K1h[(size_t)(8 * y + i) * W + 8 * xx + j] = e[i * 8 + j] / sum;
     }

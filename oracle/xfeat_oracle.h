@@ -88,6 +88,9 @@ int xfo_match_mnn(const float* d1, int n1, const float* d2, int n2, float min_co
 /* dense form of ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:2242-2250) */
 int xfo_distance_i32(const float* d1, int n1, const float* d2, int n2, int32_t* out);
 int xfo_descriptor_distance(const float* a, const float* b);
+/* exp() of libtorch's CPU softmax / sigmoid kernels (Sleef u10, FMA form), see xfeat_oracle.c */
+float xfo_expf(float d);
+void xfo_expf_array(const float* x, float* y, int64_t n);
 
 /* best / second-best integer distance over per-query candidate lists: the inner loop of
  * ORBmatcher::SearchByProjection and friends (src/ORBmatcher.cc:75-119) */

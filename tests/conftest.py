@@ -37,6 +37,25 @@ def weights_dense():
     return w, WT.pack_blob(w)
 
 
+EXTRACT_GOLDENS = ["extract_96x128", "extract_vga", "extract_odd_170x230", "extract_720p", "extract_vga_dense_mono",
+                   # round 5, the parity campaign: weight family x image family (tests/golden/make_golden.py)
+                   "extract_vga_pruned_blobs", "extract_vga_heavy_saturated", "extract_720p_denormal_lowcontrast", "extract_vga_dc_steps"]
+
+
+def golden_inputs(g):
+    """(weights dict, image) a golden extraction case was generated from: the round-1 fixtures carry (gain, seed) of make_synthetic(1234) /
+    synth.image, the round-5 ones also a weight family, its seed and an image family"""
+    from xfeatslam_amd import synth, weights as WT
+    fam = str(g["family"]) if "family" in g.files else ""
+    if fam:
+        w = WT.make_family(fam, int(g["wseed"]), float(g["gain"]))
+        img = synth.image_family(str(g["image_family"]), int(g["H"]), int(g["W"]), int(g["seed"]))
+    else:
+        w = WT.make_synthetic(1234, float(g["gain"]))
+        img = synth.image(int(g["H"]), int(g["W"]), int(g["seed"]))
+    return w, img
+
+
 def kp_set(kps):
     v = kps["size"] > 0
     return set(zip(kps["x"][v].astype(int).tolist(), kps["y"][v].astype(int).tolist()))

@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, joined_desc_diff, kp_set, records_equal
+from conftest import EXTRACT_GOLDENS, GOLDEN, golden_inputs, joined_desc_diff, kp_set, records_equal
 from xfeatslam_amd import capi, synth, weights as WT
 
 pytestmark = pytest.mark.gpu
@@ -44,13 +44,14 @@ def test_extract_matches_oracle(gpu_lib, oracle_mod, H, W, gain, nf, lap):
     assert np.all(np.abs(nrm - 1.0) < 1e-5)                            # unit descriptors
 
 
-@pytest.mark.parametrize("name", ["extract_96x128", "extract_vga", "extract_vga_dense_mono", "extract_720p", "extract_odd_170x230"])
+@pytest.mark.parametrize("name", EXTRACT_GOLDENS)
 def test_extract_matches_golden(gpu_lib, name):
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
     H, W, nf = int(g["H"]), int(g["W"]), int(g["nfeatures"])
+    w, img = golden_inputs(g)
     ctx = _ctx(nf, H, W)
-    ctx.load_weights(WT.pack_blob(WT.make_synthetic(1234, float(g["gain"]))))
-    (kps, desc, nv, mono, nc), = ctx.extract_batch(synth.image(H, W, int(g["seed"]))[None], tuple(int(v) for v in g["lap"]))
+    ctx.load_weights(WT.pack_blob(w))
+    (kps, desc, nv, mono, nc), = ctx.extract_batch(img[None], tuple(int(v) for v in g["lap"]))
     ctx.close()
     assert (nv, mono, nc) == (int(g["n_valid"]), int(g["mono_index"]), int(g["n_candidates"]))
     assert kp_set(kps) == set(map(tuple, g["xy"].tolist()))
@@ -165,8 +166,10 @@ def test_stage_tensors_match_oracle(gpu_lib, oracle_mod, weights_std):
             a, b = raw(i), orc.tensor(OT["RAW0"] + i)
             assert a.shape == b.shape and np.abs(a - b).max() <= 1e-5, f"raw {i}"
         assert np.abs(ctx.debug_tensor(T["STAT0"] + i) - orc.tensor(OT["STAT0"] + i)).max() <= 1e-5, f"stat {i}"
-    assert np.abs(ctx.debug_tensor(T["H1"]) - orc.tensor(OT["H1"])).max() < 1e-6        # expf differs by <= 1 ulp
-    assert np.abs(ctx.debug_tensor(T["K1H"]) - orc.tensor(OT["K1H"])).max() < 1e-6
+    # round 5: both sides evaluate exp() as libtorch's vector kernels do (xfh_expf / xfo_expf, every step one IEEE fp32 operation): the
+    # sigmoid and softmax maps are the same bits (rounds 1-4: device expf against glibc expf, <= 1 ulp apart)
+    assert np.array_equal(ctx.debug_tensor(T["H1"]), orc.tensor(OT["H1"]))
+    assert np.array_equal(ctx.debug_tensor(T["K1H"]), orc.tensor(OT["K1H"]))
     hs, os_ = ctx.debug_tensor(T["SEL"]).reshape(-1, 3), orc.tensor(OT["SEL"]).reshape(-1, 3)
     assert set(map(tuple, hs[:, :2].astype(int))) == set(map(tuple, os_[:, :2].astype(int)))
     ctx.close()
@@ -644,13 +647,13 @@ def test_eval_bn_modes_through_the_pipeline_lanes(gpu_lib, weights_dense):
 def test_exact_score_tie_straddles_the_cut(gpu_lib, oracle_mod, weights_dense):
     """two NMS candidates with bit-equal scores on either side of rank nfeatures (tests/test_oracle.py::test_exact_score_tie_at_the_cut
     holds the frames): the 64-bit selection key is (~ordered(score), y * W + x), so the candidate with the lower pixel index wins the
-    cut -- the reference's stable order.  The device's expf may differ from glibc's by an ulp, so the tie is located in the DEVICE's
-    own score list first; where the device and the oracle tie at the same pair the two selected sets must be identical."""
+    cut -- the reference's stable order.  The tie is located in the DEVICE's own score list; since round 5 device and oracle evaluate the
+    same exp(), so the oracle ties at the same pair in every frame and the two selected sets must be identical."""
     _, blob = weights_dense
     H, W = 256, 320
     orc = oracle_mod.Oracle(blob)
     checked = same_pair = 0
-    for seed in (16, 42, 50):
+    for seed in (16, 19, 27, 50):
         img = synth.image(H, W, seed)
         full = _ctx(8192, H, W); full.load_weights(blob)
         full.extract_batch(img[None])
@@ -675,7 +678,7 @@ def test_exact_score_tie_straddles_the_cut(gpu_lib, oracle_mod, weights_dense):
             if osc[(int(a[0]), int(a[1]))] == osc[(int(b[0]), int(b[1]))]:            # the oracle ties at the same pair
                 assert kp_set(ok) == got
                 same_pair += 1
-    assert checked >= 1 and same_pair >= 1
+    assert checked >= 4 and same_pair == checked
 
 
 def test_border_and_origin_candidates(gpu_lib, oracle_mod, weights_dense):

@@ -39,6 +39,30 @@ __host__ __device__ inline float ord2f(unsigned u) {
     return __builtin_bit_cast(float, u);
 }
 
+// exp() as libtorch's CPU softmax / sigmoid kernels evaluate it (Vectorized<float>::exp = Sleef expf u10, FMA form; reached by the
+// reference through torch::sigmoid, src/XFeat.cc:82, and F::softmax, src/XFextractor.cc:207): q = rint(d * log2 e), two-fma
+// Cody-Waite reduction, degree-6 Horner chain in fma, 1 + (s*s*u + s), scaling by 2^q as two exact multiplications, 0 below -104,
+// inf above 100.  Every step is one IEEE fp32 operation, so the device result equals the oracle's xfo_expf -- and libtorch's own
+// vector kernels -- bit for bit (rounds 1-4 called the device library's expf here: 1 ulp away from glibc's in 1 % of the elements,
+// and both away from libtorch's).  Denormal results stay denormal (the kernels are compiled with fp32 denormals on, the gfx9 default).
+__device__ __forceinline__ float xfh_expf(float d) {
+    const float qf = __builtin_rintf(d * 1.442695040888963407359924681001892137426645954152985934135449406931f);
+    const int q = (int)__builtin_fminf(__builtin_fmaxf(qf, -300.f), 300.f);
+    float s = __builtin_fmaf(qf, -0.693145751953125f, d);
+    s = __builtin_fmaf(qf, -1.428606765330187045e-06f, s);
+    float u = 0.000198527617612853646278381f;
+    u = __builtin_fmaf(u, s, 0.00139304355252534151077271f);
+    u = __builtin_fmaf(u, s, 0.00833336077630519866943359f);
+    u = __builtin_fmaf(u, s, 0.0416664853692054748535156f);
+    u = __builtin_fmaf(u, s, 0.166666671633720397949219f);
+    u = __builtin_fmaf(u, s, 0.5f);
+    u = 1.0f + __builtin_fmaf(s * s, u, s);
+    u = u * __builtin_bit_cast(float, (unsigned)((q >> 1) + 127) << 23) * __builtin_bit_cast(float, (unsigned)((q - (q >> 1)) + 127) << 23);
+    if (d < -104.f) u = 0.f;
+    if (d > 100.f) u = __builtin_inff();
+    return u;
+}
+
 // hipcc (ROCm 7.2) pads the MFMA -> VALU-read hazard (18 wait states after a 16-pass v_mfma_f32_32x32x2_f32) along the
 // fall-through path only: with a taken branch between the last MFMA and the first read of its result a stale register
 // came back (k_conv_mfma_p<8,24,...>: 10 wait states).  Every kernel therefore lets the matrix pipe drain explicitly between

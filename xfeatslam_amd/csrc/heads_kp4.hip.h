@@ -96,7 +96,7 @@ __device__ __forceinline__ void heads_kp4_body(const Kp4Args ka, int block, int 
     }
     mx = fmaxf(mx, __shfl_xor(mx, 1)); mx = fmaxf(mx, __shfl_xor(mx, 2));
 #pragma unroll
-    for (int n = 0; n < 17; ++n) acc[n] = expf(acc[n] - mx);
+    for (int n = 0; n < 17; ++n) acc[n] = xfh_expf(acc[n] - mx);
     // sum over n = 0 .. 64 in that order: lane r continues the sum lane r - 1 has reached
     float sum = 0.f;
 #pragma unroll

@@ -149,7 +149,7 @@ void k_heads_heat(const float* __restrict__ rawH, StatSrc sH,     // heatmap_hea
     float acc = 0.f;
     for (int k = 0; k < 64; ++k) acc = fmaf(sA[k * HF_LD + t], wh[k], acc);
     acc += bh[0];
-    if (pix < npix) H1[(size_t)b * h1_stride + pix] = 1.0f / (1.0f + expf(-acc));
+    if (pix < npix) H1[(size_t)b * h1_stride + pix] = 1.0f / (1.0f + xfh_expf(0.f - acc));
 }
 
 // keypoint head: 64 -> 65, softmax, drop dustbin, depth-to-space (XFeat.cc:89, XFextractor.cc:204-217).
@@ -199,7 +199,7 @@ void k_heads_kp(const float* __restrict__ rawK, StatSrc sK,      // keypoint_hea
     for (int n = 0; n < 65; ++n) { acc[n] += bk[n]; mx = fmaxf(mx, acc[n]); }
     float sum = 0.f;
 #pragma unroll
-    for (int n = 0; n < 65; ++n) { acc[n] = expf(acc[n] - mx); sum += acc[n]; }
+    for (int n = 0; n < 65; ++n) { acc[n] = xfh_expf(acc[n] - mx); sum += acc[n]; }
     const Recip ks = recip_of(sum);                       // 64 softmax quotients share the divisor
     if (pix < npix) {
         const int y = pix / Wh, x = pix % Wh;
@@ -317,7 +317,7 @@ void k_nms_score(const float* __restrict__ K1h, size_t k_stride, const float* __
         float acc = 0.f;
         for (int c = 0; c < 64; ++c) acc = fmaf(s_act[t * 65 + c], wh[c], acc);
         acc += bh[0];
-        const float hval = 1.0f / (1.0f + expf(-acc));
+        const float hval = 1.0f / (1.0f + xfh_expf(0.f - acc));
         s_h1[t] = hval;
         const int r = t / NMS_HCW, c = t % NMS_HCW, cy = cyb + r, cx = cxb + c;
         if (r >= 1 && r <= NMS_TH / 8 && c >= 1 && c <= NMS_TW / 8 && cy < Hh && cx < Wh) H1out[(size_t)b * h_stride + (size_t)cy * Wh + cx] = hval;   // the tile's own cells

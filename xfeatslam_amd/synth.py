@@ -31,6 +31,57 @@ def image(H: int = 480, W: int = 640, seed: int = 42, blur: int = 2) -> np.ndarr
     return np.clip(np.rint((a - lo) / (hi - lo) * 255.0), 0, 255).astype(np.uint8)
 
 
+IMAGE_FAMILIES = ("noise", "steps", "gradient", "lowcontrast", "saturated", "checker8", "checker4", "blobs")
+
+
+def image_family(family: str, H: int = 480, W: int = 640, seed: int = 42) -> np.ndarray:
+    """u8 [H,W] frames of the parity campaign: the structure box-blurred noise lacks.
+
+    noise        `image()`
+    steps        piecewise constant: 40 random axis-aligned rectangles of random grey level over a flat ground (step edges, corners,
+                 T-junctions; large flat regions, where the 8x8 cells of the keypoint head see identical inputs)
+    gradient     a horizontal and a vertical ramp added, quantised to u8 (every 8x8 cell differs from its neighbour by a constant)
+    lowcontrast  noise squeezed into 8 grey levels around 128 (InstanceNorm amplifies the quantisation steps)
+    saturated    left half of the frame 0, a band of 255, the rest noise (half the pixels identical)
+    checker8     8x8-pixel squares 0 / 255 aligned with the keypoint head's cells: a frame of exactly periodic cells, the worst case
+                 for ties in the 5x5 NMS and at the top-k cut
+    checker4     4x4-pixel squares 32 / 224 (period 8): every cell holds the same 2x2 pattern
+    blobs        smooth Gaussian bumps on a dark ground (isolated strong maxima)
+    """
+    if family == "noise":
+        return image(H, W, seed)
+    yy, xx = np.mgrid[0:H, 0:W]
+    if family == "steps":
+        a = np.full((H, W), 90.0)
+        r = uniform01(seed, 11, 40 * 5).reshape(40, 5)
+        for x0, y0, ww, hh, g in r:
+            xa, ya = int(x0 * W), int(y0 * H)
+            xb, yb = min(W, xa + 8 + int(ww * W / 3)), min(H, ya + 8 + int(hh * H / 3))
+            a[ya:yb, xa:xb] = np.rint(g * 255.0)
+        return a.astype(np.uint8)
+    if family == "gradient":
+        return np.clip(np.rint(xx * (200.0 / max(W - 1, 1)) + yy * (55.0 / max(H - 1, 1))), 0, 255).astype(np.uint8)
+    if family == "lowcontrast":
+        return (124 + (image(H, W, seed).astype(np.int32) * 8) // 256).astype(np.uint8)
+    if family == "saturated":
+        a = image(H, W, seed).copy()
+        a[:, : W // 2] = 0
+        a[:, W // 2: W // 2 + W // 8] = 255
+        return a
+    if family == "checker8":
+        return np.where(((yy // 8) + (xx // 8)) % 2 == 0, 0, 255).astype(np.uint8)
+    if family == "checker4":
+        return np.where(((yy // 4) + (xx // 4)) % 2 == 0, 32, 224).astype(np.uint8)
+    if family == "blobs":
+        a = np.zeros((H, W))
+        r = uniform01(seed, 13, 60 * 4).reshape(60, 4)
+        for cx, cy, sg, amp in r:
+            s2 = (2.0 + 10.0 * sg) ** 2
+            a += (0.3 + amp) * np.exp(-((xx - cx * W) ** 2 + (yy - cy * H) ** 2) / (2.0 * s2))
+        return np.clip(np.rint(a / a.max() * 255.0), 0, 255).astype(np.uint8)
+    raise ValueError(family)
+
+
 def frames(B: int, H: int = 480, W: int = 640, seed: int = 42) -> np.ndarray:
     """u8 [B,H,W]; frame i uses seed+i."""
     return np.stack([image(H, W, seed + i) for i in range(B)])

@@ -118,6 +118,86 @@ def make_synthetic(seed: int = 1234, kp_logit_gain: float = 1.0, with_bn: bool =
     return out
 
 
+# ---- weight families of the parity campaign (tests/test_oracle.py, tests/test_gpu_campaign.py) -------------------------------
+# The trained `weights/xfeat.pt` is absent, so breadth has to stand in for it: every family below is a deterministic function of
+# (name, seed) and stresses one thing a trained net can do and U(-b, b) draws never do.
+FAMILIES = ("uniform", "normal", "heavy", "scaled", "tiny", "pruned", "dc", "heat_on", "heat_off", "heat_denormal", "peaky")
+
+
+def _normal01(seed: int, stream: int, n: int) -> np.ndarray:
+    u1 = uniform01(seed, 2 * stream + 5000, n)
+    u2 = uniform01(seed, 2 * stream + 5001, n)
+    return np.sqrt(-2.0 * np.log(1.0 - u1)) * np.cos(2.0 * np.pi * u2)
+
+
+def make_family(family: str, seed: int = 1, kp_logit_gain: float = 3.0) -> "OrderedDict[str, np.ndarray]":
+    """One member of a weight family (same tensor table as `make_synthetic`).
+
+    uniform        the `make_synthetic` draw with another seed
+    normal         N(0, 1/fan_in)
+    heavy          Student-t, 3 degrees of freedom, scaled to the same variance (a few weights 10-30 x the rest)
+    scaled         BasicLayer i multiplied by 10 (i even) or 0.1 (i odd): raw maps of very different magnitude feed BatchNorm
+    tiny           every third BasicLayer x 3e-3: its channel variances (~3e-6) fall below eps = 1e-5, rstd saturates towards 316
+    pruned         a quarter of the output filters of every BasicLayer are all-zero (dead channels: raw map = 0, variance 0), and so
+                   is one input channel of every layer that follows
+    dc             a quarter of the output filters of every BasicLayer behind block1.0 are `|w| + 4 b`: all-positive filters on
+                   non-negative inputs, the largest |mean| / sigma this architecture can produce (BasicLayers carry no bias)
+    heat_on/off    heatmap_head.2.bias = +30 / -110: sigmoid saturates to exactly 1 / exactly 0 (no valid keypoint at all)
+    heat_denormal  heatmap_head.2.bias = -87: reliabilities around 1e-38, i.e. on both sides of the smallest normal fp32 number; the
+                   scores (x K1h <= 1) are fp32 denormals but > 0, so every candidate stays valid
+    peaky          keypoint_head.3 x 12: a near one-hot 65-way softmax, exp() arguments down to -100
+    """
+    if family not in FAMILIES:
+        raise ValueError(family)
+    shapes = dict(TENSORS)
+    w = make_synthetic(seed, kp_logit_gain)
+    if family in ("normal", "heavy"):
+        for i, (name, shape) in enumerate(TENSORS):
+            fan_in = int(np.prod((shapes[name[:-4] + "weight"] if name.endswith("bias") else shape)[1:]))
+            n = int(np.prod(shape))
+            z = _normal01(seed, i, n)
+            if family == "heavy":
+                chi = sum(_normal01(seed, 100 + 3 * i + k, n) ** 2 for k in range(3)) / 3.0
+                z = z / np.sqrt(chi) / np.sqrt(3.0)                       # t3 has variance 3
+            a = (z / np.sqrt(fan_in)).astype(np.float32).reshape(shape)
+            if name == "keypoint_head.3.weight":
+                a = (a * np.float32(kp_logit_gain)).astype(np.float32)
+            w[name] = a
+    basic = [n for n, _ in TENSORS if n.endswith(".layer.0.weight")]
+    if family == "scaled":
+        for i, n in enumerate(basic):
+            w[n] = (w[n] * np.float32(10.0 if i % 2 == 0 else 0.1)).astype(np.float32)
+    elif family == "tiny":
+        for n in basic[1::3]:
+            w[n] = (w[n] * np.float32(3e-3)).astype(np.float32)
+    elif family == "pruned":
+        for i, n in enumerate(basic):
+            co, ci = shapes[n][0], shapes[n][1]
+            dead = uniform01(seed, 900 + i, co) < 0.25
+            dead[0] = True
+            w[n][dead] = 0.0
+            if ci > 1:
+                w[n][:, int(uniform01(seed, 950 + i, 1)[0] * ci)] = 0.0
+    elif family == "dc":
+        for i, n in enumerate(basic):
+            if n == "block1.0.layer.0.weight" or n.startswith("keypoint_head.0"):       # inputs of mean 0: a DC filter gives no mean there
+                continue
+            co = shapes[n][0]
+            b = 1.0 / np.sqrt(float(np.prod(shapes[n][1:])))
+            pick = uniform01(seed, 800 + i, co) < 0.25
+            pick[co - 1] = True
+            w[n][pick] = (np.abs(w[n][pick]) + np.float32(4.0 * b)).astype(np.float32)
+    elif family == "heat_on":
+        w["heatmap_head.2.bias"][:] = 30.0
+    elif family == "heat_off":
+        w["heatmap_head.2.bias"][:] = -110.0
+    elif family == "heat_denormal":
+        w["heatmap_head.2.bias"][:] = -87.0
+    elif family == "peaky":
+        w["keypoint_head.3.weight"] = (w["keypoint_head.3.weight"] * np.float32(12.0 / kp_logit_gain)).astype(np.float32)
+    return w
+
+
 def pack_blob(weights: "dict[str, np.ndarray]") -> bytes:
     entries = []
     data = []
