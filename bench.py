@@ -308,7 +308,7 @@ def main():
         "value": frames_per_s, "unit": "frames/s", "n_gpus": N, "steps": K, "warmup": args.warmup,
         "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"configs[1]: {H}x{W} u8 frames, XFeat extract, nfeatures {nf}, {B * S} distinct frames per GPU per step "
+        "config": {"workload": f"configs[1], HBM-resident (host-visible: config.host_visible_frames_per_s): {H}x{W} u8 frames, XFeat extract, nfeatures {nf}, {B * S} distinct frames per GPU per step "
                                f"({S} sub-batch(es) of {B}, each on its own ctx / HIP streams) ({BN_TEXT[args.bn]}), inputs and 4096-row records resident in HBM"
                                + (f", RCCL {GATHER_TEXT[args.gather]} through the C ABI (xfh_comm_*), overlapped with the next step" if use_comm else ""),
                    "frames_per_gpu_per_step": B * S, "sub_batches_in_flight": S, "height": H, "width": W, "nfeatures": nf,
@@ -357,6 +357,7 @@ def main():
     if not args.no_legs:
         legs(out, args, lib, capi, synth, Context, ctx, blob, frames, d_in, d_rec[0], B, H, W, nf, rec_bytes, traffic, N)
 
+    flat_scalars(out, N)
     if use_comm:
         sync()
         comm.close()
@@ -365,6 +366,67 @@ def main():
         C.CDLL(None).fflush(None)                          # RCCL's banner sits in the C stdio buffer of fd 1: out to stderr with it
         os.dup2(saved_stdout, 1)
     print(json.dumps(out), flush=True)
+
+
+def flat_scalars(out, N):
+    """The figures a reader of the driver's record needs, as flat scalars inside `config` and `roofline` (the driver's parser keeps scalars of those two
+    objects and drops nested ones: BENCH_r04.json lost `host_visible`, `match` and `step_roofline`).  `value` stays the HBM-resident regime -- the bench
+    contract: "inputs already resident in HBM when the timed region starts ... the PCIe-inclusive rate is never `value`" -- and SURVEY.md 8d's host-visible
+    reading of the same metric sits next to it."""
+    c, r = out["config"], out["roofline"]
+    c["hbm_resident_frames_per_s_per_gpu"] = out["value"] / N
+    if "host_visible" in out:
+        hv = out["host_visible"]
+        c["host_visible_frames_per_s"] = hv["value"]                                   # SURVEY.md 8d read literally: host memory -> host memory, PCIe inside the clock (rank 0's GPU)
+        c["host_visible_blocking_frames_per_s"] = hv["blocking"]["value"]
+        c["host_visible_vs_hbm_resident"] = hv["vs_hbm_resident"]
+        if "one_frame_per_call" in hv:
+            c["host_visible_one_frame_per_call_frames_per_s"] = hv["one_frame_per_call"]["value"]
+    if "single_frame" in out:
+        c["single_frame_ms"] = out["single_frame"]["ms_per_frame"]
+    if "step_roofline" in out:
+        c["step_mfma_frac"] = out["step_roofline"]["frac"]
+        r["step_frac"] = out["step_roofline"]["frac"]
+    m = out.get("match")
+    if m:
+        flop = 2.0 * m["n1"] * m["n2"] * 64
+        c["match_us_per_call"] = m["us_per_call"]
+        c["match_pairs_per_s"] = m["pairs_per_s"]
+        c["match_call_frac"] = flop / (m["us_per_call"] * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS
+        c["match_gemm_us"] = m["roofline"]["avg_launch_us"]
+        c["match_gemm_frac"] = m["roofline"]["frac"]
+        r["match_gemm_frac"] = m["roofline"]["frac"]
+        r["match_call_frac"] = c["match_call_frac"]
+        if "batched" in m:
+            c["match_batched_us_per_pair"] = m["batched"]["us_per_pair"]
+            c["match_batched_pairs_per_s"] = m["batched"]["pairs_per_s"]
+            c["match_batched_call_frac"] = flop / (m["batched"]["us_per_pair"] * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS
+            c["match_batched_gemm_frac"] = m["batched"]["roofline"]["frac"]
+        if "paced_30hz" in m:
+            c["match_paced_30hz_us_per_call"] = m["paced_30hz"]["us_per_call_median"]
+    ak = out.get("aux_kernels") or {}
+    for k, v in ak.items():
+        if k.startswith("k_dist_i32"):
+            c["dist_i32_kernel_us"] = v["kernel_us"]
+    par = out.get("parity")
+    if par:
+        c["parity_keypoint_sets_equal"] = bool(par["keypoint_sets_equal"])
+        c["parity_max_abs_desc_diff"] = par["max_abs_desc_diff"]
+        c["parity_match_pairs_equal"] = bool(par["match_pairs_equal"])
+    if isinstance(out.get("extract_only"), dict):                                      # multi-rank legs (N > 1): scaling with and without the exchange, side by side
+        c["extract_only_frames_per_s"] = out["extract_only"]["frames_per_s"]
+        c["gather_cost_frac"] = 1.0 - out["value"] / out["extract_only"]["frames_per_s"]
+    for form, v in (out.get("gather_forms") or {}).items():
+        if isinstance(v, dict) and "frames_per_s" in v:
+            c[f"gather_{form}_frames_per_s"] = v["frames_per_s"]
+    c3 = out.get("configs3")
+    if isinstance(c3, dict):
+        for form, v in c3.get("per_gather_form", {}).items():
+            c[f"configs3_{form}_frames_per_s"] = v["frames_per_s"]
+            c[f"configs3_{form}_latency_ms"] = v["one_step_latency_ms"]
+    c31 = out.get("configs3_one_gpu")
+    if isinstance(c31, dict):
+        c["configs3_one_gpu_frames_per_s"] = c31["device_resident"]["frames_per_s"]
 
 
 PCIE_GBPS = 63.0      # PCIe 5.0 x16, one direction, after 128b/130b (tools/pcie_probe.py on the bench box: 56.5 GB/s for one copy stream)
@@ -846,6 +908,21 @@ def legs(out, args, lib, capi, synth, Context, ctx, blob, frames, d_in, d_recb, 
                     "epilogue is below this peak as well: DESIGN.md 5"}
     for b in (bimgs, brec, bout, bcnt):
         b.free()
+
+    # ---- what a tracker at 30 Hz sees: ONE match call per 33 ms on an otherwise idle GPU, i.e. inside the clock ramp the back-to-back loops above
+    # deliberately leave.  Two stream events around the single call (xfh_bench_match_prepared with one iteration).
+    if not args.only_match_leg:
+        paced = []
+        c_one = C.c_double(0.0)
+        for _ in range(24):
+            time.sleep(0.033)
+            capi.check(lib.xfh_bench_match_prepared(ctx.h, hand1, nf, hand2, nf, -1.0, *mo, 1, C.byref(c_one)), ctx.h)
+            paced.append(c_one.value)
+        paced_s = sorted(paced[4:])
+        out["match"]["paced_30hz"] = {"us_per_call_median": paced_s[len(paced_s) // 2], "us_per_call_min": paced_s[0], "us_per_call_max": paced_s[-1], "calls": len(paced_s),
+                                      "frac_of_peak": gemm_flop / (paced_s[len(paced_s) // 2] * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                                      "note": "one xfh_match_mnn_prepared_device call every 33 ms from an idle GPU, two stream events around the call: the GPU never leaves its idle clock, "
+                                              "so this is slower than `us_per_call` (calls back to back on a settled clock); it is what a 30 Hz tracker that matches once per frame gets"}
 
     # ---- the other matcher kernels (no timing anywhere in round 1) ----------------------------------------------------
     aux = {}

@@ -503,6 +503,44 @@ def test_match_records_drops_padding_pairs(gpu_lib, oracle_mod):
     ctx.close()
 
 
+def test_reload_weights_while_batches_in_flight(gpu_lib):
+    """xfh_load_weights replaces the packed buffers, and the pipeline lanes are host threads that hold copies of the pointers.
+    A reload issued while multi-sub-batch submits are outstanding must first wait for the lanes: the outstanding submits complete with the OLD weights
+    (records equal to a blocking call before the reload), later calls use the NEW weights, nothing reads freed memory.  Repeated, alternating two sets."""
+    L = gpu_lib
+    H, W, nf, S = 96, 128, 256, 4
+    n = 6 * S
+    fr = synth.frames(n, H, W, seed=321)
+    blobs = [WT.pack_blob(WT.make_synthetic(1234, 6.0)), WT.pack_blob(WT.make_family("heavy", 9))]
+    ctx = _ctx(nf, H, W, B=S)
+    rb = ctx.rec_bytes
+    hin = capi.HostBuffer(fr.nbytes); hin.array[:] = fr.reshape(-1)
+    want = []
+    for b in blobs:
+        ctx.load_weights(b)
+        o = np.zeros(n * rb, np.uint8)
+        capi.check(L.xfh_extract_batch(ctx.h, hin.ptr, n, H, W, 0, 64, o.ctypes.data), ctx.h)
+        want.append(o)
+    houts = [capi.HostBuffer(n * rb) for _ in range(2)]
+    cur = 1
+    for it in range(12):
+        for h in houts:
+            h.array[:] = 0
+            capi.check(L.xfh_extract_batch_submit(ctx.h, hin.ptr, n, H, W, 0, 64, h.ptr), ctx.h)
+        nxt = 1 - cur
+        ctx.load_weights(blobs[nxt])                         # while two submits (12 sub-batches) are queued on the lanes
+        capi.check(L.xfh_extract_batch_drain(ctx.h), ctx.h)
+        for h in houts:
+            assert records_equal(ctx, h.array, want[cur], n), it        # the outstanding work saw the old weights, complete and intact
+        cur = nxt
+        o = np.zeros(n * rb, np.uint8)
+        capi.check(L.xfh_extract_batch(ctx.h, hin.ptr, n, H, W, 0, 64, o.ctypes.data), ctx.h)
+        assert records_equal(ctx, o, want[cur], n), it
+    for h in houts + [hin]:
+        h.free()
+    ctx.close()
+
+
 def test_host_visible_batch_pipeline(gpu_lib, oracle_mod, weights_dense):
     """xfh_extract_batch / _submit / _wait (host frames in, host records out): a call of B frames with B far above
     cfg.max_batch is cut into sub-batches that go into one queue drained by the lanes (own activations and streams, shared weights, a worker

@@ -412,7 +412,14 @@ int xfh_load_weights(xfh_ctx* c, const void* blob, size_t nbytes) {
     // pointers: until the reload has succeeded nobody has weights, and whatever happens the children get the parent's current state -- after a
     // failed reload that is "not loaded" (xfh_extract* then return XFH_ERR_NO_WEIGHTS) instead of pointers into freed memory.
     c->w.loaded = false;
+    // Nothing of this ctx may be in flight while the buffers are replaced: the pipeline lanes are HOST threads holding copies of the weight pointers
+    // (a lane between its upload and its kernels is not covered by hipFree's device synchronisation), the twin and the ctx' own streams may still run
+    // a submitted frame.  Wait for all of them first.
+    pipe_wait_idle(c);
+    for (int l = 0; l < c->pipe.nlanes; ++l) if (c->pipe.lane[l].ctx) HIPCK(c, hipStreamSynchronize(c->pipe.lane[l].ctx->stream));
     if (c->twin) HIPCK(c, hipStreamSynchronize(c->twin->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    if (c->aux_stream) HIPCK(c, hipStreamSynchronize(c->aux_stream));
     const int rc = load_weights_impl(c, blob, nbytes);
     int rs = XFH_OK;
     if (c->twin) rs = ctx_share_weights(c, c->twin);

@@ -28,7 +28,10 @@ struct xfh_ctx;
 // B frames is cut into sub-batches of cfg.max_batch frames.  One sub-batch: on the ctx itself, in order on its stream (H2D, kernels, D2H, an event).
 // More: the sub-batches go into ONE queue that up to XFH_PIPE_MAX_LANES worker lanes drain.  A lane = a child ctx (own activations and streams,
 // the parent's weights) + a copy stream + a host thread that drives, per sub-batch, copy in -> wait -> kernels -> wait -> copy out -> wait: no copy
-// command ever sits in a stream in front of a kernel and there is no GPU-side event wait anywhere; the lanes overlap each other.  pipeline.cpp says why.
+// command ever sits in a stream in front of a kernel and no stream waits for a COPY on the GPU (the only event waits left are the fork / join of a lane's own
+// keypoint branch onto its second kernel stream for sub-batches above 8 frames, kernel to kernel); the lanes overlap each other.  pipeline.cpp says why.
+// Cost: the first submit of more than one sub-batch builds min(sub-batches, xfh_pipeline_lanes) lanes, each a FULL ctx with activations for
+// cfg.max_batch frames (29 MB per VGA frame: 1.9 GB per lane at max_batch 64) and a host thread; XFH_ERR_OUT_OF_MEMORY surfaces at that submit.
 #define XFH_PIPE_MAX_LANES 8
 #define XFH_PIPE_MAX_BATCHES 8                   // xfh_extract_batch_submit calls outstanding (include/xfeat_hip.h: XFH_MAX_BATCHES_INFLIGHT)
 struct PipeShared;                               // queue, mutex, condition variables, per-slot counters (pipeline.cpp)
@@ -124,6 +127,7 @@ struct XfhRange { explicit XfhRange(const char* n) { xfh_trace_push(n); } ~XfhRa
 int ctx_share_weights(xfh_ctx* parent, xfh_ctx* child);      // child borrows the parent's packed weights (and its eval()-mode statistics)
 void pipe_destroy(xfh_ctx* c);
 int pipe_reshare_weights(xfh_ctx* c);
+void pipe_wait_idle(xfh_ctx* c);
 
 // helpers implemented in capi.cpp
 // kernel timing: when the timer is armed for (kernel_id, layer) the launch goes through

@@ -19,7 +19,8 @@
 //      event: 22-26 k by box and by step size.  Its flaw: a lane's next kernels sit BEHIND its own download in the stream, and lanes that started
 //      together stay in phase -- all four compute, then all four copy (22.4 k at 256 frames per step, 25.6 k at 512 on one box).
 //  (4) this file, round 4: the ordering moves to the HOST.  Every lane has a worker thread that drives its sub-batch with blocking waits -- copy in
-//      (copy stream), kernels (the lane ctx' streams), copy out (copy stream) -- so a stream never holds a command that waits for another engine,
+//      (copy stream), kernels (the lane ctx' streams), copy out (copy stream) -- so a stream never holds a command that waits for a copy engine (a lane's
+//      two kernel streams still fork / join its keypoint branch by events for sub-batches above 8 frames, kernel to kernel: run_extract, as on any ctx),
 //      and a lane that is copying simply is not in anybody's way.  Sub-batches sit in one queue; whichever lane is free takes the next.  Measured with
 //      tools/host_thread_probe.py before it was built: 28.5 k (4 lanes) - 29.2 k (8) against 30.5-31 k device resident on the same box.
 // A submit of ONE sub-batch (B <= cfg.max_batch: the latency case) runs on the ctx itself, in order on its stream, as before: no thread hand-off.
@@ -91,7 +92,7 @@ static void lane_main(xfh_ctx* parent, int li) {
     }
 }
 
-static void pipe_wait_idle(xfh_ctx* c) {          // every queued sub-batch has landed
+void pipe_wait_idle(xfh_ctx* c) {                 // every queued sub-batch has landed (also called by xfh_load_weights before it touches a buffer)
     Pipe& P = c->pipe;
     if (!P.sh) return;
     std::unique_lock<std::mutex> lk(P.sh->m);
@@ -168,8 +169,14 @@ int xfh_host_unregister(void* p) { return !p || hipHostUnregister(p) == hipSucce
 
 int xfh_pipeline_lanes(xfh_ctx* c, int lanes) {
     if (!c || lanes < 1 || lanes > XFH_PIPE_MAX_LANES) return XFH_ERR_INVALID_ARG;
-    c->pipe.max_lanes = lanes;                         // lanes already built stay; with a smaller number the surplus ones sleep
-    if (c->pipe.sh) c->pipe.sh->cv_job.notify_all();
+    // lanes already built stay; with a smaller number the surplus ones sleep.  The workers read max_lanes inside their wait predicate under the
+    // shared mutex: the store takes the same mutex, so a wake-up can not fall between a worker's check and its sleep
+    if (c->pipe.sh) {
+        { std::lock_guard<std::mutex> lk(c->pipe.sh->m); c->pipe.max_lanes = lanes; }
+        c->pipe.sh->cv_job.notify_all();
+    } else {
+        c->pipe.max_lanes = lanes;
+    }
     return XFH_OK;
 }
 
