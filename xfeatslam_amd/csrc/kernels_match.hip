@@ -21,116 +21,7 @@
 #include <utility>
 #include <stdlib.h>
 
-// ---- k_dist_mfma: dense table of ORBmatcher::DescriptorDistance (ORBmatcher.cc:2246-2247) -----------------------
-//     out[i][j] = (int)(float(sum_k double(a_k - b_k)^2) * 512)          (cv::norm NORM_L2SQR: fp32 difference, fp64 accumulate)
-// The table is HBM-write bound (n1 * n2 * 4 bytes), the exact expression is fp64 VALU work 10x above that bound.  So the
-// bulk goes through the matrix cores: d^2 = |a|^2 + |b|^2 - 2 <a, b> with the norms in fp64 and the dot product from
-// v_mfma_f32_32x32x2_f32, combined in fp64.  That value v = 512 d^2 differs from the exact 512 * float(s) by at most
-//     E = 512 * (64 * 2^-24 * (|a|^2 + |b|^2)          fp32 fma chain of the dot product (gamma_64 |a||b| <= gamma_64 (|a|^2+|b|^2)/2, times 2)
-//              + 2^-22 * d^2)                           fp32 rounding of each difference (2^-23 relative on the sum) and of float(s) (2^-24)
-// so wherever v is further than E from an integer, floor(v) IS the reference's integer.  The other entries (about 1 % for
-// unit descriptors; all entries that are exact integers, e.g. against zero-padded rows) are marked in an LDS bitmap and
-// recomputed with the exact expression from the tiles that are still in LDS.  Identical integers by construction; the
-// C oracle (sequential fp64) is the checker in tests/test_gpu_match.py::test_distance_i32_exact.
-#define DT 128          // tile edge
-#define DLDK 68         // padded LDS row (floats)
-__global__ __launch_bounds__(256, 2)
-void k_dist_mfma(const float* __restrict__ d1, int n1, const float* __restrict__ d2, int n2, int32_t* __restrict__ out) {
-    __shared__ __attribute__((aligned(16))) float sA[DT * DLDK];
-    __shared__ __attribute__((aligned(16))) float sB[DT * DLDK];
-    __shared__ double sNa[DT], sNb[DT];
-    __shared__ unsigned sMask[DT * 4];                    // [row][4 words]: entries to recompute exactly
-    const int t = threadIdx.x, sub = t & 15, r0 = t >> 4;
-    const int row_base = blockIdx.y * DT, col_base = blockIdx.x * DT;
-    for (int e = t; e < DT * 4; e += 256) sMask[e] = 0u;
-    // staging: 16 lanes per row; k permutation inside each group of 8 (element e at 4*(e&1) + (e>>1)) by one pair exchange
-#pragma unroll
-    for (int side = 0; side < 2; ++side) {
-        const float* d = side ? d2 : d1;
-        const int n = side ? n2 : n1, base = side ? col_base : row_base;
-        float* sT = side ? sB : sA;
-        double* sN = side ? sNb : sNa;
-#pragma unroll
-        for (int p = 0; p < 8; ++p) {
-            const int rl = p * 16 + r0, row = base + rl;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (row < n) v = *(const f32x4*)(d + (size_t)row * 64 + sub * 4);
-            double ss = (double)v.x * (double)v.x + (double)v.y * (double)v.y + (double)v.z * (double)v.z + (double)v.w * (double)v.w;
-            ss += __shfl_xor(ss, 1); ss += __shfl_xor(ss, 2); ss += __shfl_xor(ss, 4); ss += __shfl_xor(ss, 8);
-            if (sub == 0) sN[rl] = ss;
-            const bool odd = sub & 1;
-            const float sx = odd ? v.x : v.y, sy = odd ? v.z : v.w;
-            const float rx = __shfl_xor(sx, 1), ry = __shfl_xor(sy, 1);
-            const f32x4 o = odd ? f32x4{rx, ry, v.y, v.w} : f32x4{v.x, v.z, rx, ry};
-            *(f32x4*)(sT + rl * DLDK + (sub >> 1) * 8 + (odd ? 4 : 0)) = o;
-        }
-    }
-    __syncthreads();
-    const int wave = t >> 6, lane = t & 63, i = lane & 31, h = lane >> 5;
-    const int wr = wave >> 1, wc = wave & 1;
-    const float* pa = sA + (wr * 64 + i) * DLDK + 4 * h;
-    const float* pb = sB + (wc * 64 + i) * DLDK + 4 * h;
-    const f32x16 Z16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int g = 0; g < 8; ++g) {
-        const f32x4 a0 = *(const f32x4*)(pa + g * 8), a1 = *(const f32x4*)(pa + 32 * DLDK + g * 8);
-        const f32x4 b0 = *(const f32x4*)(pb + g * 8), b1 = *(const f32x4*)(pb + 32 * DLDK + g * 8);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[j], (g | j) ? acc[0][0] : Z16, 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b1[j], (g | j) ? acc[0][1] : Z16, 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b0[j], (g | j) ? acc[1][0] : Z16, 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1[j], (g | j) ? acc[1][1] : Z16, 0, 0, 0);
-        }
-    }
-    XFH_MFMA_SETTLE();                                      // common.h: the epilogue branches
-    // acc[rt][ct][r] = < row wr*64 + rt*32 + (r&3) + 8*(r>>2) + 4*h , column wc*64 + ct*32 + i >
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-        const int cl = wc * 64 + ct * 32 + i, col = col_base + cl;
-        const double nb = sNb[cl];
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rl = wr * 64 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, row = row_base + rl;
-                const double na = sNa[rl];
-                const double d2v = na + nb - 2.0 * (double)acc[rt][ct][r];
-                const double v = 512.0 * d2v;
-                const double E = 512.0 * (3.814697265625e-6 * (na + nb) + 2.384185791015625e-7 * fabs(d2v));
-                const double fl = floor(v), fr = v - fl;
-                const bool safe = (fr > E) && (fr < 1.0 - E) && (v < 2.0e9);      // NaN / huge values fail every test: exact path
-                if (row < n1 && col < n2) {
-                    if (safe) out[(size_t)row * n2 + col] = (int32_t)fl;
-                    else atomicOr(&sMask[rl * 4 + (cl >> 5)], 1u << (cl & 31));
-                }
-            }
-    }
-    __syncthreads();
-    // exact expression for the marked entries, from the tiles in LDS: element k = 8g + 2j + hh sits at 8g + 4hh + j
-    for (int w = t; w < DT * 4; w += 256) {
-        unsigned m = sMask[w];
-        const int rl = w >> 2;
-        const float* ra = sA + rl * DLDK;
-        while (m) {
-            const int bit = __builtin_ctz(m); m &= m - 1;
-            const int cl = (w & 3) * 32 + bit;
-            const float* rb = sB + cl * DLDK;
-            double s = 0.0;
-            for (int g = 0; g < 8; ++g)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int hh = 0; hh < 2; ++hh) {
-                        const double df = (double)(ra[g * 8 + 4 * hh + j] - rb[g * 8 + 4 * hh + j]);
-                        s = fma(df, df, s);
-                    }
-            const float nd = (float)s;
-            out[(size_t)(row_base + rl) * n2 + col_base + cl] = (int)(nd * 512.0f);
-        }
-    }
-}
+#include "dist_mfma.hip.h"
 
 // ---- k_best2_csr: best / second-best integer distance over per-query candidate lists -----------
 // One wave per query (the query row comes through the scalar cache); lane l visits candidates
@@ -421,6 +312,7 @@ hipError_t bench_mnn_gemm_batch(xfh_ctx* c, const XfhMatchPair* pairs, int n_pai
 
 hipError_t launch_dist_i32(xfh_ctx* c, const float* d1, int n1, const float* d2, int n2, int32_t* out) {
     if (n1 <= 0 || n2 <= 0) return hipSuccess;
-    launch_k(c, XFH_K_DIST_I32, -1, k_dist_mfma, dim3((n2 + DT - 1) / DT, (n1 + DT - 1) / DT), dim3(256), 0, d1, n1, d2, n2, out);
+    const int nt = dist_tiles_per_block(n1, n2, c->num_cu);
+    launch_k(c, XFH_K_DIST_I32, -1, k_dist_mfma<0>, dim3((n2 + nt * DTC - 1) / (nt * DTC), (n1 + DT - 1) / DT), dim3(512), 0, d1, n1, d2, n2, out, nt);
     return hipGetLastError();
 }
