@@ -214,6 +214,7 @@ def main():
 
     def step(form=None):
         form = form or args.gather
+        step.count = step_no[0] + 1
         # S sub-batches of B frames, each on its own ctx / stream; the exchange of generation g runs on the ctx's
         # communication stream while the next step extracts into the other generation
         g = step_no[0] & 1 if use_comm else 0
@@ -325,6 +326,7 @@ def main():
     if traffic and traffic.get("conv_bytes_per_launch"):
         conv_traffic = traffic["conv_bytes_per_launch"] * (B / traffic["conv_batch"] if traffic.get("conv_batch") else 1.0)
     out["config"]["bn_mode"] = args.bn
+    out["config"]["library"] = lib.xfh_version().decode()
     pmc_src = "profiles/pmc_traffic.json: the builder's separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes (tools/gpu_round.sh), corrected with the factors calibrated on known-byte-count kernels (xfh_bench_calib); a constant in this run, not an observation of it"
     step_tf = net_flops(H, W) * frames_per_s / N / 1e12
     out["step_roofline"] = {"what": "all convolutions of the network (algorithmic flops per frame) x frames/s per GPU of the timed region, against the f32 MFMA peak: "
@@ -419,6 +421,9 @@ def flat_scalars(out, N):
     for form, v in (out.get("gather_forms") or {}).items():
         if isinstance(v, dict) and "frames_per_s" in v:
             c[f"gather_{form}_frames_per_s"] = v["frames_per_s"]
+    if isinstance(out.get("exchange_check"), dict):
+        c["exchange_records_equal_serial_ctx"] = bool(out["exchange_check"]["equal_to_serial_ctx"])
+        c["exchange_records_checked"] = out["exchange_check"]["records_checked"]
     c3 = out.get("configs3")
     if isinstance(c3, dict):
         for form, v in c3.get("per_gather_form", {}).items():
@@ -431,6 +436,10 @@ def flat_scalars(out, N):
 
 PCIE_GBPS = 63.0      # PCIe 5.0 x16, one direction, after 128b/130b (tools/pcie_probe.py on the bench box: 56.5 GB/s for one copy stream)
 C3_H, C3_W = 720, 1280
+
+
+def step_no_of(step):
+    return getattr(step, "count", 0)
 
 
 def multi_rank_legs(args, lib, capi, synth, Context, xd, comm, ctx, blob, rank, N, dev, nf, rec_bytes, step, timed, gather, gather_target, frames_per_rank):
@@ -456,6 +465,30 @@ def multi_rank_legs(args, lib, capi, synth, Context, xd, comm, ctx, blob, rank, 
     comm.fence(0); comm.fence(1)
     res["extract_only"] = {"frames_per_s": N * frames_per_rank / dt, "ms_per_step": dt * 1e3, "steps": k2,
                            "note": "no gather: extraction on every rank, MAX over ranks of the step time; value / this = what the exchange costs at this N"}
+    # ---- what rank 0 holds after the default exchange IS what a serial ctx produces for those frames: one step with xfh_allgather_records, then rank 0
+    # regenerates the first frames of EVERY rank's shard (the frames are a function of (seed, rank)), extracts them alone on its own ctx and compares the
+    # records field by field (header, keypoints, descriptors; statistics are per frame, so the batch a frame sat in does not matter)
+    gather_target("allgather", frames_per_rank)
+    timed(lambda: step("allgather"), 1, warm=0)             # one step between two barriers, every ctx and the communicator idle afterwards
+    if rank == 0:
+        nchk = min(2, frames_per_rank)
+        tgt = gather_target("allgather", frames_per_rank)[(step_no_of(step) - 1) & 1]
+        equal, checked = True, 0
+        for r in range(N):
+            fr = synth.frames(nchk, args.height, args.width, seed=42 + 1000 * r)
+            d_f = capi.DeviceBuffer(fr.nbytes).upload(fr); d_r = capi.DeviceBuffer(nchk * rec_bytes)
+            capi.check(lib.xfh_extract_batch_device(ctx.h, d_f.ptr, nchk, args.height, args.width, 0, 0, d_r.ptr), ctx.h)
+            ctx.synchronize()
+            want = ctx.parse_records(d_r.download(np.uint8, nchk * rec_bytes), nchk)
+            got = ctx.parse_records(tgt.download(np.uint8, nchk * rec_bytes, r * frames_per_rank * rec_bytes), nchk)
+            for a, b in zip(got, want):
+                equal = equal and a[2:] == b[2:] and bool(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]))
+                checked += 1
+            d_f.free(); d_r.free()
+        res["exchange_check"] = {"records_checked": checked, "ranks": N, "equal_to_serial_ctx": bool(equal),
+                                 "what": f"after one xfh_allgather_records step: the first {nchk} records of every rank's shard as they sit in rank 0's gathered buffer, against "
+                                         "the same frames extracted alone on rank 0's ctx (header, keypoints, descriptors bit for bit)"}
+    comm.barrier_max(0.0)
     # ---- configs[3] ---------------------------------------------------------------------------------------------------
     ctx3 = Context(nfeatures=nf, max_height=C3_H, max_width=C3_W, max_batch=1, device=dev)
     ctx3.load_weights(blob)

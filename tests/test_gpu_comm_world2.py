@@ -139,3 +139,17 @@ def test_bench_runs_with_n_ranks(gpu_lib, tmp_path, world):
     assert all(v["frames_per_s"] > 0 and v["one_step_latency_ms"] > 0 for v in c3["per_gather_form"].values())
     assert line["roofline"]["frac"] > 0 and "in_timed_region" in line["roofline"] and line["host_visible"]["value"] > 0
     assert line["match"]["batched"]["pair_lists_equal_pair_by_pair_calls"] is True
+    # the first real multi-GPU curve should explain itself: the partitioning is named, every multi-rank sub-key agrees on the world size, the flat scalars
+    # the driver keeps carry the headline next to the extraction alone, and what rank 0 holds after the exchange equals a serial ctx's records
+    cfg = line["config"]
+    assert cfg["parallelism"] == f"frames x{world}"
+    assert c3["n_ranks"] == world and line["exchange_check"]["ranks"] == world
+    assert line["exchange_check"]["equal_to_serial_ctx"] is True and line["exchange_check"]["records_checked"] == 2 * world
+    assert cfg["exchange_records_equal_serial_ctx"] is True
+    assert cfg["extract_only_frames_per_s"] == line["extract_only"]["frames_per_s"] and 0 <= 1 - line["value"] / cfg["extract_only_frames_per_s"] == cfg["gather_cost_frac"] or cfg["gather_cost_frac"] < 0
+    for form in ("root", "compact"):
+        assert cfg[f"gather_{form}_frames_per_s"] == line["gather_forms"][form]["frames_per_s"]
+    for form in ("allgather", "root", "compact"):
+        assert cfg[f"configs3_{form}_frames_per_s"] > 0
+    assert cfg["host_visible_frames_per_s"] == line["host_visible"]["value"] and cfg["match_us_per_call"] == line["match"]["us_per_call"]
+    assert "gfx950" in cfg["library"]

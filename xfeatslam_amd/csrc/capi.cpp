@@ -44,7 +44,22 @@ bool xfh_verbose() { static const bool v = []() { const char* e = getenv("XFH_VE
 
 extern "C" {
 
-const char* xfh_version(void) { return "xfeat_hip 0.1 (gfx950)"; }
+// "xfeat_hip 0.1 (gfx950); built with <clang version of the hipcc that compiled this file>, HIP <HIP_VERSION of the headers>; runtime HIP <hipRuntimeGetVersion>,
+// driver <hipDriverGetVersion>": the library carries hand-counted MFMA hazard padding (common.h: XFH_MFMA_SETTLE), so the compiler it was built with and
+// the runtime it meets are part of its identity (bench.py prints the string, tests/test_gpu_hazard.py checks the padding with the box's own compiler)
+const char* xfh_version(void) {
+    static char buf[320];
+    static bool done = false;
+    if (!done) {
+        int rt = 0, drv = 0;
+        if (hipRuntimeGetVersion(&rt) != hipSuccess) rt = 0;
+        if (hipDriverGetVersion(&drv) != hipSuccess) drv = 0;
+        snprintf(buf, sizeof buf, "xfeat_hip 0.1 (gfx950); built with clang %d.%d.%d, HIP %d.%d.%d; runtime HIP %d, driver %d",
+                 __clang_major__, __clang_minor__, __clang_patchlevel__, HIP_VERSION_MAJOR, HIP_VERSION_MINOR, HIP_VERSION_PATCH, rt, drv);
+        done = true;
+    }
+    return buf;
+}
 
 const char* xfh_strerror(int s) {
     switch (s) {
