@@ -51,12 +51,15 @@ sys.path.insert(0, ROOT)
 PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, dense f32 MFMA
 
 # MFMA-busy of the dominant kernels from the builder's SQ-counter pass over a serial 64-frame step (tools/pmc_kernels.sh -> profiles/r04_pmc_kernels_B64.json)
-PMC_BUSY_SRC = ("profiles/r04_pmc_kernels_B64.json: SQ_VALU_MFMA_BUSY_CYCLES (busy SIMD-cycles, calibrated on a pure MFMA loop) / (launch duration x 1024 SIMDs x 2.4 GHz) from the "
+PMC_BUSY_SRC = ("profiles/r05_pmc_kernels_B64.json (r04 if that round's file is all there is): SQ_VALU_MFMA_BUSY_CYCLES (busy SIMD-cycles, calibrated on a pure MFMA loop) / (launch duration x 1024 SIMDs x 2.4 GHz) from the "
                 "builder's rocprofv3 --pmc pass over a serial 64-frame step; a constant in this run, not an observation of it")
-try:
-    _pmck = json.load(open(os.path.join(ROOT, "profiles", "r04_pmc_kernels_B64.json")))["kernels"]
-except Exception:
-    _pmck = {}
+_pmck = {}
+for _tag in ("r05", "r04"):
+    try:
+        _pmck = json.load(open(os.path.join(ROOT, "profiles", _tag + "_pmc_kernels_B64.json")))["kernels"]
+        break
+    except Exception:
+        pass
 
 def pmc_busy(prefix):
     for k_, v_ in _pmck.items():
@@ -344,7 +347,7 @@ def main():
     kname = ("k_conv_mfma<64,64,3,...>" if B > 32 else "k_conv_mfma16<64,64,1,16,2,...> (16x16x4 tiles, the form for batches <= 32)") + " (block3.1, block_fusion.1: 3x3 64->64 at 1/8 res)" + ("" if args.bn != "folded" else ", bias+ReLU epilogue")
     out["roofline"] = {"kernel": kname,
                        "measured": f"HIP events attached to every dispatch of the kernel (hipExtLaunchKernelGGL): the same launches ({B} frames each) with ONE ctx alone on the GPU "
-                                   "right after the timed region -- the kernel's own duration, the view rocprofv3 --kernel-trace gives of a serial run (profiles/r04_roofline_table_B64.md: "
+                                   "right after the timed region -- the kernel's own duration, the view rocprofv3 --kernel-trace gives of a serial run (profiles/r05_roofline_table_B64.md: "
                                    "`bench.py --streams 1 --batch 64 --serial-branch --only-match-leg` under rocprofv3, 191 us per launch on the box whose events read 192)",
                        "bound": "mfma", "achieved": iso_tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": iso_tf / PEAK_F32_MFMA_TFLOPS,
                        "traffic": conv_traffic, "traffic_source": pmc_src if conv_traffic else None,

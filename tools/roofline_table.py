@@ -81,8 +81,13 @@ for n, d in agg.items():
         flops, bytes_, bound = 2.0 * 4096 * 4096 * 64 * MATCH_PAIRS, (1 + MATCH_PAIRS) * 4096 * 256.0, "mfma"
     elif "k_mnn_gemm" in n:
         flops, bytes_, bound = 2.0 * 4096 * 4096 * 64, 2 * 4096 * 256.0, "mfma"
-    elif "k_dist_mfma" in n:                         # 4096 x 4096 int32 distance table (DescriptorDistance of every pair): the 64 MB write bounds it
-        flops, bytes_, bound = 2.0 * 4096 * 4096 * 64, 4096.0 * 4096 * 4 + 2 * 4096 * 256.0, "hbm"
+    elif "k_dist_mfma" in n:                         # 4096 x 4096 int32 distance table (DescriptorDistance of every pair): 2.1 GFLOP of f32 MFMA (13.7 us) bound it before the 64 MB write (8.4 us) does
+        flops, bytes_, bound = 2.0 * 4096 * 4096 * 64, 4096.0 * 4096 * 4 + 2 * 4096 * 256.0, "mfma"
+    elif "k_mnn_post" in n:
+        # bytes a pair's rows fetch from L2 / Infinity Cache (nothing of it is compulsory HBM traffic): per d1 row its row-key planes (16 x 8 B; 4 x 8 B behind
+        # k_mnn_gemm_seg, which merges a panel's planes), 16 candidate d2 rows of 256 B, the column keys of the 16 candidates over 16 planes (16 x 16 x 8 B)
+        npairs = MATCH_PAIRS if "batch" in n else 1
+        bytes_, bound = npairs * 4096.0 * ((32 if "batch" in n else 128) + 16 * 256 + 16 * 16 * 8), "cache"
     elif "k_best2_csr" in n: bytes_, bound = 4096.0 * 64 * (256 + 4) + 4096 * 256, "hbm"      # 64 gathered 256-byte rows per query (L2 resident table)
     elif "k_distinctive_csr" in n: bytes_, bound = 4096.0 * 16 * (256 + 4), "hbm"
     elif "k_block1_stats" in n: bytes_, bound, flops = 4.0 * B * H * W, "valu", 2.0 * H * W * 4 * 9 * B
@@ -100,6 +105,8 @@ for n, d in agg.items():
     elif "k_nms_score" in n: bytes_, bound = 4.0 * B * H * W, "valu"
     elif "k_desc" in n: bytes_, bound = B * 4096.0 * (4 * 256 + 284), "hbm"
     elif "k_rownorm" in n: bytes_, bound = 2 * 4096 * 256.0 * 2, "hbm"
+    if per_step < 0.9:                               # not a kernel of the timed step (a small-batch / eval()-mode instance that one of the bench legs launches): its bytes would be priced with the step's geometry
+        continue
     rows.append((us * per_step, n, len(d), per_step, us, flops, bytes_, bound))
 rows.sort(key=lambda r: -r[0])
 MATCH = ("k_mnn", "k_rownorm", "k_dist_mfma", "k_best2_csr", "k_distinctive_csr")
@@ -116,7 +123,7 @@ with open(out, "w") as o:
             f"Source: rocprofv3 --kernel-trace of `python bench.py --streams 1 --batch {B} --serial-branch` (all kernels serial on one stream; tools/gpu_round.sh), launches with the batched grid only; {steps} steps.  The matcher kernels (k_mnn_*, k_rownorm_img, k_dist_mfma, k_best2_csr, k_distinctive_csr) are the 4096 x 4096 legs of the same run.\n"
             f"`alg` = algorithmic flops / HBM bytes per launch (raw input map read once + raw output map written once; no halo, no weights);\n"
             f"achieved = alg / average duration; % of the bound's peak (f32 MFMA {PEAK_TF} TFLOP/s, HBM {PEAK_TB} TB/s).  `latency` = per-frame single\n"
-            f"workgroup or dependent-launch bound kernels (no meaningful roofline).  Extraction kernels sum to {tot:.0f} us per step = {tot / B:.1f} us per frame.\n"
+            f"workgroup or dependent-launch bound kernels (no meaningful roofline); `cache` = k_mnn_post[_batch]: the key planes and candidate rows a pair's rows fetch (L2 / Infinity Cache traffic, no compulsory HBM bytes).  Extraction kernels sum to {tot:.0f} us per step = {tot / B:.1f} us per frame.\n"
             f"`valu` = kernels whose traffic is within 1.05 - 1.25 x of algorithmic while they sit far below the HBM peak: bound by their vector work; for them (and as a second\n"
             f"figure for the MFMA kernels) `pipe` = share of the 1024 SIMDs' cycles the launch's plain VALU instructions (4 cycles each; SQ_INSTS_VALU minus the MFMAs it includes) and MFMAs (64 / 32 cycles) account for,\n"
             f"from the SQ counters of a serial step (tools/pmc_kernels.sh; VALU and f32 MFMA share one pipe on gfx950, profiles/{tag}_pipe_probe.log) at 2.4 GHz; `mfma busy` = SQ_VALU_MFMA_BUSY_CYCLES (busy SIMD-cycles, calibrated on a pure MFMA loop) / (launch duration in the counter run x 1024 SIMDs x 2.4 GHz).\n\n"
@@ -126,6 +133,7 @@ with open(out, "w") as o:
         if bound == "mfma": ach, pct = f"{fl / us / 1e6:.1f} TFLOP/s", f"{fl / us / 1e6 / PEAK_TF * 100:.0f} %"
         elif bound == "hbm": ach, pct = f"{by / us / 1e6:.2f} TB/s", f"{by / us / 1e6 / PEAK_TB * 100:.0f} %"
         elif bound == "valu": ach, pct = (f"{by / us / 1e6:.2f} TB/s" if by else "-"), (f"{by / us / 1e6 / PEAK_TB * 100:.0f} % of HBM" if by else "-")
+        elif bound == "cache": ach, pct = f"{by / us / 1e6:.2f} TB/s from L2 / Infinity Cache", f"({by / us / 1e6 / PEAK_TB * 100:.0f} % of the HBM rate)"
         else: ach, pct = "-", "-"
         pm = pmc_of(nm)
         pipe = mb = "-"
@@ -135,4 +143,26 @@ with open(out, "w") as o:
             mb = f"{pm['mfma_busy_pct']:.0f} %" if pm.get('mfma_busy_pct') is not None and pm['mfma_per_launch'] > 0 else "-"
         o.write(f"| `{nm}` | {per:.0f} | {us:.1f} | {tot_us:.1f} | {bound} | {fl / 1e9:.2f} | {by / 1e6:.1f} | {ach} | {pct} | {pipe} | {mb} |\n" if fl and by else
                 f"| `{nm}` | {per:.0f} | {us:.1f} | {tot_us:.1f} | {bound} | {'-' if not fl else f'{fl / 1e9:.2f}'} | {'-' if not by else f'{by / 1e6:.1f}'} | {ach} | {pct} | {pipe} | {mb} |\n")
+# ---- the same kernels inside the default bench's timed region (four ctx of 64 frames side by side): gpurun_out/prof/*kernel_trace.csv + gpurun_out/bench_prof.json
+try:
+    f2 = glob.glob(os.path.join(ROOT, "gpurun_out", "prof", "*kernel_trace.csv"))[0]
+    l2 = json.loads(open(os.path.join(ROOT, "gpurun_out", "bench_prof.json")).read().strip().splitlines()[-1])
+    c2 = l2["config"]; S2 = c2["sub_batches_in_flight"]; B2 = c2["frames_per_gpu_per_step"] // S2
+    if not suffix and B2 != B:
+        agg2 = collections.defaultdict(list)
+        for r in csv.DictReader(open(f2)):
+            gz, gx = int(r["Grid_Size_Z"]), int(r["Grid_Size_X"]) // max(int(r["Workgroup_Size_X"]), 1)
+            n = r["Kernel_Name"]
+            if gz == B2 or (gx == B2 and any(k in n for k in ("k_bn_finalize", "k_select"))) or "k_conv_mfma_p" in n or "k_chain1x1" in n:
+                agg2[n].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        nsub = len(agg2[[k for k in agg2 if "k_preproc" in k][0]])             # sub-batches traced (timed region + warm-up + the legs that run the same grid)
+        ksum = sum(sum(d) for n, d in agg2.items() if len(d) >= 0.9 * nsub) / 1e3 / nsub * S2
+        with open(out, "a") as o:
+            o.write(f"\n## The same step as the bench runs it: {S2} ctx of {B2} frames side by side\n\n"
+                    f"rocprofv3 --kernel-trace of the default `python bench.py` ({nsub} sub-batches of {B2} frames traced): the durations of one step's launches ({S2} sub-batches) add up to "
+                    f"**{ksum:.0f} us**, the step takes **{l2['ms_per_step'] * 1e3:.0f} us** of wall time in that run ({l2['value']:.0f} frames/s): with {S2} streams a launch shares the CUs with the other "
+                    f"sub-batches' kernels, so every single launch is longer than in the serial table above ({tot:.0f} us for {B} frames on one stream = {tot / B * B2 * S2:.0f} us per {B2 * S2} frames), "
+                    f"and the overlap of the streams (memory-bound kernels of one sub-batch beside the MFMA-bound ones of another) is what brings the wall time below the serial sum.\n")
+except Exception as e:       # noqa: BLE001
+    print("in-region view skipped:", e)
 print(open(out).read())

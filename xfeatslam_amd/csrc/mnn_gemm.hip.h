@@ -22,12 +22,13 @@ __device__ __forceinline__ void mnn_dma1k(const float* gsrc_lane, float* lds_dst
 // Two-level exact arg-max.  On gfx950 the f32 MFMA issues on the SIMD's vector pipe, so every epilogue VALU
 // instruction costs matrix time.  The epilogue therefore takes only VALUE maxima (v_max3_f32: half an instruction
 // per value and direction) over candidate groups that are fixed by the lane position:
-//     d1 row  -> best value over a group of 16 consecutive d2 rows   (key: value, d2 row / 16)
+//     d1 row  -> best value over a group of 4 consecutive d2 rows    (key: value, d2 row / 4: the four rows one lane holds; found in two steps,
+//                the maximum over 16 first, then which quarter of that group reaches it)
 //     d2 row  -> best value over a group of 16 consecutive d1 rows   (key: value, d1 row / 16)
 // as keys (ordered(value) << 32 | ~group), merged across waves through LDS and written to this block's plane:
 //     partR[blockIdx.x][d1 row]   (ldr = rows per plane),   partC[blockIdx.y][d2 row]   (ldc)
 // k_mnn_post takes the maximum over the planes: largest value, then lowest group = torch.max's "first index of the
-// maximum" once it has named the first member of the group that reaches the value (it recomputes the <= 16 dot
+// maximum" once it has named the first member of the group that reaches the value (it recomputes the 4 / <= 16 dot
 // products with the MFMA's own arithmetic).  Every plane entry of a launched block is written (0 = no valid product),
 // so nothing has to be cleared between calls.
 template <int PRIO, int PIPE, int STG, int DBG = 0>      // DBG (probes only): 1 = no epilogue, 2 = no staging
@@ -210,8 +211,11 @@ void k_mnn_gemm_img(const float* __restrict__ img1, int n1, const float* __restr
         int gi = 7;
 #pragma unroll
         for (int g = 6; g >= 0; --g) gi = (mg[g] == M) ? g : gi;
-        // source lanes 4*gi .. 4*gi+3 of this wave column <-> d2 rows col_base + wc*128 + 16*gi .. +15
-        const unsigned grp = (unsigned)((col_base + wc * 128) >> 4) + (unsigned)gi;
+        // source lanes 4*gi .. 4*gi+3 of this wave column <-> d2 rows col_base + wc*128 + 16*gi .. +15; the first of the four that reaches M names the
+        // candidate group: source lane s holds the d2 rows col_base + wc*128 + 4s .. 4s+3 (one more LDS read at a computed address, three selects)
+        const f32x4 wv = *(const f32x4*)(src + gi * 4);
+        const int li = (wv.x == M) ? 0 : ((wv.y == M) ? 1 : ((wv.z == M) ? 2 : 3));
+        const unsigned grp = (unsigned)((col_base + wc * 128) >> 2) + (unsigned)(gi * 4 + li);
         sRow[wc * 256 + wr * 64 + lane] = (M > NEG) ? mnn_pack_key(M, grp) : 0ull;
     }
     __syncthreads();

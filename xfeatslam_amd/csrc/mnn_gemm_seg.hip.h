@@ -299,10 +299,13 @@ void k_mnn_gemm_seg(const MnnBatch jb) {
                 int gi = 7;
 #pragma unroll
                 for (int g = 6; g >= 0; --g) gi = (mg[g] == M) ? g : gi;
-                // source lanes 4*gi .. 4*gi+3 <-> d2 rows col_base + wc*128 + 16*gi .. +15
+                // source lanes 4*gi .. 4*gi+3 <-> d2 rows col_base + wc*128 + 16*gi .. +15; the first of the four that reaches M names the candidate
+                // group of 4 d2 rows (source lane s holds col_base + wc*128 + 4s .. 4s+3): one more LDS read at a computed address, three selects
+                const f32x4 wv = *(const f32x4*)(src + ((h * 32 + gi * 4) ^ x));
+                const int li = (wv.x == M) ? 0 : ((wv.y == M) ? 1 : ((wv.z == M) ? 2 : 3));
                 // a later tile only wins with a larger value (the tiles of a d1 panel come in ascending d2 order): ties keep the lower d2 group
                 const bool better = M > rkv;
-                rkg = better ? (unsigned)((col_base + wc * 128) >> 4) + (unsigned)gi : rkg;
+                rkg = better ? (unsigned)((col_base + wc * 128) >> 2) + (unsigned)(gi * 4 + li) : rkg;
                 rkv = better ? M : rkv;
             }
         }

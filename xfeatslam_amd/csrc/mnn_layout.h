@@ -33,7 +33,8 @@
 #define MNN_PANEL 256                 // rows per panel
 #define MNN_PANEL_FLOATS (MNN_PANEL * 64)
 #define MNN_RGROUP 16                 // d1 rows per column-candidate group  (bestC key)
-#define MNN_CGROUP 16                 // d2 rows per row-candidate group     (bestR key)
+#define MNN_CGROUP 4                  // d2 rows per row-candidate group     (bestR key): the 4 consecutive d2 rows one lane of the GEMM holds (round 5; 16 before:
+                                      // k_mnn_post fetched 16 candidate rows and 16 x 16 column keys per d1 row -- 6 KB per row, and at 8 pairs it ran at the cache's rate)
 
 __host__ __device__ inline int mnn_pos(int r256) {             // row inside the panel -> position
     return (r256 & 128) | ((r256 & 3) << 5) | ((r256 & 127) >> 2);

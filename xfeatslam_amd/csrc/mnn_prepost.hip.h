@@ -34,15 +34,17 @@ __device__ __forceinline__ const float* mnn_row(const float* img, int row, int& 
 // k_mnn_post: second level of the arg-max, the mutual check (ORBmatcher.cc:367-372), the min_cossim gate (:361)
 // and the ordered output (:371-403) in one launch.  Blocks 0 .. gridDim.x-2: sixteen lanes per d1 row, sixteen rows
 // per workgroup (= one d1 row group of the bestC keys).
-//   bestR[row] = max over the planes partR[.][row] = (M, gc): the row maximum M sits in d2 rows 16*gc .. 16*gc+15 -> lane c recomputes <row, 16*gc + c>;
-//   the first one equal to M is m12[row] (torch.max returns the first index of the maximum).
+//   bestR[row] = max over the planes partR[.][row] = (M, gc): the row maximum M sits in the MNN_CGROUP = 4 d2 rows 4*gc .. 4*gc+3 -> lanes 0 .. 3 of the
+//   row recompute <row, 4*gc + c>; the first one equal to M is m12[row] (torch.max returns the first index of the maximum).
 //   bestC[col] = max over the planes partC[.][col] = (Mc, gr): m21[col] is the first d1 row of 16*gr .. 16*gr+15 whose dot product equals Mc.  `row` is a
 //   mutual match iff Mc == M, row lies in that group and no earlier row of the group reaches Mc -- lane c recomputes
 //   <16*gr + c, col> for the rows before `row` only; those rows are the workgroup's own 16 rows.
-// The kernel is bound by dependent memory round trips and by the number of cache-line requests, so all global reads
-// are cooperative and coalesced (one 16-byte piece per lane; a 16-lane group fetches one 256-byte row per instruction)
-// and go through LDS, where lane c then reads "its" candidate row: the workgroup's own 16 d1 rows once (sA), and for
-// every row its 16 candidate d2 rows (sB).  Two dependent round trips remain: bestR -> candidates (+ their bestC keys).
+// All global reads are cooperative and coalesced (one 16-byte piece per lane; a 16-lane group fetches one 256-byte row per instruction)
+// and go through LDS: the workgroup's own 16 d1 rows once (sA), and for every row its 4 candidate d2 rows (sB); the column keys of the four
+// candidates are dealt out over the row's 16 lanes (4 planes each at 4096 rows).  Two dependent round trips remain: bestR -> candidates (+ their
+// bestC keys).  Round 5: candidate groups of 4 instead of 16 d2 rows (the GEMMs name the quarter of the winning group of 16: one LDS read and three
+// selects per row in their epilogues) -- a d1 row fetches 1.7 KB instead of 6.3 KB from L2 / Infinity Cache, which is what the kernel's time was
+// (k_mnn_post_batch: 25 us for 8 pairs = 8 TB/s), and the workgroup's LDS drops from 74 to 22 KB.
 // Each row publishes (column or -1, value) as one 8-byte agent-scope atomic store.  The last `ncoll` blocks are the
 // collectors (grid = nb + ncoll, nb = ceil(n1/16)): they poll the pairs (agent-scope atomic loads; MNN_PAIR_EMPTY = not
 // yet written; the data is its own flag, so no ticket and no fence) and write the matches in ascending idx1 with
@@ -52,7 +54,7 @@ __device__ __forceinline__ const float* mnn_row(const float* img, int row, int& 
 #define MNN_SPIN_LIMIT (1 << 22)
 __host__ __device__ inline int mnn_ncoll(int n1) { const int nq = (n1 + 255) >> 8; return nq < 16 ? (nq < 1 ? 1 : nq) : 16; }
 #define MNN_POST_LD 68                 // LDS row pitch in floats (272 B: per-lane rows are read conflict free)
-#define MNN_POST_LDS ((16 + 256) * MNN_POST_LD * 4)
+#define MNN_POST_LDS ((16 + 16 * MNN_CGROUP) * MNN_POST_LD * 4)
 // everything one match needs from k_mnn_post.  segG > 0: the key planes come from k_mnn_gemm_seg (mnn_gemm_seg.hip.h) -- the number of
 // row planes of a d1 panel follows from (segT, segG, tile0, P2) with the GEMM's own arithmetic and `npr` is ignored.
 struct MnnPostArgs {
@@ -80,7 +82,7 @@ __device__ __forceinline__ void mnn_post_body(const MnnPostArgs& a, const int bi
     MNN_STAMP(0);
     if (bid < nb) {
         float* sA = spost;                               // [16 rows][68]: row in natural piece order (piece p = 2g + half at 4p)
-        float* sB = spost + 16 * MNN_POST_LD;            // [16 row groups][16 candidates][68]
+        float* sB = spost + 16 * MNN_POST_LD;            // [16 rows][MNN_CGROUP candidates][68]
         const int c = t & 15, grp = t >> 4;
         const int row = bid * 16 + grp;                  // the image holds whole panels: rows up to the panel end are readable (zeros)
         // bestR[row] = maximum over the npr planes the GEMM blocks of this d1 panel wrote: lane c takes planes c, c+16, ...
@@ -96,53 +98,59 @@ __device__ __forceinline__ void mnn_post_body(const MnnPostArgs& a, const int bi
         }
         const float M = ord2f((unsigned)(kr >> 32));
         const int gc = (int)(0xFFFFFFFFu - (unsigned)(kr & 0xFFFFFFFFull));
-        const int col = gc * MNN_CGROUP + c;
+        // the row maximum sits in the MNN_CGROUP = 4 d2 rows 4*gc .. 4*gc+3 (a group never straddles a panel).  Lane c serves candidate cj = c & 3:
+        // bestC[its column] = maximum over the npc planes, the planes dealt out over the four lanes that share a candidate (c >> 2, + 4, ...)
+        const int cj = c & 3;
+        const int col = gc * MNN_CGROUP + cj;
         const bool have = kr != 0ull && col < n2;
-        u64 kcand = 0ull;                                // bestC[col] = maximum over the npc planes
+        u64 kcand = 0ull;
         if (have) {
-            int pl = 0;
-            for (; pl + 8 <= npc; pl += 8) {              // eight independent loads in flight
-                u64 v[8];
+            int pl = c >> 2;
+            for (; pl + 12 < npc; pl += 16) {             // four independent loads in flight
+                u64 v[4];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = partC[(size_t)(pl + u) * ldc + col];
+                for (int u = 0; u < 4; ++u) v[u] = partC[(size_t)(pl + 4 * u) * ldc + col];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) kcand = mnn_umax64(kcand, v[u]);
+                for (int u = 0; u < 4; ++u) kcand = mnn_umax64(kcand, v[u]);
             }
-            for (; pl < npc; ++pl) kcand = mnn_umax64(kcand, partC[(size_t)pl * ldc + col]);
+            for (; pl < npc; pl += 4) kcand = mnn_umax64(kcand, partC[(size_t)pl * ldc + col]);
         }
-        if (kr != 0ull) {                                // candidate rows 16*gc .. 16*gc+15 (inside the panel image: readable)
-            f32x4 pv[16];
+        kcand = mnn_umax64(kcand, __shfl_xor(kcand, 4)); kcand = mnn_umax64(kcand, __shfl_xor(kcand, 8));      // every lane: bestC of candidate c & 3
+        if (kr != 0ull) {                                // the four candidate rows (inside the panel image: readable), one 256-byte row per instruction and 16 lanes
+            f32x4 pv[MNN_CGROUP];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
+            for (int j = 0; j < MNN_CGROUP; ++j) {
                 int sb;
                 const float* rb = mnn_row(img2, gc * MNN_CGROUP + j, sb);
                 pv[j] = *(const f32x4*)(rb + (c >> 2) * 4096 + (((c & 3) ^ sb) << 2));
             }
 #pragma unroll
-            for (int j = 0; j < 16; ++j) *(f32x4*)(sB + (grp * 16 + j) * MNN_POST_LD + c * 4) = pv[j];
+            for (int j = 0; j < MNN_CGROUP; ++j) *(f32x4*)(sB + (grp * MNN_CGROUP + j) * MNN_POST_LD + c * 4) = pv[j];
         }
         MNN_STAMP(1);
         __syncthreads();
-        // <row, col>: one fp32 fma chain in k order -- the arithmetic of the MFMA loop (k = 2j of lane-half 0, then 2j+1)
+        // <row, candidate>: one fp32 fma chain in k order -- the arithmetic of the MFMA loop (k = 2j of lane-half 0, then 2j+1); lanes 0 .. 3 of the row
         const float* pa = sA + grp * MNN_POST_LD;
-        const float* pb = sB + (grp * 16 + c) * MNN_POST_LD;
+        const float* pb = sB + (grp * MNN_CGROUP + cj) * MNN_POST_LD;
         float dv = 0.f;
+        if (c < MNN_CGROUP) {
 #pragma unroll
-        for (int g = 0; g < 8; ++g) {
-            const f32x4 a0 = *(const f32x4*)(pa + g * 8), a1 = *(const f32x4*)(pa + g * 8 + 4);
-            const f32x4 b0 = *(const f32x4*)(pb + g * 8), b1 = *(const f32x4*)(pb + g * 8 + 4);
+            for (int g = 0; g < 8; ++g) {
+                const f32x4 a0 = *(const f32x4*)(pa + g * 8), a1 = *(const f32x4*)(pa + g * 8 + 4);
+                const f32x4 b0 = *(const f32x4*)(pb + g * 8), b1 = *(const f32x4*)(pb + g * 8 + 4);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { dv = fmaf(a0[j], b0[j], dv); dv = fmaf(a1[j], b1[j], dv); }
+                for (int j = 0; j < 4; ++j) { dv = fmaf(a0[j], b0[j], dv); dv = fmaf(a1[j], b1[j], dv); }
+            }
         }
         MNN_STAMP(2);
-        unsigned eq = (have && dv == M) ? (1u << c) : 0u;
+        unsigned eq = (c < MNN_CGROUP && have && dv == M) ? (1u << c) : 0u;
         eq |= __shfl_xor(eq, 1); eq |= __shfl_xor(eq, 2); eq |= __shfl_xor(eq, 4); eq |= __shfl_xor(eq, 8);
         int cs;
         if (eq) cs = __builtin_ctz(eq);
         else {      // cannot happen while the recomputation is bit-identical (NaN rows aside); stay deterministic anyway
-            u64 k = have ? mnn_pack_key(dv, (unsigned)c) : 0ull;
+            u64 k = (c < MNN_CGROUP && have) ? mnn_pack_key(dv, (unsigned)c) : 0ull;
             k = mnn_umax64(k, __shfl_xor(k, 1)); k = mnn_umax64(k, __shfl_xor(k, 2)); k = mnn_umax64(k, __shfl_xor(k, 4)); k = mnn_umax64(k, __shfl_xor(k, 8));
-            cs = (int)(0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull)) & 15;
+            cs = (int)(0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull)) & (MNN_CGROUP - 1);
         }
         const int cstar = gc * MNN_CGROUP + cs;
         const u64 kc = __shfl(kcand, (t & 48) | cs);                       // the lane of this wave that holds column cstar
@@ -151,7 +159,7 @@ __device__ __forceinline__ void mnn_post_body(const MnnPostArgs& a, const int bi
         bool mutual = false;
         if (kr != 0ull && cstar < n2 && kc != 0ull && Mc == M && (row >> 4) == gr) {      // uniform over the 16 lanes of a row
             const float* pg = sA + c * MNN_POST_LD;                        // d1 row 16*gr + c is row c of this workgroup
-            const float* ps = sB + (grp * 16 + cs) * MNN_POST_LD;
+            const float* ps = sB + (grp * MNN_CGROUP + cs) * MNN_POST_LD;
             float d2v = 0.f;
 #pragma unroll
             for (int g = 0; g < 8; ++g) {
