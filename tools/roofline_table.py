@@ -85,9 +85,9 @@ for n, d in agg.items():
         flops, bytes_, bound = 2.0 * 4096 * 4096 * 64, 4096.0 * 4096 * 4 + 2 * 4096 * 256.0, "mfma"
     elif "k_mnn_post" in n:
         # bytes a pair's rows fetch from L2 / Infinity Cache (nothing of it is compulsory HBM traffic): per d1 row its row-key planes (16 x 8 B; 4 x 8 B behind
-        # k_mnn_gemm_seg, which merges a panel's planes), 16 candidate d2 rows of 256 B, the column keys of the 16 candidates over 16 planes (16 x 16 x 8 B)
+        # k_mnn_gemm_seg, which merges a panel's planes), its own row (256 B), MNN_CGROUP = 4 candidate d2 rows of 256 B, the column keys of the 4 candidates over 16 planes
         npairs = MATCH_PAIRS if "batch" in n else 1
-        bytes_, bound = npairs * 4096.0 * ((32 if "batch" in n else 128) + 16 * 256 + 16 * 16 * 8), "cache"
+        bytes_, bound = npairs * 4096.0 * ((32 if "batch" in n else 128) + 256 + 4 * 256 + 4 * 16 * 8), "cache"
     elif "k_best2_csr" in n: bytes_, bound = 4096.0 * 64 * (256 + 4) + 4096 * 256, "hbm"      # 64 gathered 256-byte rows per query (L2 resident table)
     elif "k_distinctive_csr" in n: bytes_, bound = 4096.0 * 16 * (256 + 4), "hbm"
     elif "k_block1_stats" in n: bytes_, bound, flops = 4.0 * B * H * W, "valu", 2.0 * H * W * 4 * 9 * B
