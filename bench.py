@@ -217,7 +217,6 @@ def main():
 
     def step(form=None):
         form = form or args.gather
-        step.count = step_no[0] + 1
         # S sub-batches of B frames, each on its own ctx / stream; the exchange of generation g runs on the ctx's
         # communication stream while the next step extracts into the other generation
         g = step_no[0] & 1 if use_comm else 0
@@ -296,7 +295,7 @@ def main():
 
     multi = None
     if use_comm and not args.no_legs:
-        multi = multi_rank_legs(args, lib, capi, synth, Context, xd, comm, ctx, blob, rank, N, dev, nf, rec_bytes, step, timed, gather, gather_target, B * S)
+        multi = multi_rank_legs(args, lib, capi, synth, Context, xd, comm, ctx, blob, rank, N, dev, nf, rec_bytes, step, timed, gather, gather_target, B * S, step_no)
 
     if rank != 0:
         sync()                                             # rank 0 runs its extra legs, then everybody leaves together
@@ -441,11 +440,7 @@ PCIE_GBPS = 63.0      # PCIe 5.0 x16, one direction, after 128b/130b (tools/pcie
 C3_H, C3_W = 720, 1280
 
 
-def step_no_of(step):
-    return getattr(step, "count", 0)
-
-
-def multi_rank_legs(args, lib, capi, synth, Context, xd, comm, ctx, blob, rank, N, dev, nf, rec_bytes, step, timed, gather, gather_target, frames_per_rank):
+def multi_rank_legs(args, lib, capi, synth, Context, xd, comm, ctx, blob, rank, N, dev, nf, rec_bytes, step, timed, gather, gather_target, frames_per_rank, step_no):
     """collective legs, run by EVERY rank after the timed region: the headline workload under the other two gather forms, and
     BASELINE.json configs[3] itself -- one 1280x720 frame per rank per step (frame i of the batch of N -> rank i), extracted on the
     rank's GPU and gathered to rank 0, all three gather forms; reference consumer: the sequential loop of src/System.cc:197-233"""
@@ -475,7 +470,7 @@ def multi_rank_legs(args, lib, capi, synth, Context, xd, comm, ctx, blob, rank, 
     timed(lambda: step("allgather"), 1, warm=0)             # one step between two barriers, every ctx and the communicator idle afterwards
     if rank == 0:
         nchk = min(2, frames_per_rank)
-        tgt = gather_target("allgather", frames_per_rank)[(step_no_of(step) - 1) & 1]
+        tgt = gather_target("allgather", frames_per_rank)[(step_no[0] - 1) & 1]       # the generation the last step gathered into
         equal, checked = True, 0
         for r in range(N):
             fr = synth.frames(nchk, args.height, args.width, seed=42 + 1000 * r)

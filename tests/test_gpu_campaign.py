@@ -93,3 +93,40 @@ def test_campaign_gpu_vs_oracle(gpu_lib, oracle_mod, family, size):
                 assert np.array_equal(x, y), f"equal frames {j} and {i} of one batch gave different records"
     ctx.close()
     assert not problems, problems
+
+
+@pytest.mark.parametrize("family", WT.FAMILIES)
+def test_campaign_match_on_extracted_descriptors(gpu_lib, oracle_mod, family):
+    """ORBmatcher::match on what the extraction produces for the campaign's frames -- not on Gaussian rows: 4096-row records whose padding rows are zero rows
+    (from a few dozen to all 4096 of them: `heat_off` and the period-8 checkerboard give records with nothing but padding, where every similarity is an exact
+    tie at 0 and torch.max's first-index rule decides), real descriptors of structured scenes, one frame against itself.  Every image family against the next
+    one and the 8x8 checkerboard against itself, through the raw-rows call and through the prepared-images batch call; pair lists and distances equal to the
+    oracle's bit for bit (the audit prints valid rows and duplicate d2 rows per pair)."""
+    from xfeatslam_amd.extractor import Context
+    O = oracle_mod
+    H, W, nf = 480, 640, 4096
+    fams = synth.IMAGE_FAMILIES
+    blob = WT.pack_blob(WT.make_family(family, seed=5))
+    fr = np.stack([synth.image_family(f, H, W, seed=100) for f in fams])
+    ctx = Context(nfeatures=nf, max_height=H, max_width=W, max_batch=len(fams))
+    ctx.load_weights(blob)
+    recs = ctx.extract_batch(fr, (0, W // 3))
+    descs = [r[1] for r in recs]
+    pairs = [(k, (k + 1) % len(fams)) for k in range(len(fams))] + [(fams.index("checker8"), fams.index("checker8"))]
+    prepared = [ctx.match_prepare(d) for d in descs]
+    batch = ctx.match_mnn_prepared_batch([(prepared[a], prepared[b]) for a, b in pairs])
+    problems = []
+    for (a, b), got_b in zip(pairs, batch):
+        want = O.match_mnn(descs[a], descs[b])
+        got = ctx.match_mnn(descs[a], descs[b])
+        dup = nf - len(np.unique(descs[b].view(np.uint8).reshape(nf, -1), axis=0))
+        ok = all(np.array_equal(x, y) for x, y in zip(got[:2], want[:2])) and np.array_equal(got[2], want[2], equal_nan=True)
+        okb = all(np.array_equal(x, y) for x, y in zip(got_b[:2], want[:2])) and np.array_equal(got_b[2], want[2], equal_nan=True)
+        print(f"  {family:13s} {fams[a]:11s} x {fams[b]:11s} valid rows {recs[a][2]:4d} x {recs[b][2]:4d}, duplicate d2 rows {dup:4d}: {len(want[0]):4d} matches "
+              f"{'OK' if ok and okb else 'DIFFER'}", flush=True)
+        if not (ok and okb):
+            problems.append((fams[a], fams[b], "raw" if not ok else "batch"))
+    for p in prepared:
+        p[0].free()
+    ctx.close()
+    assert not problems, problems

@@ -28,9 +28,9 @@ int main(int argc, char** argv) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const int nt = dist_tiles_per_block(n, n, 256);
     const dim3 g((n + nt * DTC - 1) / (nt * DTC), (n + DT - 1) / DT);
-    const char* names[] = {"product", "no fix-up", "no fix-up, no bulk epilogue", "staging + MFMA without the norm shuffles", "staging only (no MFMA, no epilogue)", "no MFMA (staging + epilogue + fix-up)", "no stores in the bulk pass (timing)", "no stores, no fix-up"};
+    const char* names[] = {"product", "no fix-up", "no fix-up, no bulk epilogue", "staging + MFMA without the norm shuffles", "staging only (no MFMA, no epilogue)", "no MFMA (staging + epilogue + fix-up)", "no stores in the bulk pass (timing)", "no stores, no fix-up", "second half of the grid starts 3.4 us late", "odd blockIdx.x starts 3.4 us late"};
     for (int rep = 0; rep < 2; ++rep)
-        for (int v = 0; v < 8; ++v) {
+        for (int v = 0; v < 10; ++v) {
             auto launch = [&]() {
                 switch (v) {
                     case 0: go<0>(g, s, a, n, b, n, o); break;
@@ -41,6 +41,8 @@ int main(int argc, char** argv) {
                     case 5: go<4>(g, s, a, n, b, n, o); break;
                     case 6: go<32>(g, s, a, n, b, n, o); break;
                     case 7: go<33>(g, s, a, n, b, n, o); break;
+                    case 8: go<64>(g, s, a, n, b, n, o); break;
+                    case 9: go<128>(g, s, a, n, b, n, o); break;
                 }
             };
             for (int i = 0; i < 300; ++i) launch();

@@ -48,17 +48,16 @@ extern "C" {
 // driver <hipDriverGetVersion>": the library carries hand-counted MFMA hazard padding (common.h: XFH_MFMA_SETTLE), so the compiler it was built with and
 // the runtime it meets are part of its identity (bench.py prints the string, tests/test_gpu_hazard.py checks the padding with the box's own compiler)
 const char* xfh_version(void) {
-    static char buf[320];
-    static bool done = false;
-    if (!done) {
+    static const std::string v = [] {                // (a function-local static: initialised once, also under concurrent first calls)
         int rt = 0, drv = 0;
         if (hipRuntimeGetVersion(&rt) != hipSuccess) rt = 0;
         if (hipDriverGetVersion(&drv) != hipSuccess) drv = 0;
+        char buf[320];
         snprintf(buf, sizeof buf, "xfeat_hip 0.1 (gfx950); built with clang %d.%d.%d, HIP %d.%d.%d; runtime HIP %d, driver %d",
                  __clang_major__, __clang_minor__, __clang_patchlevel__, HIP_VERSION_MAJOR, HIP_VERSION_MINOR, HIP_VERSION_PATCH, rt, drv);
-        done = true;
-    }
-    return buf;
+        return std::string(buf);
+    }();
+    return v.c_str();
 }
 
 const char* xfh_strerror(int s) {

@@ -123,6 +123,8 @@ void k_dist_mfma(const float* __restrict__ d1, int n1, const float* __restrict__
     const int col0 = blockIdx.x * (nt * DTC);
     const int ntile = (n2 - col0 + DTC - 1) / DTC < nt ? (n2 - col0 + DTC - 1) / DTC : nt;        // >= 1 by the grid
     if (t < 2) sCnt[t] = 0;
+    if ((DBG & 64) && (blockIdx.y * gridDim.x + blockIdx.x) * 2 >= gridDim.x * gridDim.y) __builtin_amdgcn_s_sleep(127);
+    if ((DBG & 128) && (blockIdx.x & 1)) __builtin_amdgcn_s_sleep(127);
     f32x4 vb[2];                                            // this thread's piece of the NEXT column tile: 8 lanes per row, row t >> 3
     auto load_b = [&](int kt) {
         const int row = col0 + kt * DTC + (t >> 3);
@@ -154,6 +156,27 @@ void k_dist_mfma(const float* __restrict__ d1, int n1, const float* __restrict__
         c4[q] = *(const f32x4*)(sCa + wr * 32 + 8 * q + 4 * h);
         u4[q] = 0.5f - *(const f32x4*)(sEa + wr * 32 + 8 * q + 4 * h);
     }
+    // List a wave's marked entries of column tile kt: the wave reserves a range of the workgroup's list (one LDS atomic), a lane's place is the exclusive
+    // prefix of the counts over the lanes; what does not fit stays in `mask` and raises the overflow flag.  About 90 of a tile's 8192 entries for unit descriptors.
+    auto list_marked = [&](unsigned& mask, int kt) {
+        if (!__ballot(mask != 0u)) return;
+        const int cnt = __popc(mask);
+        int pre = cnt;                                       // inclusive prefix over the lanes
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(pre, d); if (lane >= d) pre += o; }
+        const int wtotal = __shfl(pre, 63);
+        int base = 0;
+        if (lane == 63) base = atomicAdd(&sCnt[0], wtotal);
+        base = __shfl(base, 63);
+        pre += base - cnt;
+        while (mask && pre < DLIST) {
+            const int bit = 31 - __builtin_clz(mask); mask &= ~(1u << bit);
+            const int r = 15 - bit;                          // dist_bulk's bit order
+            const int rl = wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, cs = kt * DTC + wc * 32 + i;
+            sList[pre++] = ((unsigned)rl << 16) | (unsigned)cs;
+        }
+        if (__ballot(mask != 0u) && lane == 0) atomicOr(&sCnt[1], 1);           // the list is full: flush, then list the rest
+    };
     for (int kt = 0; kt < ntile; ++kt) {
         const int col_base = col0 + kt * DTC, b = kt & 1;
         if (kt + 1 < ntile) load_b(kt + 1);                // in flight through the MFMAs and the bulk pass of this tile
@@ -175,26 +198,8 @@ void k_dist_mfma(const float* __restrict__ d1, int n1, const float* __restrict__
         if (DBG & 2) { mask = 0u; if (acc[3] + acc[5] == 123.456f) out[t] = 1; }
         else if (row_base + DT <= n1 && col_base + DTC <= n2) mask = dist_bulk<true, (DBG & 32) != 0>(acc, c4, u4, cb, eb, wr, wc, i, h, row_base, col_base, n1, n2, out);
         else mask = dist_bulk<false>(acc, c4, u4, cb, eb, wr, wc, i, h, row_base, col_base, n1, n2, out);
-        // list the marked entries: a wave reserves a range of the workgroup's list (one LDS atomic), a lane's place is the exclusive prefix of the
-        // counts over the lanes.  About 90 of a tile's 8192 entries for unit descriptors; a full list is flushed by the fix-up below before the next tile
-        if (!(DBG & 1) && __ballot(mask != 0u)) {
-            const int cnt = __popc(mask);
-            int pre = cnt;                                   // inclusive prefix over the lanes
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(pre, d); if (lane >= d) pre += o; }
-            const int wtotal = __shfl(pre, 63);
-            int base = 0;
-            if (lane == 63) base = atomicAdd(&sCnt[0], wtotal);
-            base = __shfl(base, 63);
-            pre += base - cnt;
-            while (mask && pre < DLIST) {
-                const int bit = 31 - __builtin_clz(mask); mask &= ~(1u << bit);
-                const int r = 15 - bit;                      // dist_bulk's bit order
-                const int rl = wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, cs = kt * DTC + wc * 32 + i;
-                sList[pre++] = ((unsigned)rl << 16) | (unsigned)cs;
-            }
-            if (__ballot(mask != 0u) && lane == 0) atomicOr(&sCnt[1], 1);       // the list is full: flush, then list the rest
-        }
+        // list the marked entries (list_marked above); a full list is flushed by the fix-up below before the next tile
+        if (!(DBG & 1)) list_marked(mask, kt);
         // next tile -> the other half of sB (its last readers were the MFMAs of tile kt - 1: a barrier ago)
         if (kt + 1 < ntile) dist_stage_row<8, DBG>(vb, t >> 3, t & 7, sB[b ^ 1], sCb[b ^ 1], sEb[b ^ 1]);
         __syncthreads();
@@ -240,25 +245,7 @@ void k_dist_mfma(const float* __restrict__ d1, int n1, const float* __restrict__
             if (t < 2) sCnt[t] = 0;
             __syncthreads();
             if (!more) break;
-            // the lanes that kept entries list them now (the same code as above, mask by mask)
-            if (__ballot(mask != 0u)) {
-                const int cnt = __popc(mask);
-                int pre = cnt;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(pre, d); if (lane >= d) pre += o; }
-                const int wtotal = __shfl(pre, 63);
-                int base = 0;
-                if (lane == 63) base = atomicAdd(&sCnt[0], wtotal);
-                base = __shfl(base, 63);
-                pre += base - cnt;
-                while (mask && pre < DLIST) {
-                    const int bit = 31 - __builtin_clz(mask); mask &= ~(1u << bit);
-                    const int r = 15 - bit;
-                    const int rl = wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, cs = kt * DTC + wc * 32 + i;
-                    sList[pre++] = ((unsigned)rl << 16) | (unsigned)cs;
-                }
-                if (__ballot(mask != 0u) && lane == 0) atomicOr(&sCnt[1], 1);
-            }
+            list_marked(mask, kt);                          // the lanes that kept entries list them now
             __syncthreads();
         }
     }
