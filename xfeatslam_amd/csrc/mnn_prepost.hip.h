@@ -53,8 +53,14 @@ __device__ __forceinline__ const float* mnn_row(const float* img, int row, int& 
 #define MNN_PAIR_EMPTY 0xFFFFFFFE00000000ull
 #define MNN_SPIN_LIMIT (1 << 22)
 __host__ __device__ inline int mnn_ncoll(int n1) { const int nq = (n1 + 255) >> 8; return nq < 16 ? (nq < 1 ? 1 : nq) : 16; }
-#define MNN_POST_LD 68                 // LDS row pitch in floats (272 B: per-lane rows are read conflict free)
+// LDS rows of k_mnn_post: 64 floats, no padding; the 16-byte chunk q of row r sits at chunk q ^ (r & 15), so that the lanes of a wave that read chunk q of 16
+// DIFFERENT rows (the candidate dot products, the mutual check) hit 16 different chunk positions -- two lanes per bank pair instead of sixteen.  Without padding
+// a workgroup takes (16 + 64) x 256 B = exactly 20 KB: eight workgroups per CU (with the 56 registers the kernel needs: eight waves per SIMD), so the 2048
+// writer workgroups of an 8-pair call are resident in ONE round (the padded form, 21.25 KB, fitted seven: the last 256 workgroups paid a second full latency chain).
+#define MNN_POST_LD 64
 #define MNN_POST_LDS ((16 + 16 * MNN_CGROUP) * MNN_POST_LD * 4)
+__device__ __forceinline__ float* mnn_post_chunk(float* row_base, int row, int q) { return row_base + ((q ^ (row & 15)) << 2); }
+__device__ __forceinline__ const float* mnn_post_chunk(const float* row_base, int row, int q) { return row_base + ((q ^ (row & 15)) << 2); }
 // everything one match needs from k_mnn_post.  segG > 0: the key planes come from k_mnn_gemm_seg (mnn_gemm_seg.hip.h) -- the number of
 // row planes of a d1 panel follows from (segT, segG, tile0, P2) with the GEMM's own arithmetic and `npr` is ignored.
 struct MnnPostArgs {
@@ -81,8 +87,8 @@ __device__ __forceinline__ void mnn_post_body(const MnnPostArgs& a, const int bi
 #define MNN_STAMP(k) do { if (TS && t == 0 && (bid == 0 || bid + 1 == nblk)) stamps[(bid ? 16 : 0) + (k)] = wall_clock64(); } while (0)
     MNN_STAMP(0);
     if (bid < nb) {
-        float* sA = spost;                               // [16 rows][68]: row in natural piece order (piece p = 2g + half at 4p)
-        float* sB = spost + 16 * MNN_POST_LD;            // [16 rows][MNN_CGROUP candidates][68]
+        float* sA = spost;                               // [16 rows][64]: row in natural piece order (piece p = 2g + half is chunk p), chunks swizzled (mnn_post_chunk)
+        float* sB = spost + 16 * MNN_POST_LD;            // [16 rows][MNN_CGROUP candidates][64], chunks swizzled
         const int c = t & 15, grp = t >> 4;
         const int row = bid * 16 + grp;                  // the image holds whole panels: rows up to the panel end are readable (zeros)
         // bestR[row] = maximum over the npr planes the GEMM blocks of this d1 panel wrote: lane c takes planes c, c+16, ...
@@ -94,7 +100,7 @@ __device__ __forceinline__ void mnn_post_body(const MnnPostArgs& a, const int bi
         {
             int sa;
             const float* ra = mnn_row(img1, row, sa);
-            *(f32x4*)(sA + grp * MNN_POST_LD + c * 4) = *(const f32x4*)(ra + (c >> 2) * 4096 + (((c & 3) ^ sa) << 2));
+            *(f32x4*)mnn_post_chunk(sA + grp * MNN_POST_LD, grp, c) = *(const f32x4*)(ra + (c >> 2) * 4096 + (((c & 3) ^ sa) << 2));
         }
         const float M = ord2f((unsigned)(kr >> 32));
         const int gc = (int)(0xFFFFFFFFu - (unsigned)(kr & 0xFFFFFFFFull));
@@ -125,19 +131,20 @@ __device__ __forceinline__ void mnn_post_body(const MnnPostArgs& a, const int bi
                 pv[j] = *(const f32x4*)(rb + (c >> 2) * 4096 + (((c & 3) ^ sb) << 2));
             }
 #pragma unroll
-            for (int j = 0; j < MNN_CGROUP; ++j) *(f32x4*)(sB + (grp * MNN_CGROUP + j) * MNN_POST_LD + c * 4) = pv[j];
+            for (int j = 0; j < MNN_CGROUP; ++j) *(f32x4*)mnn_post_chunk(sB + (grp * MNN_CGROUP + j) * MNN_POST_LD, grp * MNN_CGROUP + j, c) = pv[j];
         }
         MNN_STAMP(1);
         __syncthreads();
         // <row, candidate>: one fp32 fma chain in k order -- the arithmetic of the MFMA loop (k = 2j of lane-half 0, then 2j+1); lanes 0 .. 3 of the row
         const float* pa = sA + grp * MNN_POST_LD;
-        const float* pb = sB + (grp * MNN_CGROUP + cj) * MNN_POST_LD;
+        const int rbi = grp * MNN_CGROUP + cj;
+        const float* pb = sB + rbi * MNN_POST_LD;
         float dv = 0.f;
         if (c < MNN_CGROUP) {
 #pragma unroll
             for (int g = 0; g < 8; ++g) {
-                const f32x4 a0 = *(const f32x4*)(pa + g * 8), a1 = *(const f32x4*)(pa + g * 8 + 4);
-                const f32x4 b0 = *(const f32x4*)(pb + g * 8), b1 = *(const f32x4*)(pb + g * 8 + 4);
+                const f32x4 a0 = *(const f32x4*)mnn_post_chunk(pa, grp, 2 * g), a1 = *(const f32x4*)mnn_post_chunk(pa, grp, 2 * g + 1);
+                const f32x4 b0 = *(const f32x4*)mnn_post_chunk(pb, rbi, 2 * g), b1 = *(const f32x4*)mnn_post_chunk(pb, rbi, 2 * g + 1);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { dv = fmaf(a0[j], b0[j], dv); dv = fmaf(a1[j], b1[j], dv); }
             }
@@ -159,12 +166,13 @@ __device__ __forceinline__ void mnn_post_body(const MnnPostArgs& a, const int bi
         bool mutual = false;
         if (kr != 0ull && cstar < n2 && kc != 0ull && Mc == M && (row >> 4) == gr) {      // uniform over the 16 lanes of a row
             const float* pg = sA + c * MNN_POST_LD;                        // d1 row 16*gr + c is row c of this workgroup
-            const float* ps = sB + (grp * MNN_CGROUP + cs) * MNN_POST_LD;
+            const int rsi = grp * MNN_CGROUP + cs;
+            const float* ps = sB + rsi * MNN_POST_LD;
             float d2v = 0.f;
 #pragma unroll
             for (int g = 0; g < 8; ++g) {
-                const f32x4 a0 = *(const f32x4*)(pg + g * 8), a1 = *(const f32x4*)(pg + g * 8 + 4);
-                const f32x4 b0 = *(const f32x4*)(ps + g * 8), b1 = *(const f32x4*)(ps + g * 8 + 4);
+                const f32x4 a0 = *(const f32x4*)mnn_post_chunk(pg, c, 2 * g), a1 = *(const f32x4*)mnn_post_chunk(pg, c, 2 * g + 1);
+                const f32x4 b0 = *(const f32x4*)mnn_post_chunk(ps, rsi, 2 * g), b1 = *(const f32x4*)mnn_post_chunk(ps, rsi, 2 * g + 1);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { d2v = fmaf(a0[j], b0[j], d2v); d2v = fmaf(a1[j], b1[j], d2v); }
             }
@@ -201,23 +209,23 @@ __device__ __forceinline__ void mnn_post_body(const MnnPostArgs& a, const int bi
     const u64 below = (1ull << lane) - 1ull;
     int before_w = 0;                                    // matches in rows < 256*q_lo seen by THIS wave (same in all its lanes)
     bool timeout = false;
-    for (int q0 = 0; q0 < q_lo; q0 += 16) {
-        u64 pr[16];
-        for (int spin = 0;; ++spin) {                   // 16 loads unconditionally: they are in flight together
+    for (int q0 = 0; q0 < q_lo; q0 += 8) {               // (8 blocks of 256 rows at a time: 16 cost the writers' path its eighth wave per SIMD in registers)
+        u64 pr[8];
+        for (int spin = 0;; ++spin) {                   // 8 loads unconditionally: they are in flight together
             bool pending = false;
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
+            for (int u = 0; u < 8; ++u) {
                 const int i = (q0 + u) * 256 + t;
                 pr[u] = (q0 + u < q_lo && i < n1) ? __hip_atomic_load(pairs + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0ull;
             }
 #pragma unroll
-            for (int u = 0; u < 16; ++u) pending = pending || pr[u] == MNN_PAIR_EMPTY;
+            for (int u = 0; u < 8; ++u) pending = pending || pr[u] == MNN_PAIR_EMPTY;
             if (!pending) break;
             if (spin > MNN_SPIN_LIMIT) { timeout = true; break; }
             __builtin_amdgcn_s_sleep(1);
         }
 #pragma unroll
-        for (int u = 0; u < 16; ++u) before_w += __popcll(__ballot((int)(unsigned)(pr[u] >> 32) >= 0 && pr[u] != MNN_PAIR_EMPTY));
+        for (int u = 0; u < 8; ++u) before_w += __popcll(__ballot((int)(unsigned)(pr[u] >> 32) >= 0 && pr[u] != MNN_PAIR_EMPTY));
     }
     if (TS) MNN_STAMP(1);
     int run = 0;
@@ -277,7 +285,7 @@ __device__ __forceinline__ void mnn_post_body(const MnnPostArgs& a, const int bi
 }
 
 template <int TS>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(256, 8)
 void k_mnn_post(const float* __restrict__ img1, int n1, const float* __restrict__ img2, int n2,
                 const u64* __restrict__ partR, size_t ldr, int npr, const u64* __restrict__ partC, size_t ldc, int npc, float min_cossim,
                 u64* __restrict__ pairs, int nb, int ncoll, int* __restrict__ idx1, int* __restrict__ idx2, float* __restrict__ dist, int* __restrict__ n_matches,
@@ -298,7 +306,7 @@ void k_mnn_post(const float* __restrict__ img1, int n1, const float* __restrict_
 // find room.  Should a writer still never show up, the collectors' spin is bounded (MNN_SPIN_LIMIT) and the pair reports n_matches = -1, which the host
 // API turns into an error instead of a hang.
 struct MnnPostBatch { MnnPostArgs job[MNN_MAX_JOBS]; };
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(256, 8)
 void k_mnn_post_batch(const MnnPostBatch pb) {
     const MnnPostArgs& a = pb.job[blockIdx.y];
     const int nblk = a.nb + a.ncoll;
