@@ -305,6 +305,8 @@ int xfh_synchronize(xfh_ctx* ctx);
 int xfh_set_stream(xfh_ctx* ctx, void* hip_stream);
 const char* xfh_strerror(int status);
 const char* xfh_last_hip_error(xfh_ctx* ctx);
+/* "xfeat_hip 0.1 (gfx950); built with clang <x.y.z>, HIP <x.y.z>; runtime HIP <n>, driver <n>": the compiler the library was built with and the HIP runtime it
+ * met in this process (the library carries hand-counted MFMA hazard padding; tests/test_gpu_hazard.py re-checks it with the GPU box's own compiler) */
 const char* xfh_version(void);
 int xfh_device_count(void);
 
