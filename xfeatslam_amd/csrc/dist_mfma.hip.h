@@ -106,8 +106,8 @@ __device__ __forceinline__ void dist_stage_row(const f32x4 (&v)[16 / LANES], int
 // Workgroup = one d1 panel of 128 rows (staged once) x up to DNT column tiles of 64 d2 rows, walked one after the other.  The global loads of tile
 // k + 1 are issued before the MFMAs of tile k and go to the OTHER half of a double-buffered sB after its bulk pass: one barrier per tile, no memory
 // latency exposed from the second tile on, and the stores of tile k drain under the arithmetic of tile k + 1.  The entries that need the exact
-// expression are only LISTED while the tiles go by (per workgroup, LDS) and recomputed once, after the last tile, with the d2 rows read back from
-// global memory (L2): one 64-term fp64 chain per thread, one latency-bound phase per workgroup instead of one per tile.  (Rounds 2-4 and the first
+// expression are only LISTED while the tiles go by (per workgroup, LDS) and recomputed after every second tile, while both halves of sB still hold
+// their d2 rows: one 64-term fp64 chain per thread on dense lanes, everything read from LDS, one latency-bound phase per two tiles.  (Rounds 2-4 and the first
 // form of round 5: one 128 x 128 tile per workgroup, two workgroups per CU in lock step -- staging, MFMAs, stores and fix-up followed each other
 // with nothing to overlap them: 12 + 14 + 8 + 4 us.)  512 threads = 8 waves as 4 (rows) x 2 (columns), a wave owns 32 x 32 outputs of a tile.
 template <int DBG>          // probes only: 1 = no exact fix-up, 2 = no bulk epilogue either, 4 = no MFMAs, 8 = no norm shuffles (bits combine)
@@ -198,47 +198,43 @@ void k_dist_mfma(const float* __restrict__ d1, int n1, const float* __restrict__
         if (DBG & 2) { mask = 0u; if (acc[3] + acc[5] == 123.456f) out[t] = 1; }
         else if (row_base + DT <= n1 && col_base + DTC <= n2) mask = dist_bulk<true, (DBG & 32) != 0>(acc, c4, u4, cb, eb, wr, wc, i, h, row_base, col_base, n1, n2, out);
         else mask = dist_bulk<false>(acc, c4, u4, cb, eb, wr, wc, i, h, row_base, col_base, n1, n2, out);
-        // list the marked entries (list_marked above); a full list is flushed by the fix-up below before the next tile
+        // list the marked entries (list_marked above)
         if (!(DBG & 1)) list_marked(mask, kt);
-        // next tile -> the other half of sB (its last readers were the MFMAs of tile kt - 1: a barrier ago)
-        if (kt + 1 < ntile) dist_stage_row<8, DBG>(vb, t >> 3, t & 7, sB[b ^ 1], sCb[b ^ 1], sEb[b ^ 1]);
+        // The exact fix-up runs after every SECOND tile (and after the last one): then both halves of sB still hold the d2 rows its entries name (tile kt in
+        // sB[b], tile kt - 1 in the other half), so the chains read everything from LDS.  On those tiles the next column tile is staged AFTER the fix-up; on
+        // the others right here (its half's last readers were the MFMAs of tile kt - 1: a barrier ago).
+        const bool flush_tile = (kt & 1) || kt + 1 == ntile;               // block-uniform
+        if (!flush_tile) dist_stage_row<8, DBG>(vb, t >> 3, t & 7, sB[b ^ 1], sCb[b ^ 1], sEb[b ^ 1]);        // (an even tile that is not the last one has a successor)
         __syncthreads();
-        // ---- exact expression for the listed entries: after the last tile, or as soon as the list has overflowed (block-uniform).  One entry per
-        // thread: the d1 row from sA (element k = 8g + 2j + hh of a row sits at 8g + 4hh + j), the d2 row from global memory (natural order), one
-        // fp64 fma chain in k order = the oracle's.
-        while (!(DBG & 1) && (kt + 1 == ntile || sCnt[1]) && sCnt[0] > 0) {
+        // ---- exact expression for the listed entries (block-uniform: a flush tile, or the list has overflowed -- then it holds entries of this tile only, the
+        // previous flush having emptied it).  One entry per thread: both rows from LDS (element k = 8g + 2j + hh of a row sits at 8g + 4hh + j), one fp64 fma
+        // chain in k order = the oracle's.
+        while (!(DBG & 1) && (flush_tile || sCnt[1]) && sCnt[0] > 0) {
             const int total = sCnt[0], more = sCnt[1];
             const int n = total < DLIST ? total : DLIST;
             int fix_val = 0; size_t fix_at = 0;
             if (t < n) {
                 const unsigned code = sList[t];
-                const int rl = (int)(code >> 16), col = col0 + (int)(code & 0xFFFFu);
+                const int rl = (int)(code >> 16), cs = (int)(code & 0xFFFFu);          // cs = column inside the workgroup's strip = tile * 64 + column of the tile
                 const float* ra = sA + rl * DLDK;
-                const f32x4* rbp = (const f32x4*)(d2 + (size_t)col * 64);
+                const float* rb = sB[(cs >> 6) & 1] + (cs & 63) * DLDK;
                 double s = 0.0;
+#pragma unroll 2
+                for (int g = 0; g < 8; ++g) {
+                    const f32x4 a0 = *(const f32x4*)(ra + g * 8), a1 = *(const f32x4*)(ra + g * 8 + 4);
+                    const f32x4 b0 = *(const f32x4*)(rb + g * 8), b1 = *(const f32x4*)(rb + g * 8 + 4);
 #pragma unroll
-                for (int hf = 0; hf < 2; ++hf) {               // half a d2 row at a time: eight loads in flight (sixteen would cost the second workgroup per CU its registers)
-                    f32x4 rb[8];
-#pragma unroll
-                    for (int g = 0; g < 8; ++g) rb[g] = rbp[hf * 8 + g];
-#pragma unroll
-                    for (int g2 = 0; g2 < 4; ++g2) {
-                        const int g = hf * 4 + g2;
-                        const f32x4 a0 = *(const f32x4*)(ra + g * 8), a1 = *(const f32x4*)(ra + g * 8 + 4);
-                        const f32x4 b0 = rb[2 * g2], b1 = rb[2 * g2 + 1];        // elements 8g .. 8g+3, 8g+4 .. 8g+7
-                        const float bn[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const double df0 = (double)(a0[j] - bn[2 * j]); s = fma(df0, df0, s);
-                            const double df1 = (double)(a1[j] - bn[2 * j + 1]); s = fma(df1, df1, s);
-                        }
+                    for (int j = 0; j < 4; ++j) {
+                        const double df0 = (double)(a0[j] - b0[j]); s = fma(df0, df0, s);
+                        const double df1 = (double)(a1[j] - b1[j]); s = fma(df1, df1, s);
                     }
                 }
                 const float nd = (float)s;
-                fix_val = (int)(nd * 512.0f); fix_at = (size_t)(row_base + rl) * n2 + col;
+                fix_val = (int)(nd * 512.0f); fix_at = (size_t)(row_base + rl) * n2 + col0 + cs;
             }
             // An entry is overwritten by whichever thread got it from the list, i.e. by another wave than the one whose bulk pass stored there first:
-            // every wave waits until its bulk stores have reached L2 (vmcnt(0) -- by now they have), then the barrier, then the exact values go out.
+            // every wave waits until its bulk stores have reached L2 (vmcnt(0) -- by now they have; the prefetched loads of the next tile are older), then
+            // the barrier, then the exact values go out.
             __builtin_amdgcn_s_waitcnt(0x0f70);
             __syncthreads();                                 // also: everybody has read the counters and the list
             if (t < n) out[fix_at] = fix_val;
@@ -246,6 +242,10 @@ void k_dist_mfma(const float* __restrict__ d1, int n1, const float* __restrict__
             __syncthreads();
             if (!more) break;
             list_marked(mask, kt);                          // the lanes that kept entries list them now
+            __syncthreads();
+        }
+        if (flush_tile && kt + 1 < ntile) {                 // every thread is done with both halves of sB
+            dist_stage_row<8, DBG>(vb, t >> 3, t & 7, sB[b ^ 1], sCb[b ^ 1], sEb[b ^ 1]);
             __syncthreads();
         }
     }
