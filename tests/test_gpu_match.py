@@ -23,7 +23,8 @@ def mctx(gpu_lib):
 
 @pytest.mark.parametrize("n1,n2,zero,noise", [(256, 256, 0, 0.3), (300, 200, 7, 0.3), (1, 5, 0, 0.3), (5, 1, 0, 0.3),
                                                (129, 127, 0, 0.5), (128, 128, 0, 0.3), (1000, 4096, 0, 0.4),
-                                               (4096, 4096, 0, 0.3), (4096, 4096, 100, 0.3)])
+                                               (4096, 4096, 0, 0.3), (4096, 4096, 100, 0.3),
+                                               (4097, 300, 0, 0.3), (5000, 4500, 9, 0.3)])          # 17 / 20 d1 panels: the column-key planes no longer divide by the four lanes of a candidate
 def test_mnn_matches_oracle(mctx, oracle_mod, n1, n2, zero, noise):
     d1, d2 = synth.descriptor_sets(n1, n2, zero_rows=zero, noise=noise)
     a = oracle_mod.match_mnn(d1, d2)
