@@ -13,8 +13,12 @@
  *   (1) oracle/torch_restatement.py calls, line by line, the same libtorch/ATen CPU
  *       operators the reference calls (conv2d, batch_norm(training), instance_norm,
  *       avg_pool2d, interpolate, softmax, max_pool2d, nonzero, grid_sample, argsort,
- *       normalize) and tests/test_oracle_vs_torch.py checks this C code against it;
- *   (2) golden vectors produced by (1) are committed under tests/golden/.
+ *       normalize) and tests/test_oracle.py checks this C code against it, live, stage by stage -- since
+ *       round 5 over eleven weight families x eight image families (test_campaign_oracle_vs_aten);
+ *   (2) golden vectors produced by (1) are committed under tests/golden/ (nine extraction cases, four matches);
+ *   (3) exp() of the softmax and the sigmoid is libtorch's own vector kernel (Sleef expf_u10, FMA form), restated
+ *       as xfo_expf and checked bit for bit against torch.sigmoid / F.softmax (test_exp_is_atens_vector_exp).
+ * None of this is an execution of the reference: parity stays "partial".
  * ORBmatcher::match has no compiled definition in the reference at all (dead code,
  * src/ORBmatcher.cc:340-405); DescriptorDistance calls cv::norm from OpenCV 4.5.4
  * (un-vendored).  Both are restated from the call sites.
