@@ -412,6 +412,8 @@ def flat_scalars(out, N):
     for k, v in ak.items():
         if k.startswith("k_dist_i32"):
             c["dist_i32_kernel_us"] = v["kernel_us"]
+            if "frac_of_f32_mfma_peak" in v:
+                c["dist_i32_mfma_frac"] = v["frac_of_f32_mfma_peak"]
     par = out.get("parity")
     if par:
         c["parity_keypoint_sets_equal"] = bool(par["keypoint_sets_equal"])
@@ -975,7 +977,25 @@ def legs(out, args, lib, capi, synth, Context, ctx, blob, frames, d_in, d_recb, 
         nl, ms = ctx.timing_read()
         ctx.timing_enable(0)
         aux[name] = {"kernel_us": ms / max(nl, 1) * 1e3, "launches": nl}
-    aux["k_dist_i32 4096x4096 (64 MB table)"]["hbm_write_GBps"] = nf * nf * 4 / (aux["k_dist_i32 4096x4096 (64 MB table)"]["kernel_us"] * 1e-6) / 1e9
+    # the dense table once more on device-resident rows, back to back (the five host-API calls above each start from an idle GPU, inside the clock ramp)
+    dk = "k_dist_i32 4096x4096 (64 MB table)"
+    aux[dk]["from_idle_kernel_us"] = aux[dk]["kernel_us"]
+    b1 = capi.DeviceBuffer(d1h.nbytes).upload(d1h); b2 = capi.DeviceBuffer(d2h.nbytes).upload(d2h); tbl = capi.DeviceBuffer(4 * nf * nf)
+    for _ in range(60):
+        capi.check(lib.xfh_distance_i32_device(ctx.h, b1.ptr, nf, b2.ptr, nf, tbl.ptr), ctx.h)
+    ctx.synchronize()
+    ctx.timing_enable(capi.K["DIST_I32"])
+    for _ in range(100):
+        capi.check(lib.xfh_distance_i32_device(ctx.h, b1.ptr, nf, b2.ptr, nf, tbl.ptr), ctx.h)
+    ctx.synchronize()
+    nl, ms = ctx.timing_read(); ctx.timing_enable(0)
+    aux[dk].update({"kernel_us": ms / max(nl, 1) * 1e3, "launches": nl,
+                    "measured": "dispatch events over 100 back-to-back launches on device-resident rows after 60 of the same (settled clock); from_idle_kernel_us = the same kernel inside five host-API calls"})
+    for b_ in (b1, b2, tbl):
+        b_.free()
+    aux[dk]["hbm_write_GBps"] = nf * nf * 4 / (aux[dk]["kernel_us"] * 1e-6) / 1e9
+    aux[dk]["mfma_TFLOPs"] = 2.0 * nf * nf * 64 / (aux[dk]["kernel_us"] * 1e-6) / 1e12
+    aux[dk]["frac_of_f32_mfma_peak"] = aux[dk]["mfma_TFLOPs"] / PEAK_F32_MFMA_TFLOPS
     out["aux_kernels"] = aux
 
     # ---- CPU baseline + parity verdict (N == 1 only) ------------------------------------------------------------------
