@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import EXTRACT_GOLDENS, GOLDEN, golden_inputs, joined_desc_diff, kp_set, records_equal
+from conftest import EXTRACT_GOLDENS, GOLDEN, check_extract_golden, golden_inputs, joined_desc_diff, kp_set, records_equal
 from xfeatslam_amd import capi, synth, weights as WT
 
 pytestmark = pytest.mark.gpu
@@ -53,13 +53,9 @@ def test_extract_matches_golden(gpu_lib, name):
     ctx.load_weights(WT.pack_blob(w))
     (kps, desc, nv, mono, nc), = ctx.extract_batch(img[None], tuple(int(v) for v in g["lap"]))
     ctx.close()
-    assert (nv, mono, nc) == (int(g["n_valid"]), int(g["mono_index"]), int(g["n_candidates"]))
-    assert kp_set(kps) == set(map(tuple, g["xy"].tolist()))
-    pos = {(int(k["x"]), int(k["y"])): i for i, k in enumerate(kps) if k["size"] > 0}
-    idx = np.array([pos[tuple(p)] for p in g["xy"].tolist()])
-    assert np.abs(kps["response"][idx] - g["score"]).max() < 1e-5
-    ridx = np.array([pos[tuple(p)] for p in g["desc_rows_xy"].tolist()])
-    assert np.abs(desc[ridx] - g["desc_rows"]).max() < DESC_TOL
+    # candidate / valid counts, identical keypoint set, scores and sampled descriptors joined by position; differences only inside a
+    # near-tie at the top-k cut (conftest.check_extract_golden prints how many)
+    check_extract_golden(g, kps, desc, nv, mono, nc, DESC_TOL)
 
 
 def test_config3_batch8_720p_device_resident(gpu_lib, oracle_mod):

@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN
+from conftest import GOLDEN, MATCH_X_GOLDENS, match_x_inputs
 from xfeatslam_amd import capi, synth
 
 pytestmark = pytest.mark.gpu
@@ -62,6 +62,24 @@ def test_mnn_matches_golden(mctx, name):
     assert np.array_equal(i1, g["idx1"]) and np.array_equal(i2, g["idx2"])      # identical match pairs
     assert np.allclose(dist, g["dist"], atol=2e-6, equal_nan=True)
     assert np.array_equal(mctx.distance_i32(d1[:48], d2[:40]), g["dist_i32_corner"])
+
+
+@pytest.mark.parametrize("name", MATCH_X_GOLDENS)
+def test_mnn_matches_golden_extracted(mctx, name):
+    """round 6: ORBmatcher::match on descriptor blocks that came out of the extractor -- zero padding rows where a frame has fewer than
+    nfeatures keypoints, the lapping split's row order, exact duplicate rows, a ragged 4096 x 1000 pair -- the fixture carries the
+    blocks (int16 / 2^14) and the lists libtorch's matmul / max give on them (tests/golden/make_golden.py: match_extracted_case)"""
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    d1, d2 = match_x_inputs(g)
+    i1, i2, dist = mctx.match_mnn(d1, d2)
+    assert np.array_equal(i1, g["idx1"]) and np.array_equal(i2, g["idx2"])      # identical match pairs
+    assert np.allclose(dist, g["dist"], atol=2e-6, equal_nan=True)
+    p1, p2 = mctx.match_prepare(d1), mctx.match_prepare(d2)                     # the device-resident form the tracker would use
+    j1, j2, _ = mctx.match_mnn_prepared(p1, p2)
+    p1[0].free(); p2[0].free()
+    assert np.array_equal(j1, g["idx1"]) and np.array_equal(j2, g["idx2"])
+    assert np.array_equal(mctx.distance_i32(d1[:48], d2[:40]), g["dist_i32_corner"])
+    assert np.array_equal(mctx.distance_i32(d1[-24:], d2[-24:]), g["dist_i32_tail"])
 
 
 def test_mnn_edge_cases(mctx, oracle_mod):
