@@ -140,7 +140,7 @@ def test_mnn_ties_across_candidate_groups(mctx, oracle_mod, n1, n2):
 def test_distance_i32_exact(mctx, oracle_mod):
     """k_dist_mfma: MFMA bulk (|a|^2 + |b|^2 - 2ab) + exact recomputation wherever the value is within the error bound of an
     integer; the checker is the oracle's sequential fp32-difference / fp64-accumulate expression.  Zero rows (distance exactly
-    512 against unit rows), duplicates (distance 0), unnormalised and tiny-magnitude rows all stress the fix-up path."""
+    512 against unit rows), duplicates (distance 0), unnormalised rows, and both sets scaled down to norms of 1e-4 .. 3e-2 with duplicates across them, all stress the fix-up path."""
     for n1, n2, z in [(512, 384, 0), (70, 33, 3), (1, 1, 0), (64, 65, 0), (4096, 4096, 100), (129, 1000, 5)]:
         d1, d2 = synth.descriptor_sets(n1, n2, noise=0.3, zero_rows=z)
         if n2 > 10:
@@ -149,6 +149,13 @@ def test_distance_i32_exact(mctx, oracle_mod):
     d1, d2 = synth.descriptor_sets(300, 260, noise=0.5)
     s1 = (np.arange(300, dtype=np.float32) % 7 + 0.25)[:, None]; s2 = (np.arange(260, dtype=np.float32) % 5 * 0.5 + 1e-3)[:, None]
     assert np.array_equal(mctx.distance_i32(d1 * s1, d2 * s2), oracle_mod.distance_i32(d1 * s1, d2 * s2))
+    # BOTH sets tiny, with exact duplicates across them: the safety test's own fp32 roundings decide here -- a relative error bound
+    # below 2^-26 let a v32 of -1e-10 between identical rows through as floor(v32) = -1 (dist_mfma.hip.h: the absolute 2^-23 terms)
+    for sc in (1e-4, 1e-3, 2e-3, 1e-2, 3e-2):
+        a = (d1 * np.float32(sc)).astype(np.float32); b = (d2 * np.float32(sc)).astype(np.float32)
+        b[::3] = a[:260:3]; b[5] = 0; a[9] = 0
+        got, want = mctx.distance_i32(a, b), oracle_mod.distance_i32(a, b)
+        assert np.array_equal(got, want), (sc, int((got != want).sum()), got[got != want][:4], want[got != want][:4])
     q = (np.round(d1 * 64) / 64).astype(np.float32); r = (np.round(d2 * 64) / 64).astype(np.float32)       # many exactly representable distances
     assert np.array_equal(mctx.distance_i32(q, r), oracle_mod.distance_i32(q, r))
     d1, d2 = synth.descriptor_sets(n1, n2, noise=0.3, zero_rows=z)

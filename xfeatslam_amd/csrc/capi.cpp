@@ -422,18 +422,21 @@ static int load_weights_impl(xfh_ctx* c, const void* blob, size_t nbytes) {
 int xfh_load_weights(xfh_ctx* c, const void* blob, size_t nbytes) {
     if (!c || !blob) return XFH_ERR_INVALID_ARG;
     HIPCK(c, hipSetDevice(c->cfg.device));
-    // A reload replaces the packed buffers one by one (upload() frees and reallocates), and the twin / the pipeline lanes hold COPIES of the
-    // pointers: until the reload has succeeded nobody has weights, and whatever happens the children get the parent's current state -- after a
-    // failed reload that is "not loaded" (xfh_extract* then return XFH_ERR_NO_WEIGHTS) instead of pointers into freed memory.
-    c->w.loaded = false;
     // Nothing of this ctx may be in flight while the buffers are replaced: the pipeline lanes are HOST threads holding copies of the weight pointers
     // (a lane between its upload and its kernels is not covered by hipFree's device synchronisation), the twin and the ctx' own streams may still run
-    // a submitted frame.  Wait for all of them first.
+    // a submitted frame.  Wait for all of them first -- BEFORE any state changes: a failed synchronisation returns with the old
+    // weights still loaded everywhere, parent and children alike (the flag used to be cleared first, and an early return then left
+    // the parent "not loaded" while the twin and the lanes still reported the old buffers).
     pipe_wait_idle(c);
     for (int l = 0; l < c->pipe.nlanes; ++l) if (c->pipe.lane[l].ctx) HIPCK(c, hipStreamSynchronize(c->pipe.lane[l].ctx->stream));
     if (c->twin) HIPCK(c, hipStreamSynchronize(c->twin->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));
     if (c->aux_stream) HIPCK(c, hipStreamSynchronize(c->aux_stream));
+    // A reload replaces the packed buffers one by one (upload() frees and reallocates), and the twin / the pipeline lanes hold COPIES of the
+    // pointers: until the reload has succeeded nobody has weights, and from here on there is no early return -- whatever load_weights_impl does, the
+    // children get the parent's current state; after a failed reload that is "not loaded" (xfh_extract* then return XFH_ERR_NO_WEIGHTS) instead of
+    // pointers into freed memory.
+    c->w.loaded = false;
     const int rc = load_weights_impl(c, blob, nbytes);
     int rs = XFH_OK;
     if (c->twin) rs = ctx_share_weights(c, c->twin);

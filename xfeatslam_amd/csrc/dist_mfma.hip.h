@@ -17,6 +17,10 @@
 //        2^-23 (|a|^2+|b|^2) * 512 + 2^-24 v the roundings of ca, cb, c and of the final fma            (4 of the 72 units are slack)
 //        the two terms in v (together < 2^-21 |v32|) are bounded through |v32| <= 2 c: 2^-20 * 512 (|a|^2+|b|^2), so that E is a sum
 //        of a row part and a column part and costs half a packed add per output
+//        + 2^-23 ABSOLUTE in each of ea, eb (round 6): the test itself rounds -- u = fl(fl(0.5 - ea) - eb) and t = fl(fract - 0.5),
+//        up to 3 * 2^-26 together -- and for rows of norm below ~2e-3 a purely relative E fell under 2^-26: u rounded to exactly 0.5 and a v32 of
+//        -1e-10 between two identical tiny rows (fract clamps to 1 - 2^-24, t = 0.5 - 2^-24 < u) passed as "safe" with floor(v32) = -1 against the
+//        reference's 0.  With the absolute term u <= 0.5 - 2^-22, so every value within 2^-22 of an integer (the clamp included) is marked.
 // Wherever the fractional part of v32 is further than E from 0 and 1, floor(v32) IS the reference's integer (v32 >= 2^23 has no
 // fractional part, infinities and NaN give NaN: they fail the test).  The other entries (about 1 % for unit descriptors; every entry
 // that is an exact integer, e.g. against zero-padded rows) are collected per wave into a dense list (LDS) and recomputed with the exact
@@ -94,7 +98,7 @@ __device__ __forceinline__ void dist_stage_row(const f32x4 (&v)[16 / LANES], int
     }
     if (sub == 0) {
         sC[rl] = (float)(512.0 * ss);
-        sE[rl] = (float)(512.0 * (72.0 * 5.9604644775390625e-8 + 9.5367431640625e-7) * 1.00002 * ss);      // rounded up: the bound stays a bound
+        sE[rl] = (float)(512.0 * (72.0 * 5.9604644775390625e-8 + 9.5367431640625e-7) * 1.00002 * ss + 1.1920928955078125e-7);      // rounded up: the bound stays a bound; + 2^-23 absolute (header)
     }
 #pragma unroll
     for (int g = 0; g < NV / 2; ++g) {                   // group of 8 = pieces 2g (e0..e3), 2g+1 (e4..e7) -> (e0 e2 e4 e6), (e1 e3 e5 e7)
@@ -117,12 +121,12 @@ void k_dist_mfma(const float* __restrict__ d1, int n1, const float* __restrict__
     __shared__ __attribute__((aligned(16))) float sB[2][DTC * DLDK];
     __shared__ __attribute__((aligned(16))) float sCa[DT], sEa[DT], sCb[2][DTC], sEb[2][DTC];      // 512 |x|^2 and the row's share of the error bound
     __shared__ unsigned sList[DLIST];                      // (row in the panel << 16 | column in the workgroup's strip) of the entries to recompute exactly
-    __shared__ int sCnt[2];                                // entries listed; lanes that still hold entries
+    __shared__ int sCnt[3];                                // entries listed; "lanes still hold entries" raised while listing an even / an odd column tile
     const int t = threadIdx.x;
     const int row_base = blockIdx.y * DT;
     const int col0 = blockIdx.x * (nt * DTC);
     const int ntile = (n2 - col0 + DTC - 1) / DTC < nt ? (n2 - col0 + DTC - 1) / DTC : nt;        // >= 1 by the grid
-    if (t < 2) sCnt[t] = 0;
+    if (t < 3) sCnt[t] = 0;
     if ((DBG & 64) && (blockIdx.y * gridDim.x + blockIdx.x) * 2 >= gridDim.x * gridDim.y) __builtin_amdgcn_s_sleep(127);
     if ((DBG & 128) && (blockIdx.x & 1)) __builtin_amdgcn_s_sleep(127);
     f32x4 vb[2];                                            // this thread's piece of the NEXT column tile: 8 lanes per row, row t >> 3
@@ -175,7 +179,9 @@ void k_dist_mfma(const float* __restrict__ d1, int n1, const float* __restrict__
             const int rl = wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, cs = kt * DTC + wc * 32 + i;
             sList[pre++] = ((unsigned)rl << 16) | (unsigned)cs;
         }
-        if (__ballot(mask != 0u) && lane == 0) atomicOr(&sCnt[1], 1);           // the list is full: flush, then list the rest
+        // the list is full: flush, then list the rest.  The flag of tile kt's PARITY: a wave that has already left tile kt - 1 (an even, non-flush tile ends
+        // without a barrier behind its loop condition) raises the other flag than the one a slower wave of the workgroup is still reading there
+        if (__ballot(mask != 0u) && lane == 0) atomicOr(&sCnt[1 + (kt & 1)], 1);
     };
     for (int kt = 0; kt < ntile; ++kt) {
         const int col_base = col0 + kt * DTC, b = kt & 1;
@@ -209,8 +215,8 @@ void k_dist_mfma(const float* __restrict__ d1, int n1, const float* __restrict__
         // ---- exact expression for the listed entries (block-uniform: a flush tile, or the list has overflowed -- then it holds entries of this tile only, the
         // previous flush having emptied it).  One entry per thread: both rows from LDS (element k = 8g + 2j + hh of a row sits at 8g + 4hh + j), one fp64 fma
         // chain in k order = the oracle's.
-        while (!(DBG & 1) && (flush_tile || sCnt[1]) && sCnt[0] > 0) {
-            const int total = sCnt[0], more = sCnt[1];
+        while (!(DBG & 1) && (flush_tile || sCnt[1 + b]) && sCnt[0] > 0) {
+            const int total = sCnt[0], more = sCnt[1 + b];
             const int n = total < DLIST ? total : DLIST;
             int fix_val = 0; size_t fix_at = 0;
             if (t < n) {
@@ -238,7 +244,7 @@ void k_dist_mfma(const float* __restrict__ d1, int n1, const float* __restrict__
             __builtin_amdgcn_s_waitcnt(0x0f70);
             __syncthreads();                                 // also: everybody has read the counters and the list
             if (t < n) out[fix_at] = fix_val;
-            if (t < 2) sCnt[t] = 0;
+            if (t == 0) { sCnt[0] = 0; sCnt[1 + b] = 0; }
             __syncthreads();
             if (!more) break;
             list_marked(mask, kt);                          // the lanes that kept entries list them now

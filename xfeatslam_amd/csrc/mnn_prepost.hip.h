@@ -302,7 +302,7 @@ void k_mnn_post(const float* __restrict__ img1, int n1, const float* __restrict_
 // ascending (y, x) order, so a pair's collectors only ever wait for writers that were dispatched before them.
 // ASSUMPTION: HIP does not promise that dispatch order.  What the kernel relies on is weaker: the writers never wait for anybody, so a
 // collector can only be kept waiting by writers that have not been dispatched yet, and that needs every slot of the GPU to be held by spinning
-// collectors -- at most 16 per pair x 16 pairs = 256 workgroups of 4 waves against 2048 wave slots (22 KB of LDS each: 7 per CU), so writers always
+// collectors -- at most 16 per pair x 16 pairs = 256 workgroups of 4 waves against 2048 workgroup slots (MNN_POST_LDS = 20 KB of LDS each: eight per CU), so writers always
 // find room.  Should a writer still never show up, the collectors' spin is bounded (MNN_SPIN_LIMIT) and the pair reports n_matches = -1, which the host
 // API turns into an error instead of a hang.
 struct MnnPostBatch { MnnPostArgs job[MNN_MAX_JOBS]; };
