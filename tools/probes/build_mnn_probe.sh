@@ -10,3 +10,5 @@ F="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Wno-unused-value"
 /opt/rocm/bin/hipcc $F -fno-honor-nans -c mnn_seg_probe_gemm.hip -o /tmp/mnn_seg_probe_gemm.o
 /opt/rocm/bin/hipcc $F -c mnn_seg_probe.hip -o /tmp/mnn_seg_probe.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 /tmp/mnn_seg_probe.o /tmp/mnn_seg_probe_gemm.o -o mnn_seg_probe
+# the floor of a match finished inside the GEMM launch (mnn_tail_probe.hip): the real GEMM + the skeleton of a last-arriver tail
+/opt/rocm/bin/hipcc $F -fno-honor-nans mnn_tail_probe.hip -o mnn_tail_probe

@@ -31,7 +31,11 @@ __device__ __forceinline__ void mnn_dma1k(const float* gsrc_lane, float* lds_dst
 // maximum" once it has named the first member of the group that reaches the value (it recomputes the 4 / <= 16 dot
 // products with the MFMA's own arithmetic).  Every plane entry of a launched block is written (0 = no valid product),
 // so nothing has to be cleared between calls.
-template <int PRIO, int PIPE, int STG, int DBG = 0>      // DBG (probes only): 1 = no epilogue, 2 = no staging
+// TAIL (probes only, tools/probes/mnn_tail_probe.hip): the key planes go out as agent-scope (write-through) stores and the workgroup then runs
+// mnn_tail_hook<TAIL> -- the skeleton of a match finished INSIDE this launch (arrival counters, last arriver per panel); the product instance is
+// TAIL = 0 and contains none of it (if constexpr).
+template <int TAIL> __device__ void mnn_tail_hook(float* smem, const float* img2, int n1, int n2, const u64* partR, size_t ldr, const u64* partC, size_t ldc, u64* pairs);
+template <int PRIO, int PIPE, int STG, int DBG = 0, int TAIL = 0>      // DBG (probes only): 1 = no epilogue, 2 = no staging
 __global__ __launch_bounds__(512, 2)
 void k_mnn_gemm_img(const float* __restrict__ img1, int n1, const float* __restrict__ img2, int n2,
                     u64* __restrict__ partR, size_t ldr, u64* __restrict__ partC, size_t ldc, u64* __restrict__ pairs) {
@@ -225,9 +229,14 @@ void k_mnn_gemm_img(const float* __restrict__ img1, int n1, const float* __restr
     if (t < 256) {
         // d2 row col_base + t  <->  position wc*128 + ct*32 + i  with  t = wc*128 + i*4 + ct
         const int p = (t & 128) | ((t & 3) << 5) | ((t & 127) >> 2);
-        partC[(size_t)blockIdx.y * ldc + col_base + t] = mnn_umax64(mnn_umax64(sCol[p], sCol[256 + p]), mnn_umax64(sCol[512 + p], sCol[768 + p]));
+        const u64 kc = mnn_umax64(mnn_umax64(sCol[p], sCol[256 + p]), mnn_umax64(sCol[512 + p], sCol[768 + p]));
+        if constexpr (TAIL != 0) __hip_atomic_store(&partC[(size_t)blockIdx.y * ldc + col_base + t], kc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else partC[(size_t)blockIdx.y * ldc + col_base + t] = kc;
     } else {
         const int r = t - 256;
-        partR[(size_t)blockIdx.x * ldr + row_base + r] = mnn_umax64(sRow[r], sRow[256 + r]);
+        const u64 kr = mnn_umax64(sRow[r], sRow[256 + r]);
+        if constexpr (TAIL != 0) __hip_atomic_store(&partR[(size_t)blockIdx.x * ldr + row_base + r], kr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else partR[(size_t)blockIdx.x * ldr + row_base + r] = kr;
     }
+    if constexpr (TAIL != 0) mnn_tail_hook<TAIL>(smem, img2, n1, n2, partR, ldr, partC, ldc, pairs);
 }
