@@ -329,6 +329,9 @@ def main():
         conv_traffic = traffic["conv_bytes_per_launch"] * (B / traffic["conv_batch"] if traffic.get("conv_batch") else 1.0)
     out["config"]["bn_mode"] = args.bn
     out["config"]["library"] = lib.xfh_version().decode()
+    # which librccl moves the records (comm.cpp: $XFH_RCCL_LIB, else /opt/rocm/lib/librccl.so.1, ...; file of ncclAllGather, ncclGetVersion, HIP runtime on both sides) and in which form
+    out["config"]["rccl"] = lib.xfh_comm_library().decode() if use_comm else "not loaded (one rank, no exchange)"
+    out["config"]["gather_form"] = args.gather if use_comm else "none (one rank)"
     pmc_src = "profiles/pmc_traffic.json: the builder's separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes (tools/gpu_round.sh), corrected with the factors calibrated on known-byte-count kernels (xfh_bench_calib); a constant in this run, not an observation of it"
     step_tf = net_flops(H, W) * frames_per_s / N / 1e12
     out["step_roofline"] = {"what": "all convolutions of the network (algorithmic flops per frame) x frames/s per GPU of the timed region, against the f32 MFMA peak: "
@@ -378,14 +381,14 @@ def flat_scalars(out, N):
     contract: "inputs already resident in HBM when the timed region starts ... the PCIe-inclusive rate is never `value`" -- and SURVEY.md 8d's host-visible
     reading of the same metric sits next to it."""
     c, r = out["config"], out["roofline"]
-    c["hbm_resident_frames_per_s_per_gpu"] = out["value"] / N
+    c["hbm_resident_fps_per_gpu"] = out["value"] / N
     if "host_visible" in out:
         hv = out["host_visible"]
         c["host_visible_frames_per_s"] = hv["value"]                                   # SURVEY.md 8d read literally: host memory -> host memory, PCIe inside the clock (rank 0's GPU)
-        c["host_visible_blocking_frames_per_s"] = hv["blocking"]["value"]
+        c["host_visible_blocking_fps"] = hv["blocking"]["value"]
         c["host_visible_vs_hbm_resident"] = hv["vs_hbm_resident"]
         if "one_frame_per_call" in hv:
-            c["host_visible_one_frame_per_call_frames_per_s"] = hv["one_frame_per_call"]["value"]
+            c["host_one_frame_per_call_fps"] = hv["one_frame_per_call"]["value"]
     if "single_frame" in out:
         c["single_frame_ms"] = out["single_frame"]["ms_per_frame"]
     if "step_roofline" in out:
@@ -407,7 +410,7 @@ def flat_scalars(out, N):
             c["match_batched_call_frac"] = flop / (m["batched"]["us_per_pair"] * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS
             c["match_batched_gemm_frac"] = m["batched"]["roofline"]["frac"]
         if "paced_30hz" in m:
-            c["match_paced_30hz_us_per_call"] = m["paced_30hz"]["us_per_call_median"]
+            c["match_paced_30hz_us"] = m["paced_30hz"]["us_per_call_median"]
     ak = out.get("aux_kernels") or {}
     for k, v in ak.items():
         if k.startswith("k_dist_i32"):
@@ -426,7 +429,7 @@ def flat_scalars(out, N):
         if isinstance(v, dict) and "frames_per_s" in v:
             c[f"gather_{form}_frames_per_s"] = v["frames_per_s"]
     if isinstance(out.get("exchange_check"), dict):
-        c["exchange_records_equal_serial_ctx"] = bool(out["exchange_check"]["equal_to_serial_ctx"])
+        c["exchange_equal_serial_ctx"] = bool(out["exchange_check"]["equal_to_serial_ctx"])
         c["exchange_records_checked"] = out["exchange_check"]["records_checked"]
     c3 = out.get("configs3")
     if isinstance(c3, dict):
@@ -440,6 +443,15 @@ def flat_scalars(out, N):
 
 PCIE_GBPS = 63.0      # PCIe 5.0 x16, one direction, after 128b/130b (tools/pcie_probe.py on the bench box: 56.5 GB/s for one copy stream)
 C3_H, C3_W = 720, 1280
+    # Order and names for the driver's record: its parser keeps the first ~20 scalars of `config`, names cut at 40 characters (BENCH_r05.json lost the parity
+    # flags and the paced match figure that way): what identifies the run and what a reader must see first, every name <= 32 characters.
+    first = ["workload", "parallelism", "rccl", "gather_form", "extract_only_frames_per_s", "gather_cost_frac", "exchange_equal_serial_ctx",
+             "parity_keypoint_sets_equal", "parity_match_pairs_equal", "parity_max_abs_desc_diff", "step_mfma_frac", "host_visible_frames_per_s", "single_frame_ms",
+             "match_us_per_call", "match_call_frac", "match_gemm_frac", "match_paced_30hz_us", "match_batched_us_per_pair", "dist_i32_kernel_us",
+             "frames_per_gpu_per_step", "sub_batches_in_flight", "bn_mode", "library"]
+    out["config"] = {**{k: c[k] for k in first if k in c}, **{k: v for k, v in c.items() if k not in first}}
+    assert all(len(k) <= 32 for k in out["config"]), [k for k in out["config"] if len(k) > 32]
+
 
 
 def multi_rank_legs(args, lib, capi, synth, Context, xd, comm, ctx, blob, rank, N, dev, nf, rec_bytes, step, timed, gather, gather_target, frames_per_rank, step_no):

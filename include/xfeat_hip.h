@@ -280,6 +280,10 @@ int xfh_distinctive_csr_device(xfh_ctx* ctx, const float* d_table, int n_rows, c
  * overwritten, xfh_comm_synchronize waits on the host. */
 #define XFH_UNIQUE_ID_BYTES 128
 int xfh_comm_unique_id(void* id_out /* XFH_UNIQUE_ID_BYTES */);
+/* Which librccl the exchange runs on and what it is: "<file> (RCCL a.b.c; its HIP runtime x.y at <file>; libxfeat_hip's HIP runtime x.y at <file>)",
+ * "" when none can be loaded.  Search order: $XFH_RCCL_LIB (explicit, no fallback), /opt/rocm/lib/librccl.so.1, librccl.so.1, librccl.so.
+ * xfh_comm_create returns XFH_ERR_COMM when that RCCL is bound to another HIP runtime (file or major.minor) than this library. */
+const char* xfh_comm_library(void);
 int xfh_comm_create(xfh_ctx* ctx, const void* unique_id, int rank, int world);
 int xfh_comm_destroy(xfh_ctx* ctx);
 int xfh_comm_rank(xfh_ctx* ctx);

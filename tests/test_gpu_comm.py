@@ -26,6 +26,10 @@ def test_rccl_world1_gathers_match_records(gpu_lib):
     comm = xd.Comm(ctx, 0, 1, "127.0.0.1", port)
     assert L.xfh_comm_rank(ctx.h) == 0 and L.xfh_comm_world(ctx.h) == 1
     assert L.xfh_comm_create(ctx.h, bytes(128), 0, 1) == 1                      # already has a communicator
+    # which RCCL this is (round 6): the file ncclAllGather lives in, its ncclGetVersion, and the HIP runtime on both sides -- a REAL librccl here
+    which = L.xfh_comm_library().decode()
+    print(f"\n  real RCCL, world 1: {which}", flush=True)
+    assert "librccl" in which and "stubs" not in which and "RCCL 0.0.0" not in which, which
     frames = synth.frames(B, H, W, seed=9)
     frames[1] = 0                                                               # a frame without keypoints: empty compact segment
     rec = ctx.rec_bytes

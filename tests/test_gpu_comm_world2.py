@@ -28,7 +28,7 @@ def _run_world(world, n, out_dir):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
     env = dict(os.environ)
-    env["LD_LIBRARY_PATH"] = stub_dir + (":" + env["LD_LIBRARY_PATH"] if env.get("LD_LIBRARY_PATH") else "")
+    env["XFH_RCCL_LIB"] = os.path.join(stub_dir, "librccl.so.1")           # explicit (comm.cpp: no fallback behind it); round 5 went through LD_LIBRARY_PATH
     worker = os.path.join(ROOT, "tests", "workers", "comm_world_worker.py")
     procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), str(port), str(n), str(out_dir)], env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
@@ -115,7 +115,7 @@ def test_bench_runs_with_n_ranks(gpu_lib, tmp_path, world):
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        env["LD_LIBRARY_PATH"] = stub_dir + (":" + env["LD_LIBRARY_PATH"] if env.get("LD_LIBRARY_PATH") else "")
+        env["XFH_RCCL_LIB"] = os.path.join(stub_dir, "librccl.so.1")           # explicit (comm.cpp: no fallback behind it)
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1", "--batch", "3", "--streams", "2",
                                        "--height", "96", "--width", "128", "--cpu-frames", "0", "--match-iters", "5", "--match-pairs", "2", "--host-steps", "3"],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
@@ -145,7 +145,7 @@ def test_bench_runs_with_n_ranks(gpu_lib, tmp_path, world):
     assert cfg["parallelism"] == f"frames x{world}"
     assert c3["n_ranks"] == world and line["exchange_check"]["ranks"] == world
     assert line["exchange_check"]["equal_to_serial_ctx"] is True and line["exchange_check"]["records_checked"] == 2 * world
-    assert cfg["exchange_records_equal_serial_ctx"] is True
+    assert cfg["exchange_equal_serial_ctx"] is True
     assert cfg["extract_only_frames_per_s"] == line["extract_only"]["frames_per_s"] and 0 <= 1 - line["value"] / cfg["extract_only_frames_per_s"] == cfg["gather_cost_frac"] or cfg["gather_cost_frac"] < 0
     for form in ("root", "compact"):
         assert cfg[f"gather_{form}_frames_per_s"] == line["gather_forms"][form]["frames_per_s"]
@@ -153,3 +153,9 @@ def test_bench_runs_with_n_ranks(gpu_lib, tmp_path, world):
         assert cfg[f"configs3_{form}_frames_per_s"] > 0
     assert cfg["host_visible_frames_per_s"] == line["host_visible"]["value"] and cfg["match_us_per_call"] == line["match"]["us_per_call"]
     assert "gfx950" in cfg["library"]
+    # round 6: the line says which librccl moved the records and in which form, within the first 20 config keys (what the driver's record keeps)
+    first20 = list(cfg)[:20]
+    for key in ("rccl", "gather_form", "extract_only_frames_per_s", "parity_keypoint_sets_equal", "parity_match_pairs_equal", "match_paced_30hz_us"):
+        assert key in first20, (key, first20)
+    assert "tests/stubs/librccl.so.1" in cfg["rccl"] and cfg["gather_form"] == "allgather"
+    assert all(len(k) <= 32 for k in cfg), [k for k in cfg if len(k) > 32]

@@ -84,6 +84,7 @@ SYMBOLS = [
     ("xfh_distinctive_csr", _i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp]),
     ("xfh_distinctive_csr_device", _i, [_vp, _vp, _i, _vp, _vp, _i, _i, _vp, _vp]),
     ("xfh_comm_unique_id", _i, [_vp]),
+    ("xfh_comm_library", C.c_char_p, []),
     ("xfh_comm_create", _i, [_vp, _vp, _i, _i]),
     ("xfh_comm_destroy", _i, [_vp]),
     ("xfh_comm_rank", _i, [_vp]),

@@ -4,14 +4,20 @@
 //   xfh_allgather_records     ncclAllGather of B records per rank (what BASELINE.json's configs[3] names)
 //   xfh_gather_records_root   ncclSend / ncclRecv to one root only (the other GPUs receive nothing)
 //   xfh_gather_compact_root   the same with only header + valid rows on the wire (sizes exchanged first)
-// librccl is opened with dlopen at xfh_comm_create, so the library has no link-time dependency on it and a process
-// that already carries an RCCL (e.g. PyTorch's) shares that copy.  Collectives run on a communication stream of the
+// librccl is opened with dlopen at xfh_comm_create, so the library has no link-time dependency on it.  WHICH librccl is deterministic and
+// recorded (round 6): $XFH_RCCL_LIB if set (the tests' stand-in), else /opt/rocm/lib/librccl.so.1 -- the RCCL of the ROCm this library was built
+// with -- else whatever "librccl.so.1" / "librccl.so" resolve to; xfh_comm_library() names the file (dladdr of ncclAllGather), its ncclGetVersion and the
+// HIP runtime it calls, and xfh_comm_create refuses an RCCL that would run on ANOTHER HIP runtime than this library's streams live in (a process that
+// imported PyTorch first carries the wheel's own libamdhip64 + librccl: a stream handle of one runtime means nothing to the other).  Collectives run on a communication stream of the
 // ctx, ordered after the extraction by an event, so the next extraction overlaps them; xfh_comm_fence orders a later
 // extraction after the collective that read a record buffer.
 #include "ctx.h"
 #include <dlfcn.h>
+#include <limits.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
+#include <string>
 #include <vector>
 
 namespace {
@@ -31,20 +37,53 @@ struct Rccl {
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*GetVersion)(int*) = nullptr;
+    std::string path, hip_of_rccl, hip_of_lib, describe;
+    int version = 0, hip_ver_rccl = 0, hip_ver_lib = 0;
 };
+// path of the shared object a function lives in ("?" if the loader does not know)
+static std::string so_of(void* fn) {
+    Dl_info di;
+    if (fn && dladdr(fn, &di) && di.dli_fname) { char buf[4096]; const char* rp = realpath(di.dli_fname, buf); return rp ? rp : di.dli_fname; }
+    return "?";
+}
 Rccl* rccl() {
     static Rccl* R = []() -> Rccl* {               // thread-safe one-time initialisation (C++11 static)
         static Rccl r;
-        for (const char* n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { r.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (r.h) break; }
+        const char* forced = getenv("XFH_RCCL_LIB");
+        if (forced && *forced) r.h = dlopen(forced, RTLD_NOW | RTLD_LOCAL);          // explicit: no fallback behind it
+        else for (const char* n : {"/opt/rocm/lib/librccl.so.1", "librccl.so.1", "librccl.so"}) { r.h = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (r.h) break; }
         if (!r.h) return nullptr;
 #define SYM(f, s) do { *(void**)(&r.f) = dlsym(r.h, s); if (!r.f) return nullptr; } while (0)
         SYM(GetUniqueId, "ncclGetUniqueId"); SYM(CommInitRank, "ncclCommInitRank"); SYM(CommDestroy, "ncclCommDestroy");
         SYM(AllGather, "ncclAllGather"); SYM(Send, "ncclSend"); SYM(Recv, "ncclRecv");
         SYM(GroupStart, "ncclGroupStart"); SYM(GroupEnd, "ncclGroupEnd"); SYM(GetErrorString, "ncclGetErrorString");
 #undef SYM
+        *(void**)(&r.GetVersion) = dlsym(r.h, "ncclGetVersion");                     // optional (the tests' stand-in has none)
+        r.path = so_of((void*)r.AllGather);
+        int v = 0;
+        if (r.GetVersion && r.GetVersion(&v) == 0) r.version = v;
+        // the HIP runtime this RCCL calls = the one its own symbol lookup finds, against the one this library's streams belong to
+        void* rccl_hip = dlsym(r.h, "hipRuntimeGetVersion");
+        r.hip_of_rccl = rccl_hip ? so_of(rccl_hip) : "?";
+        r.hip_of_lib = so_of((void*)&hipRuntimeGetVersion);
+        int (*rv)(int*) = nullptr; *(void**)(&rv) = rccl_hip;
+        int a = 0, b = 0;
+        if (rv && rv(&a) == 0) r.hip_ver_rccl = a;
+        if (hipRuntimeGetVersion(&b) == hipSuccess) r.hip_ver_lib = b;
+        char buf[8192];
+        snprintf(buf, sizeof buf, "%s (RCCL %d.%d.%d; its HIP runtime %d.%d at %s; libxfeat_hip's HIP runtime %d.%d at %s)", r.path.c_str(),
+                 r.version / 10000, (r.version / 100) % 100, r.version % 100, r.hip_ver_rccl / 10000000, (r.hip_ver_rccl / 100000) % 100, r.hip_of_rccl.c_str(),
+                 r.hip_ver_lib / 10000000, (r.hip_ver_lib / 100000) % 100, r.hip_of_lib.c_str());
+        r.describe = buf;
         return &r;
     }();
     return R;
+}
+// an RCCL bound to another HIP runtime than ours (another file, or another major.minor) cannot take our streams
+static bool rccl_hip_mismatch(const Rccl* r) {
+    if (r->hip_of_rccl == "?" || r->hip_ver_rccl == 0) return false;            // a stand-in without HIP inside (tests): nothing to compare
+    return r->hip_of_rccl != r->hip_of_lib || r->hip_ver_rccl / 100000 != r->hip_ver_lib / 100000;
 }
 }  // namespace
 
@@ -100,6 +139,12 @@ void k_pack_rows(const uint8_t* __restrict__ rec, size_t rec_bytes, int B, int n
 
 extern "C" {
 
+// which librccl the exchange runs on: "<file> (RCCL a.b.c; its HIP runtime x.y at <file>; libxfeat_hip's HIP runtime x.y at <file>)"; "" if none can be loaded
+const char* xfh_comm_library(void) {
+    Rccl* R = rccl();
+    return R ? R->describe.c_str() : "";
+}
+
 int xfh_comm_unique_id(void* id_out) {
     if (!id_out) return XFH_ERR_INVALID_ARG;
     Rccl* R = rccl();
@@ -132,7 +177,12 @@ int xfh_comm_destroy(xfh_ctx* c) {
 int xfh_comm_create(xfh_ctx* c, const void* unique_id, int rank, int world) {
     if (!c || !unique_id || world < 1 || rank < 0 || rank >= world || c->comm) return XFH_ERR_INVALID_ARG;
     Rccl* R = rccl();
-    if (!R) { c->hip_err = "librccl.so.1 not found"; return XFH_ERR_COMM; }
+    if (!R) { c->hip_err = "librccl not found ($XFH_RCCL_LIB, /opt/rocm/lib/librccl.so.1, librccl.so.1, librccl.so)"; return XFH_ERR_COMM; }
+    if (rccl_hip_mismatch(R) && !(getenv("XFH_RCCL_ALLOW_HIP_MISMATCH") && *getenv("XFH_RCCL_ALLOW_HIP_MISMATCH") == '1')) {
+        c->hip_err = "RCCL runs on another HIP runtime than libxfeat_hip: " + R->describe + " -- set XFH_RCCL_LIB to an RCCL of this runtime";
+        fprintf(stderr, "[xfh] %s\n", c->hip_err.c_str());
+        return XFH_ERR_COMM;
+    }
     HIPCK(c, hipSetDevice(c->cfg.device));
     XfhComm* m = new XfhComm();
     m->rank = rank; m->world = world;
@@ -146,7 +196,7 @@ int xfh_comm_create(xfh_ctx* c, const void* unique_id, int rank, int world) {
     ncclUniqueId id; memcpy(&id, unique_id, sizeof id);
     ncclResult_t r = R->CommInitRank(&m->comm, world, id, rank);
     if (r != 0) { c->hip_err = std::string("ncclCommInitRank: ") + R->GetErrorString(r); return bail(XFH_ERR_COMM); }
-    if (xfh_verbose()) fprintf(stderr, "[xfh] ctx %p: communicator rank %d of %d on device %d\n", (void*)c, rank, world, c->cfg.device);
+    if (xfh_verbose()) fprintf(stderr, "[xfh] ctx %p: communicator rank %d of %d on device %d over %s\n", (void*)c, rank, world, c->cfg.device, R->describe.c_str());
     return XFH_OK;
 }
 
