@@ -439,10 +439,6 @@ def flat_scalars(out, N):
     c31 = out.get("configs3_one_gpu")
     if isinstance(c31, dict):
         c["configs3_one_gpu_frames_per_s"] = c31["device_resident"]["frames_per_s"]
-
-
-PCIE_GBPS = 63.0      # PCIe 5.0 x16, one direction, after 128b/130b (tools/pcie_probe.py on the bench box: 56.5 GB/s for one copy stream)
-C3_H, C3_W = 720, 1280
     # Order and names for the driver's record: its parser keeps the first ~20 scalars of `config`, names cut at 40 characters (BENCH_r05.json lost the parity
     # flags and the paced match figure that way): what identifies the run and what a reader must see first, every name <= 32 characters.
     first = ["workload", "parallelism", "rccl", "gather_form", "extract_only_frames_per_s", "gather_cost_frac", "exchange_equal_serial_ctx",
@@ -451,6 +447,10 @@ C3_H, C3_W = 720, 1280
              "frames_per_gpu_per_step", "sub_batches_in_flight", "bn_mode", "library"]
     out["config"] = {**{k: c[k] for k in first if k in c}, **{k: v for k, v in c.items() if k not in first}}
     assert all(len(k) <= 32 for k in out["config"]), [k for k in out["config"] if len(k) > 32]
+
+
+PCIE_GBPS = 63.0      # PCIe 5.0 x16, one direction, after 128b/130b (tools/pcie_probe.py on the bench box: 56.5 GB/s for one copy stream)
+C3_H, C3_W = 720, 1280
 
 
 

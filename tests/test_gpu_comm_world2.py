@@ -155,7 +155,9 @@ def test_bench_runs_with_n_ranks(gpu_lib, tmp_path, world):
     assert "gfx950" in cfg["library"]
     # round 6: the line says which librccl moved the records and in which form, within the first 20 config keys (what the driver's record keeps)
     first20 = list(cfg)[:20]
-    for key in ("rccl", "gather_form", "extract_only_frames_per_s", "parity_keypoint_sets_equal", "parity_match_pairs_equal", "match_paced_30hz_us"):
+    for key in ("rccl", "gather_form", "extract_only_frames_per_s", "gather_cost_frac", "exchange_equal_serial_ctx", "step_mfma_frac", "match_us_per_call"):
         assert key in first20, (key, first20)
+    for key in ("parity_keypoint_sets_equal", "parity_match_pairs_equal", "match_paced_30hz_us"):          # legs this small run switches off (--cpu-frames 0, few match calls)
+        assert key in first20 or key not in cfg, (key, first20)
     assert "tests/stubs/librccl.so.1" in cfg["rccl"] and cfg["gather_form"] == "allgather"
     assert all(len(k) <= 32 for k in cfg), [k for k in cfg if len(k) > 32]

@@ -1,8 +1,10 @@
-"""A hazard net that does not depend on the container's compiler.  libxfeat_hip.so is built in the development
-container (ROCm 7.2 hipcc) and carries a hand-counted MFMA -> VALU-read pad (common.h: XFH_MFMA_SETTLE).  This test compiles
-tests/cpp/hazard_probe.hip with the hipcc found ON THE GPU BOX, using the library's own macro, and checks MFMA -> XFH_MFMA_SETTLE -> taken
-branch -> VALU read against a host fma chain for both MFMA forms the library issues; it also records the versions on both sides
-(xfh_version(): the clang / HIP the library was built with and the runtime it met; the probe: the box's compiler)."""
+"""The MFMA -> read-of-the-result dependency, measured on the GPU box with that box's own compiler.
+libxfeat_hip.so is built in the development container (ROCm 7.2 hipcc).  Rounds 2-5 carried a hand-counted pad between every K loop and its epilogue
+(common.h: XFH_MFMA_SETTLE); round 6's sweep (tests/cpp/hazard_probe.hip, part 2: the last MFMA, N = 0..20 wait states, an optional taken branch and the first
+VALU / global_store / ds_write read of the accumulators in one inline-asm statement, where no compiler pads anything) shows gfx950 interlocks the dependency: every
+configuration is exact from N = 0 on, so the pad was removed.  The test prints the sweep, keeps the log honest about what it found (`red configurations`), fails
+if the library-shaped kernels return a wrong value with the macro as shipped, and records the versions on both sides (xfh_version(): the clang / HIP the library
+was built with and the runtime it met; the probe: the box's compiler)."""
 import os
 import shutil
 import subprocess
@@ -35,3 +37,8 @@ def test_mfma_settle_macro_with_the_boxs_own_compiler(gpu_lib, tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     print("  " + r.stdout.strip().replace("\n", "\n  "))
     assert r.returncode == 0 and "hazard probe ok" in r.stdout, (r.returncode, r.stdout, r.stderr)
+    red = int(r.stdout.split("sweep red configurations:")[1].split()[0])
+    if red:
+        # the hardware did NOT interlock somewhere: the shipped macro has no wait states any more, so the library-shaped kernels above are the judge -- they
+        # passed (returncode 0) -- but say it loudly: rebuild with -DXFH_SETTLE_NOPS before trusting this box
+        print(f"  WARNING: {red} sweep configurations returned stale accumulators on this GPU: the interlock round 6 measured is not there; rebuild with -DXFH_SETTLE_NOPS")

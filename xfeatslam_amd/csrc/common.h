@@ -63,11 +63,19 @@ __device__ __forceinline__ float xfh_expf(float d) {
     return u;
 }
 
-// hipcc (ROCm 7.2) pads the MFMA -> VALU-read hazard (18 wait states after a 16-pass v_mfma_f32_32x32x2_f32) along the
-// fall-through path only: with a taken branch between the last MFMA and the first read of its result a stale register
-// came back (k_conv_mfma_p<8,24,...>: 10 wait states).  Every kernel therefore lets the matrix pipe drain explicitly between
-// its K loop and an epilogue that branches; the scheduling barriers keep every instruction on its side of the nops.
+// XFH_MFMA_SETTLE: the boundary between a K loop and its epilogue.  Rounds 2-5 padded it by hand (s_nop 15; s_nop 3 = 20 wait states) after a stale accumulator
+// read had been seen in k_conv_mfma_p<8,24,...> behind a taken branch, where hipcc's hazard recogniser had left 10 wait states.  Round 6 measured the hardware
+// instead of the compiler (tests/cpp/hazard_probe.hip: the last MFMA, N = 0..20 wait states, an optional taken s_cbranch and the first read of the result in ONE
+// inline-asm statement the recogniser cannot see into): gfx950 interlocks the dependency -- VALU, global_store and ds_write reads of the result of both MFMA forms the
+// library issues are correct with ZERO wait states, with and without the branch (profiles/r06_hazard_probe.log) -- and the whole GPU suite, campaign and goldens
+// included, is green without the pad (profiles/r06_nosettle.md: 203 tests; one serial 256-frame step 121.0 -> 120.0 ms of kernel time).  What had been seen was
+// therefore not this hazard; the pad is gone.  The scheduling barriers stay: they cost nothing and keep epilogue instructions out of the K loop's tail.
+// -DXFH_SETTLE_NOPS restores the old pad (A/B builds: make variant_all DEFS=-DXFH_SETTLE_NOPS).
+#ifdef XFH_SETTLE_NOPS
 #define XFH_MFMA_SETTLE() do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_nop 15\n\ts_nop 3" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define XFH_MFMA_SETTLE() do { __builtin_amdgcn_sched_barrier(0); asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#endif
 
 // ---- statistics finalisation ------------------------------------------------------------
 // Fold the npart (sum, sum of squares) fp64 partials of every channel in a FIXED order into
