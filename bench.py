@@ -51,10 +51,10 @@ sys.path.insert(0, ROOT)
 PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, dense f32 MFMA
 
 # MFMA-busy of the dominant kernels from the builder's SQ-counter pass over a serial 64-frame step (tools/pmc_kernels.sh -> profiles/r04_pmc_kernels_B64.json)
-PMC_BUSY_SRC = ("profiles/r05_pmc_kernels_B64.json (r04 if that round's file is all there is): SQ_VALU_MFMA_BUSY_CYCLES (busy SIMD-cycles, calibrated on a pure MFMA loop) / (launch duration x 1024 SIMDs x 2.4 GHz) from the "
+PMC_BUSY_SRC = ("profiles/r06_pmc_kernels_B64.json (the newest earlier round's file if that one is missing): SQ_VALU_MFMA_BUSY_CYCLES (busy SIMD-cycles, calibrated on a pure MFMA loop) / (launch duration x 1024 SIMDs x 2.4 GHz) from the "
                 "builder's rocprofv3 --pmc pass over a serial 64-frame step; a constant in this run, not an observation of it")
 _pmck = {}
-for _tag in ("r05", "r04"):
+for _tag in ("r06", "r05", "r04"):
     try:
         _pmck = json.load(open(os.path.join(ROOT, "profiles", _tag + "_pmc_kernels_B64.json")))["kernels"]
         break
@@ -349,7 +349,7 @@ def main():
     kname = ("k_conv_mfma<64,64,3,...>" if B > 32 else "k_conv_mfma16<64,64,1,16,2,...> (16x16x4 tiles, the form for batches <= 32)") + " (block3.1, block_fusion.1: 3x3 64->64 at 1/8 res)" + ("" if args.bn != "folded" else ", bias+ReLU epilogue")
     out["roofline"] = {"kernel": kname,
                        "measured": f"HIP events attached to every dispatch of the kernel (hipExtLaunchKernelGGL): the same launches ({B} frames each) with ONE ctx alone on the GPU "
-                                   "right after the timed region -- the kernel's own duration, the view rocprofv3 --kernel-trace gives of a serial run (profiles/r05_roofline_table_B64.md: "
+                                   "right after the timed region -- the kernel's own duration, the view rocprofv3 --kernel-trace gives of a serial run (profiles/r06_roofline_table_B64.md: "
                                    "`bench.py --streams 1 --batch 64 --serial-branch --only-match-leg` under rocprofv3, 191 us per launch on the box whose events read 192)",
                        "bound": "mfma", "achieved": iso_tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": iso_tf / PEAK_F32_MFMA_TFLOPS,
                        "traffic": conv_traffic, "traffic_source": pmc_src if conv_traffic else None,
@@ -875,7 +875,7 @@ def legs(out, args, lib, capi, synth, Context, ctx, blob, frames, d_in, d_recb, 
                                      "note": "an event pair attached to every GEMM dispatch (hipExtLaunchKernelGGL) inside the C loop of two-launch hand-off calls (GEMM, post, GEMM, post, ...), "
                                              "after 60 ms of the same calls.  This view is longer than the kernel: the instrumented dispatch itself costs time (the same loop without the "
                                              "events runs 4-5 us per call faster: us_per_call), and in a busy queue the timestamps of neighbouring dispatches overlap (their sum exceeds "
-                                             "the wall time, DESIGN.md 5).  Rounds 1-3 reported this figure, measured cold, as the roofline"},
+                                             "the wall time, NOTES.md 5).  Rounds 1-3 reported this figure, measured cold, as the roofline"},
                                  "in_raw_rows_call": {"avg_launch_us": gemm_us_raw, "frac": gemm_flop / (gemm_us_raw * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS if gemm_us_raw else 0.0,
                                                       "note": "per-dispatch events inside the C loop of three-launch calls (k_rownorm_img in front), same warm-up"}}}
 
@@ -950,7 +950,7 @@ def legs(out, args, lib, capi, synth, Context, ctx, blob, frames, d_in, d_recb, 
         "measured": "sclk_mhz: shader clocks (s_memtime) per 100 MHz reference tick (s_memrealtime) that workgroup 0 of k_mnn_gemm_seg saw across one launch of the batched "
                     "GEMM (xfh_bench_mnn_gemm_batch); the second figure: xfh_bench_sclk, every SIMD issuing v_mfma_f32_32x32x2_f32 back to back on constant operands. "
                     "f32 MFMAs and VALU instructions share the SIMD's vector pipe on gfx950 (profiles/r04_pipe_probe.log), so the ceiling of the GEMM with its arg-max "
-                    "epilogue is below this peak as well: DESIGN.md 5"}
+                    "epilogue is below this peak as well: NOTES.md 5"}
     for b in (bimgs, brec, bout, bcnt):
         b.free()
 

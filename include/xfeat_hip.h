@@ -131,7 +131,7 @@ size_t xfh_record_desc_offset(int nfeatures);
  * More go into one queue that up to xfh_pipeline_lanes (default 6) internal lanes drain: a lane = a child ctx (own activations and HIP streams,
  * the ctx' weights, built at the first call that needs it) + a copy stream + a host THREAD of the library that drives one sub-batch at a time --
  * copy in, kernels, copy out, each waited for on the host -- so that no copy command ever sits in a stream in front of a kernel and no stream
- * waits for a copy on the GPU; the lanes overlap each other (0.97-0.98 of the device-resident rate, 0.74-0.85 with in-order streams).
+ * waits for a copy on the GPU; the lanes overlap each other (NOTES.md 6: 0.97-0.98 of the device-resident rate, 0.74-0.85 with in-order streams).
  * Cost: every lane is a full child ctx -- activations for cfg.max_batch frames (about 29 MB per VGA frame, i.e. 1.9 GB per lane at max_batch 64) --
  * plus one host thread; they are built at the first submit that spans more than one sub-batch (min(sub-batches, lanes) of them), and that submit is
  * where XFH_ERR_OUT_OF_MEMORY surfaces if the device cannot hold them.  xfh_pipeline_lanes(ctx, n) bounds the number before that call.
