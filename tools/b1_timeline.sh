@@ -14,5 +14,9 @@ t0 = int(rows[a]["Start_Timestamp"])
 print("frame wall", (int(rows[b]["Start_Timestamp"]) - t0) / 1e3, "us (under the profiler)")
 for r in rows[a:b]:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
-    print(f"{(s - t0) / 1e3:8.1f} +{(e - s) / 1e3:6.1f}  q{r.get('Queue_Id', '?'):>3}  {r['Kernel_Name'][:70]}")
+    def dim(k):
+        try: return int(r.get("Grid_Size_" + k, r.get("Grid_Size", 0))) // max(int(r.get("Workgroup_Size_" + k, r.get("Workgroup_Size", 1))), 1)
+        except Exception: return 0
+    wgs = max(dim("X"), 1) * max(dim("Y"), 1) * max(dim("Z"), 1)
+    print(f"{(s - t0) / 1e3:8.1f} +{(e - s) / 1e3:6.1f}  q{r.get('Queue_Id', '?'):>3}  {wgs:5d} wg  {r['Kernel_Name'][:70]}")
 PY

@@ -21,6 +21,7 @@ echo "[$(date +%T)] done: ( timeout 100 tools/probes/pipe_probe ) > O/pipe_probe
 ( timeout 300 bash tools/gemm_b2b.sh ) > /dev/null 2>&1          # -> gemm_b2b.md: the match GEMM back to back from an idle GPU, events and rocprofv3 side by side
 echo "[$(date +%T)] done: ( timeout 300 bash tools/gemm_b2b.sh ) > /dev/null 2>&1     " >> $O/round_times.log
 ( timeout 100 python tools/b1_modes.py ) > $O/b1_modes.log 2>&1
+( timeout 200 bash tools/b1_timeline.sh ) > $O/b1_timeline.log 2>&1
 echo "[$(date +%T)] done: ( timeout 100 python tools/b1_modes.py ) > O/b1_modes.log 2" >> $O/round_times.log
 rm -rf $O/prof $O/pmc_fetch $O/pmc_write $O/prof_serial $O/prof_serial64
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o bench -- python $R/bench.py --steps 20 --match-warm-ms 10 --cpu-frames 0 ) > $O/bench_prof.json 2> $O/bench_prof.err
