@@ -15,7 +15,9 @@
  *       avg_pool2d, interpolate, softmax, max_pool2d, nonzero, grid_sample, argsort,
  *       normalize) and tests/test_oracle.py checks this C code against it, live, stage by stage -- since
  *       round 5 over eleven weight families x eight image families (test_campaign_oracle_vs_aten);
- *   (2) golden vectors produced by (1) are committed under tests/golden/ (nine extraction cases, four matches);
+ *   (2) golden vectors produced by (1) are committed under tests/golden/ -- since round 6 for the whole campaign: 46 extraction cases (every
+ *       weight family at VGA x 2 image families and at 720p, nfeatures = 1000 with the TUM lapping areas) and 9 matches (five on extracted
+ *       descriptor blocks); the same files check the HIP path on the GPU (tests/test_gpu_extract.py, tests/test_gpu_match.py);
  *   (3) exp() of the softmax and the sigmoid is libtorch's own vector kernel (Sleef expf_u10, FMA form), restated
  *       as xfo_expf and checked bit for bit against torch.sigmoid / F.softmax (test_exp_is_atens_vector_exp).
  * None of this is an execution of the reference: parity stays "partial".
