@@ -61,6 +61,34 @@ def test_no_device_fails_loudly():
         Context()
 
 
+def test_rccl_selection_is_explicit_and_reported():
+    """comm.cpp: $XFH_RCCL_LIB names the librccl and nothing is tried behind it; xfh_comm_library() says which file, version and HIP runtime (no GPU
+    needed: dlopen only).  Each case in its own process -- the choice is made once per process."""
+    import subprocess
+    import sys
+    code = ("import sys; from xfeatslam_amd import capi; import ctypes as C; L = capi.lib(); print(L.xfh_comm_library().decode()); "
+            "print(L.xfh_comm_unique_id(C.create_string_buffer(128)) if sys.argv[1] == '1' else 0)")
+    def run(env_lib, want_id=True):          # (a real librccl on a box without a GPU fails ncclGetUniqueId noisily: only its identity is asked for)
+        env = dict(os.environ)
+        env.pop("XFH_RCCL_LIB", None)
+        if env_lib is not None:
+            env["XFH_RCCL_LIB"] = env_lib
+        r = subprocess.run([sys.executable, "-c", code, "1" if want_id else "0"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out = r.stdout.strip().splitlines()
+        return out[-2] if len(out) > 1 else "", int(out[-1])
+    which, rc = run("/nonexistent/librccl.so.1")
+    assert which == "" and rc == capi.ERR_COMM                    # explicit and absent: an error, not a silent fallback to another copy
+    stub = os.path.join(ROOT, "tests", "stubs", "librccl.so.1")
+    if not os.path.exists(stub):
+        subprocess.check_call(["make", "-C", os.path.dirname(stub), "-s"])
+    which, rc = run(stub)
+    assert "tests/stubs/librccl.so.1" in which and "RCCL 0.0.0" in which and "HIP runtime" in which and rc == 0
+    which, _ = run(None, want_id=False)
+    if os.path.exists("/opt/rocm/lib/librccl.so.1"):
+        assert os.path.realpath("/opt/rocm/lib/librccl.so.1") in which and "RCCL 0.0.0" not in which, which
+
+
 def test_descriptor_distance_host(oracle_mod):
     from xfeatslam_amd.extractor import ORBmatcher
     d1, d2 = synth.descriptor_sets(64, 64, noise=0.4, zero_rows=2)

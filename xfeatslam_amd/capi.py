@@ -27,6 +27,7 @@ STATUS = {0: "OK", 1: "INVALID_ARG", 2: "EMPTY_IMAGE", 3: "BAD_SIZE", 4: "NO_WEI
           6: "HIP", 7: "NO_DEVICE", 8: "OUT_OF_MEMORY", 9: "BATCH_TOO_LARGE", 10: "IO", 11: "COMM"}
 ERR_EMPTY_IMAGE = 2
 ERR_NO_DEVICE = 7
+ERR_COMM = 11
 
 K = dict(NONE=0, MNN_GEMM=1, CONV_MFMA=2, CONV_DIRECT=3, NMS=4, SELECT=5, DESC=6, HEADS=7, DIST_I32=8, PREPROC=9, BEST2=10, DISTINCTIVE=11, MNN_GEMM_SEG=12)
 T = dict(X=0, XSTAT=1, SKIP_POOL=2, FEATS=6, H1=8, K1H=9, RAW0=16, STAT0=48, SEL=80)
