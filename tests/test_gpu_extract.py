@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import EXTRACT_GOLDENS, GOLDEN, check_extract_golden, golden_inputs, joined_desc_diff, kp_set, records_equal
+from conftest import CAMPAIGN_GOLDENS, EXTRACT_GOLDENS, GOLDEN, check_extract_golden, golden_inputs, joined_desc_diff, kp_set, records_equal
 from xfeatslam_amd import capi, synth, weights as WT
 
 pytestmark = pytest.mark.gpu
@@ -56,6 +56,30 @@ def test_extract_matches_golden(gpu_lib, name):
     # candidate / valid counts, identical keypoint set, scores and sampled descriptors joined by position; differences only inside a
     # near-tie at the top-k cut (conftest.check_extract_golden prints how many)
     check_extract_golden(g, kps, desc, nv, mono, nc, DESC_TOL)
+
+
+@pytest.mark.parametrize("B", [12, 40])
+@pytest.mark.parametrize("name", [n for n in CAMPAIGN_GOLDENS if n.startswith("c6_vga_") and "nf1000" not in n][::2] + [n for n in CAMPAIGN_GOLDENS if "nf1000" in n][:2])
+def test_batch_regimes_match_golden(gpu_lib, name, B):
+    """round 6: the LARGE-BATCH kernels meet libtorch-operator output first-hand.  test_extract_matches_golden runs one frame per call, i.e. the single-frame forms
+    (16x16x4 MFMA tiles, consumers folding the statistics, riders); a sub-batch of 12 runs the finalize kernels and the second stream, one of 40 the 32x32x2
+    persistent / streamed forms the bench runs.  The golden's frame sits at positions 0 and B - 1 of a batch of otherwise different frames (statistics are per
+    frame: the neighbours must not matter) and both records are checked against the ATen fixture with the checker of the single-frame test."""
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    H, W, nf = int(g["H"]), int(g["W"]), int(g["nfeatures"])
+    w, img = golden_inputs(g)
+    def other(i):          # a different frame, cheap to make: the golden's frame shifted and re-scaled in brightness
+        return np.clip(np.roll(img, 13 * i, axis=1).astype(np.int32) * (3 + i % 5) // 4 + (i % 3) * 9, 0, 255).astype(np.uint8)
+    fr = np.stack([img if i in (0, B - 1) else other(i) for i in range(B)])
+    ctx = _ctx(nf, H, W, B=B)
+    ctx.load_weights(WT.pack_blob(w))
+    recs = ctx.extract_batch(fr, tuple(int(v) for v in g["lap"]))
+    ctx.close()
+    for pos in (0, B - 1):
+        kps, desc, nv, mono, nc = recs[pos]
+        check_extract_golden(g, kps, desc, nv, mono, nc, DESC_TOL)
+    for a, b in zip(recs[0], recs[B - 1]):
+        assert np.array_equal(a, b)                                   # same frame, same record, wherever it sits in the batch
 
 
 def test_config3_batch8_720p_device_resident(gpu_lib, oracle_mod):

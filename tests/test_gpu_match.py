@@ -82,6 +82,29 @@ def test_mnn_matches_golden_extracted(mctx, name):
     assert np.array_equal(mctx.distance_i32(d1[-24:], d2[-24:]), g["dist_i32_tail"])
 
 
+def test_mnn_batched_call_matches_every_golden(mctx):
+    """round 6: the many-pairs path (k_mnn_gemm_seg + k_mnn_post_batch, xfh_match_mnn_prepared_batch_device) meets libtorch's lists first-hand: all nine match
+    goldens -- Gaussian rows and extracted descriptor blocks, square, ragged, with zero and duplicate rows -- as the pairs of ONE call (and each pair twice, so
+    that a workgroup walks tiles of different pairs)."""
+    names = ["match_256", "match_300x200_zero7", "match_4096", "match_4096_zero100"] + list(MATCH_X_GOLDENS)
+    gs, preps = [], []
+    for name in names:
+        g = np.load(os.path.join(GOLDEN, name + ".npz"))
+        if name in MATCH_X_GOLDENS:
+            d1, d2 = match_x_inputs(g)
+        else:
+            d1, d2 = synth.descriptor_sets(int(g["n1"]), int(g["n2"]), zero_rows=int(g["zero_rows"]), noise=float(g["noise"]))
+        gs.append(g); preps.append((mctx.match_prepare(d1), mctx.match_prepare(d2)))
+    res = mctx.match_mnn_prepared_batch(preps + preps[::-1])
+    assert len(res) == 2 * len(names)
+    for k, (name, g) in enumerate(zip(names, gs)):
+        for r in (res[k], res[2 * len(names) - 1 - k]):
+            assert np.array_equal(r[0], g["idx1"]) and np.array_equal(r[1], g["idx2"]), name
+            assert np.allclose(r[2], g["dist"], atol=2e-6, equal_nan=True), name
+    for a, b in preps:
+        a[0].free(); b[0].free()
+
+
 def test_mnn_edge_cases(mctx, oracle_mod):
     d1, d2 = synth.descriptor_sets(200, 180, noise=0.2)
     # duplicate rows => exact ties; first maximum (lowest index) wins on both axes
