@@ -103,30 +103,45 @@ def test_extraction_soak_eval_modes(gpu_lib, H, W, B, iters, mode):
 @pytest.mark.parametrize("n1,n2,iters", [(4096, 4096, 6000), (1000, 777, 4000), (257, 4097, 4000)])
 def test_prepared_match_soak(gpu_lib, oracle_mod, n1, n2, iters):
     """back-to-back prepared-image matches (k_mnn_gemm_img + k_mnn_post: LDS-DMA pipeline, plane keys, collectors that poll the pairs the writers
-    publish and that the next call's GEMM re-arms): the list of every call equals the oracle's"""
+    publish and that the next call's GEMM re-arms): the list of every call equals the oracle's.  Round 6: consecutive calls ALTERNATE between two different
+    descriptor pairs (and the two roles of one of them), so a key plane or a (column, value) pair left over from the previous call -- the scratch is the same
+    memory every call, and an agent-scope load is not by itself proof against a stale line in another XCD's L2 (tools/probes/mnn_tail_probe.hip) -- would give
+    a wrong list instead of silently the right one."""
     from xfeatslam_amd.extractor import Context
     lib = capi.lib()
-    d1, d2 = synth.descriptor_sets(n1, n2, zero_rows=3, noise=0.3, seed=9)
-    d2[5] = d2[2]
-    want = oracle_mod.match_mnn(d1, d2)
+    sets = []
+    for seed, noise, swap in ((9, 0.3, False), (10, 0.45, False), (9, 0.3, True)):
+        d1, d2 = synth.descriptor_sets(n1, n2, zero_rows=3, noise=noise, seed=seed)
+        d2[5] = d2[2]
+        if swap and n1 == n2:
+            d1, d2 = d2, d1
+        elif swap:
+            d1 = d1[::-1].copy()
+        sets.append((d1, d2, oracle_mod.match_mnn(d1, d2)))
+    assert not np.array_equal(sets[0][2][1], sets[1][2][1])
     ctx = Context(nfeatures=64, max_height=32, max_width=32)
     busy, kick, bufs = _busy_ctx(lib, WT.pack_blob(WT.make_synthetic(1234, 6.0)), synth.frames(4, 96, 160, seed=5))
     try:
-        p1, p2 = ctx.match_prepare(d1), ctx.match_prepare(d2)
+        prep = [(ctx.match_prepare(d1), ctx.match_prepare(d2)) for d1, d2, _ in sets]
         nm = min(n1, n2)
         out = capi.DeviceBuffer(12 * nm + 64)
         for it in range(iters):
             if it % 4 == 1:
                 kick()
+            k3 = (it * 7) % 3 if it % 5 else it % 3                 # which pair this call matches: changes from call to call, in no fixed rhythm with the reads below
+            p1, p2 = prep[k3]
             capi.check(lib.xfh_match_mnn_prepared_device(ctx.h, p1[0].ptr, n1, p2[0].ptr, n2, -1.0, out.ptr + 64, out.ptr + 64 + 4 * nm, out.ptr + 64 + 8 * nm, out.ptr), ctx.h)
             if it % 3 == 0:                              # two of three calls run back to back on the stream, the third is read
+                want = sets[k3][2]
                 ctx.synchronize()
                 k = int(out.download(np.int32, 1)[0])
-                assert k == len(want[0]), (it, k)
-                assert np.array_equal(out.download(np.int32, k, 64), want[0]) and np.array_equal(out.download(np.int32, k, 64 + 4 * nm), want[1]), it
-                assert np.array_equal(out.download(np.float32, k, 64 + 8 * nm), want[2], equal_nan=True), it
+                assert k == len(want[0]), (it, k3, k)
+                assert np.array_equal(out.download(np.int32, k, 64), want[0]) and np.array_equal(out.download(np.int32, k, 64 + 4 * nm), want[1]), (it, k3)
+                assert np.array_equal(out.download(np.float32, k, 64 + 8 * nm), want[2], equal_nan=True), (it, k3)
         busy.synchronize()
-        p1[0].free(); p2[0].free(); out.free()
+        for a, b in prep:
+            a[0].free(); b[0].free()
+        out.free()
     finally:
         ctx.close(); busy.close()
 
@@ -147,23 +162,26 @@ def test_batched_match_soak(gpu_lib, oracle_mod):
                 d2[7] = d2[1]
             data.append((d1, d2)); prepared.append((ctx.match_prepare(d1), ctx.match_prepare(d2))); want.append(oracle_mod.match_mnn(d1, d2))
         P = len(shapes)
-        nm = [min(a, b) for a, b in shapes]
-        off = np.concatenate([[0], np.cumsum([12 * k + 64 for k in nm])]).astype(np.int64)
+        NM = 4096                                          # every output slot holds the largest pair: the pairs ROTATE through the slots from call to call (round 6),
+        off = np.arange(P + 1, dtype=np.int64) * (12 * NM + 64)      # so every piece of the call's scratch meets other data than in the call before (stale planes / pairs would show)
         out = capi.DeviceBuffer(int(off[-1])); cnt = capi.DeviceBuffer(4 * P + 64)
-        p1, n1, p2, n2 = ctx.pair_tables(prepared)
-        i1 = (C.c_void_p * P)(*[out.ptr + int(off[p]) for p in range(P)]); i2 = (C.c_void_p * P)(*[out.ptr + int(off[p]) + 4 * nm[p] for p in range(P)])
-        ds = (C.c_void_p * P)(*[out.ptr + int(off[p]) + 8 * nm[p] for p in range(P)])
+        i1 = (C.c_void_p * P)(*[out.ptr + int(off[p]) for p in range(P)]); i2 = (C.c_void_p * P)(*[out.ptr + int(off[p]) + 4 * NM for p in range(P)])
+        ds = (C.c_void_p * P)(*[out.ptr + int(off[p]) + 8 * NM for p in range(P)])
+        tables = [ctx.pair_tables(prepared[r:] + prepared[:r]) for r in range(P)]
         for it in range(900):
             if it % 4 == 1:
                 kick()
+            r = (it * 3) % P if it % 2 else (it // 2) % P
+            p1, n1, p2, n2 = tables[r]
             capi.check(lib.xfh_match_mnn_prepared_batch_device(ctx.h, P, p1, n1, p2, n2, -1.0, i1, i2, ds, cnt.ptr), ctx.h)
             if it % 3 == 0:
                 ctx.synchronize()
                 ks = cnt.download(np.int32, P)
                 for p in range(P):
+                    w = want[(p + r) % P]
                     k = int(ks[p])
-                    assert k == len(want[p][0]), (it, p, k)
-                    assert np.array_equal(out.download(np.int32, k, int(off[p])), want[p][0]) and np.array_equal(out.download(np.int32, k, int(off[p]) + 4 * nm[p]), want[p][1]), (it, p)
+                    assert k == len(w[0]), (it, r, p, k)
+                    assert np.array_equal(out.download(np.int32, k, int(off[p])), w[0]) and np.array_equal(out.download(np.int32, k, int(off[p]) + 4 * NM), w[1]), (it, r, p)
         busy.synchronize()
         for a, b in prepared:
             a[0].free(); b[0].free()
