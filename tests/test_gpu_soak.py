@@ -35,23 +35,27 @@ def test_extraction_soak(gpu_lib, oracle_mod, H, W, B, iters):
     lib = capi.lib()
     nf = 512 if H < 480 else 4096
     blob = WT.pack_blob(WT.make_synthetic(1234, 6.0))
-    frames = synth.frames(B, H, W, seed=21)
+    # two different frame sets, alternating from call to call (round 6): every intermediate buffer of the ctx -- statistic partials, folded statistics, raw maps,
+    # candidate lists -- then holds ANOTHER call's values when a call starts, so a consumer that read a left-over instead of its producer's output would show
+    fsets = [synth.frames(B, H, W, seed=21), synth.frames(B, H, W, seed=22)[::-1].copy()]
     ctx = Context(nfeatures=nf, max_height=H, max_width=W, max_batch=B)
     busy, kick, bufs = _busy_ctx(lib, blob, synth.frames(4, 96, 160, seed=5))
     try:
         ctx.load_weights(blob)
-        din = capi.DeviceBuffer(frames.nbytes).upload(frames)
+        dins = [capi.DeviceBuffer(f.nbytes).upload(f) for f in fsets]
         rec = capi.DeviceBuffer(B * ctx.rec_bytes).upload(np.zeros(B * ctx.rec_bytes, np.uint8))
-        first = None
+        first = [None, None]
         for it in range(iters):
             if it % 2:
                 kick()                                   # the other ctx' kernels share the CUs with this iteration
-            capi.check(lib.xfh_extract_batch_device(ctx.h, din.ptr, B, H, W, 0, 0, rec.ptr), ctx.h)
+            k2 = (it // 3 + it) % 2                      # which frame set: AB BA AB ... (both orders of succession occur)
+            frames = fsets[k2]
+            capi.check(lib.xfh_extract_batch_device(ctx.h, dins[k2].ptr, B, H, W, 0, 0, rec.ptr), ctx.h)
             ctx.synchronize()
             raw = rec.download(np.uint8, B * ctx.rec_bytes)
-            if first is None:
-                first = raw
-                # iteration 0 is the oracle's result (frame 0 and the last frame)
+            if first[k2] is None:
+                first[k2] = raw
+                # the first result of each set is the oracle's result (frame 0 and the last frame)
                 recs = ctx.parse_records(raw, B)
                 orc = oracle_mod.Oracle(blob)
                 for b in sorted({0, B - 1}):
@@ -61,7 +65,8 @@ def test_extraction_soak(gpu_lib, oracle_mod, H, W, B, iters):
                     assert (nv, mono) == (onv, omono)
                     assert set(zip(kps["x"][v1].astype(int), kps["y"][v1].astype(int))) == set(zip(ok["x"][v2].astype(int), ok["y"][v2].astype(int)))
             else:
-                assert np.array_equal(raw, first), f"iteration {it}: records differ from iteration 0 (first byte {int(np.argmax(raw != first))})"
+                assert np.array_equal(raw, first[k2]), f"iteration {it} (set {k2}): records differ from the set's first result (first byte {int(np.argmax(raw != first[k2]))})"
+        assert not np.array_equal(first[0], first[1])
         busy.synchronize()
     finally:
         ctx.close(); busy.close()
